@@ -1,0 +1,194 @@
+/* omega_amd.h -- C ABI of libomega_amd.so, the MI355X-native compute backend for the
+ * Omega ocean-dycore hot path (Tendencies + AuxiliaryState + TimeStepper + Halo).
+ *
+ * Omega has no FFI layer: its "operator API" for this path is a set of C++ classes
+ * (O/ = components/omega/ in the reference tree).  Each entry point below names the
+ * reference interface it replaces.  The same classes exist in C++ under omega_amd/csrc/
+ * (namespace OMEGA, same class and method names) for a source-level drop-in; this C ABI
+ * is the boundary a non-C++ host (or a test harness) binds.  See INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; omg_last_error() returns the
+ *    message of the last failure on the calling thread (reference: int return codes of
+ *    Halo/OceanState and the ABORT_ERROR macro, O/src/infra/Error.h:207-270);
+ *  - arrays are LayoutRight doubles / int32, vertical index innermost, NXxSize = NXxAll+1
+ *    rows with a zero sentinel row (O/src/base/DataTypes.h:58-94, O/src/base/Decomp.cpp:1082);
+ *  - `stream` arguments are hipStream_t passed as void* (NULL = default stream); every
+ *    compute call is asynchronous on that stream;
+ *  - no function falls back to the CPU: without a HIP device every device call fails.
+ */
+#ifndef OMEGA_AMD_H
+#define OMEGA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct omg_decomp omg_decomp;   /* O/src/base/Decomp.h   class Decomp        */
+typedef struct omg_halo omg_halo;       /* O/src/base/Halo.h     class Halo          */
+typedef struct omg_mesh omg_mesh;       /* O/src/ocn/HorzMesh.h  class HorzMesh      */
+typedef struct omg_state omg_state;     /* O/src/ocn/OceanState.h class OceanState   */
+typedef struct omg_tracers omg_tracers; /* O/src/ocn/Tracers.h   class Tracers       */
+typedef struct omg_aux omg_aux;         /* O/src/ocn/AuxiliaryState.h                */
+typedef struct omg_tend omg_tend;       /* O/src/ocn/Tendencies.h                    */
+typedef struct omg_stepper omg_stepper; /* O/src/timeStepping/TimeStepper.h          */
+
+enum { OMG_ON_CELL = 0, OMG_ON_EDGE = 1, OMG_ON_VERTEX = 2 }; /* O/src/base/Halo.h:45 MeshElement */
+
+const char *omg_last_error(void);
+
+/* ---- device / stream / event plumbing (Kokkos::initialize, Kokkos::fence, Pacer timers) ---- */
+int omg_device_count(int *n);
+int omg_device_init(int device_id);
+int omg_device_synchronize(void);
+int omg_stream_create(void **stream);
+int omg_stream_destroy(void *stream);
+int omg_stream_synchronize(void *stream);
+int omg_event_create(void **event);
+int omg_event_destroy(void *event);
+int omg_event_record(void *event, void *stream);
+int omg_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+
+/* ---- global mesh as read from an MPAS mesh file (O/src/base/Decomp.cpp:108-395 readMesh,
+ *      O/src/ocn/HorzMesh.cpp:424-523 read*).  Host pointers; indices 0-based, -1 = missing. ---- */
+typedef struct omg_global_mesh {
+   int32_t nCells, nEdges, nVertices, maxEdges, vertexDegree;
+   const int32_t *cellsOnCell, *edgesOnCell, *verticesOnCell; /* [nCells][maxEdges]      */
+   const int32_t *cellsOnEdge, *verticesOnEdge;               /* [nEdges][2]             */
+   const int32_t *edgesOnEdge;                                /* [nEdges][2*maxEdges]    */
+   const int32_t *cellsOnVertex, *edgesOnVertex;              /* [nVertices][vertexDegree] */
+   const double *xCell, *yCell, *zCell, *lonCell, *latCell;
+   const double *xEdge, *yEdge, *zEdge, *lonEdge, *latEdge;
+   const double *xVertex, *yVertex, *zVertex, *lonVertex, *latVertex;
+   const double *areaCell, *areaTriangle, *kiteAreasOnVertex; /* kite: [nVertices][vertexDegree] */
+   const double *dcEdge, *dvEdge, *angleEdge, *weightsOnEdge; /* weights: [nEdges][2*maxEdges]   */
+   const double *fCell, *fEdge, *fVertex, *bottomDepth;
+} omg_global_mesh;
+
+/* ---- Decomp (O/src/base/Decomp.cpp:444-745 constructor; Decomp.h:189-260 members).
+ *      cell_task: optional [nCells] owner task of each cell (e.g. a METIS part file);
+ *      NULL = built-in recursive coordinate bisection.  The global mesh arrays must stay
+ *      alive until meshes / halos built from the decomp have been created. ---- */
+int omg_decomp_create(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
+                      const int32_t *cell_task, omg_decomp **out);
+int omg_decomp_destroy(omg_decomp *d);
+/* scalar members by reference name: "NCellsOwned", "NCellsAll", "NCellsSize", "NCellsGlobal",
+ * "NEdges...", "NVertices...", "MaxEdges", "VertexDegree", "HaloWidth" */
+int omg_decomp_get_int(const omg_decomp *d, const char *name, int32_t *out);
+/* array members: "CellID" "EdgeID" "VertexID" (1-based global ids, [NXxSize]), "CellLoc"
+ * "EdgeLoc" "VertexLoc" ([NXxSize][2]), "NCellsHalo" "NEdgesHalo" "NVerticesHalo"
+ * ([HaloWidth]), "CellTask" ([NCellsGlobal]); n = capacity of out in elements */
+int omg_decomp_get_array(const omg_decomp *d, const char *name, int32_t *out, size_t n);
+
+/* ---- Halo (O/src/base/Halo.cpp:150-201 constructor, :455-600 exchange lists;
+ *      Halo.h:767-915 exchangeFullArrayHalo) ---- */
+typedef int (*omg_transport_fn)(void *ctx, int n_neighbors, const int *tasks, void *const *send_ptrs,
+                                const size_t *send_bytes, void *const *recv_ptrs, const size_t *recv_bytes,
+                                void *stream);
+int omg_halo_create(const omg_decomp *d, omg_halo **out);
+int omg_halo_destroy(omg_halo *h);
+int omg_halo_num_neighbors(const omg_halo *h, int *n);
+int omg_halo_neighbor_task(const omg_halo *h, int i, int *task);
+int omg_halo_list_size(const omg_halo *h, int i, int elem, int recv, int *n);
+int omg_halo_get_list(const omg_halo *h, int i, int elem, int recv, int32_t *out);
+int omg_halo_required_bytes(const omg_halo *h, int i, size_t per_cell, size_t per_edge, size_t per_vertex,
+                            size_t *bytes);
+int omg_halo_set_buffers(omg_halo *h, int i, void *send_dev, void *recv_dev, size_t bytes);
+int omg_halo_set_transport(omg_halo *h, omg_transport_fn fn, void *ctx);
+/* Halo::exchangeFullArrayHalo on a raw device array [nt][rows_size][k] (nt = 1 for 2-D) */
+int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int elem, void *stream);
+
+/* ---- HorzMesh (O/src/ocn/HorzMesh.cpp:44-140 constructor; HorzMesh.h:100-265 members).
+ *      host_only != 0 builds the host arrays only (no device mirrors; compute calls fail). ---- */
+int omg_mesh_create(const omg_decomp *d, int nvertlayers, int host_only, omg_mesh **out);
+int omg_mesh_destroy(omg_mesh *m);
+int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out);
+int omg_mesh_get_array_i4(const omg_mesh *m, const char *name, int32_t *out, size_t n);
+int omg_mesh_get_array_r8(const omg_mesh *m, const char *name, double *out, size_t n);
+int omg_mesh_set_fvertex(omg_mesh *m, const double *host_values /* [NVerticesSize] */);
+
+/* ---- options (O/configs/Default.yml:25-52; Tendencies::readTendConfig O/src/ocn/Tendencies.cpp:123-213;
+ *      AuxiliaryState::readConfigOptions O/src/ocn/AuxiliaryState.cpp:259-308) ---- */
+typedef struct omg_tend_config {
+   int32_t ThicknessFluxTendencyEnable, PVTendencyEnable, KETendencyEnable, SSHTendencyEnable,
+       VelDiffTendencyEnable, VelHyperDiffTendencyEnable, WindForcingTendencyEnable, BottomDragTendencyEnable,
+       TracerHorzAdvTendencyEnable, TracerDiffTendencyEnable, TracerHyperDiffTendencyEnable;
+   int32_t FluxThicknessUpwind, FluxTracerUpwind, WindInterpIsotropic;
+   double ViscDel2, ViscDel4, DivFactor, EddyDiff2, EddyDiff4, Density0, BottomDragCoeff;
+} omg_tend_config;
+void omg_tend_config_default(omg_tend_config *c);
+
+/* ---- OceanState (O/src/ocn/OceanState.h:100-149; OceanState.cpp:247-407).  time_level:
+ *      1 = new, 0 = current, -1 = previous.  halo may be NULL on a single rank. ---- */
+int omg_state_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int ntimelevels, omg_state **out);
+int omg_state_destroy(omg_state *s);
+int omg_state_copy_to_device(omg_state *s, int time_level, const double *h_host, const double *u_host);
+int omg_state_copy_to_host(const omg_state *s, int time_level, double *h_host, double *u_host);
+int omg_state_device_ptr(const omg_state *s, int time_level, int which /*0 h, 1 u*/, double **dev);
+int omg_state_exchange_halo(omg_state *s, int time_level, void *stream);
+int omg_state_update_time_levels(omg_state *s, void *stream);
+
+/* ---- Tracers (O/src/ocn/Tracers.cpp:269 getAll, :457-496 exchangeHalo/updateTimeLevels) ---- */
+int omg_tracers_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int ntracers, int ntimelevels,
+                       omg_tracers **out);
+int omg_tracers_destroy(omg_tracers *t);
+int omg_tracers_copy_to_device(omg_tracers *t, int time_level, const double *host);
+int omg_tracers_copy_to_host(const omg_tracers *t, int time_level, double *host);
+int omg_tracers_device_ptr(const omg_tracers *t, int time_level, double **dev);
+int omg_tracers_exchange_halo(omg_tracers *t, int time_level, void *stream);
+int omg_tracers_update_time_levels(omg_tracers *t, void *stream);
+
+/* ---- AuxiliaryState (O/src/ocn/AuxiliaryState.h:49-82; AuxiliaryState.cpp:60-191) ---- */
+int omg_aux_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int ntracers, omg_aux **out);
+int omg_aux_destroy(omg_aux *a);
+int omg_aux_set_options(omg_aux *a, int flux_thickness_upwind, int flux_tracer_upwind, int wind_interp_isotropic);
+int omg_aux_compute_mom_aux(omg_aux *a, const omg_state *s, int thick_time_level, int vel_time_level, void *stream);
+int omg_aux_compute_all(omg_aux *a, const omg_state *s, const omg_tracers *t, int tracer_time_level,
+                        int thick_time_level, int vel_time_level, void *stream);
+/* array by reference member name ("KineticEnergyCell", "VelocityDivCell", "FluxLayerThickEdge",
+ * "MeanLayerThickEdge", "SshCell", "RelVortVertex", "NormRelVortVertex", "NormPlanetVortVertex",
+ * "NormRelVortEdge", "NormPlanetVortEdge", "Del2Edge", "Del2DivCell", "Del2RelVortVertex",
+ * "HTracersEdge", "Del2TracersCell", "NormalStressEdge", "ZonalStressCell", "MeridStressCell") */
+int omg_aux_copy_to_host(const omg_aux *a, const char *name, double *host, size_t n);
+int omg_aux_copy_to_device(omg_aux *a, const char *name, const double *host, size_t n);
+int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t *n);
+
+/* ---- Tendencies (O/src/ocn/Tendencies.h:73-102; Tendencies.cpp:257-600) ---- */
+int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out);
+int omg_tend_destroy(omg_tend *t);
+int omg_tend_set_fused(omg_tend *t, int use_fused_rhs);
+int omg_tend_compute_all(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr, int tracer_time_level,
+                         int thick_time_level, int vel_time_level, void *stream);
+int omg_tend_compute_thickness(omg_tend *t, const omg_state *s, omg_aux *a, int thick_time_level,
+                               int vel_time_level, void *stream);
+int omg_tend_compute_velocity(omg_tend *t, const omg_state *s, omg_aux *a, int thick_time_level, int vel_time_level,
+                              void *stream);
+int omg_tend_compute_tracer(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr,
+                            int tracer_time_level, int thick_time_level, int vel_time_level, void *stream);
+int omg_tend_compute_thickness_only(omg_tend *t, const omg_state *s, omg_aux *a, int thick_time_level,
+                                    int vel_time_level, void *stream);
+int omg_tend_compute_velocity_only(omg_tend *t, const omg_state *s, omg_aux *a, int thick_time_level,
+                                   int vel_time_level, void *stream);
+int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr,
+                                 int tracer_time_level, int thick_time_level, int vel_time_level, void *stream);
+/* which: 0 LayerThicknessTend [NCellsSize][K], 1 NormalVelocityTend [NEdgesSize][K],
+ *        2 TracerTend [NT][NCellsSize][K] */
+int omg_tend_copy_to_host(const omg_tend *t, int which, double *host, size_t n);
+int omg_tend_device_ptr(const omg_tend *t, int which, double **dev, size_t *n);
+
+/* ---- TimeStepper (O/src/timeStepping/TimeStepper.h:57-139 create/doStep;
+ *      RungeKutta4Stepper.cpp:68-137, RungeKutta2Stepper.cpp:27-73, ForwardBackwardStepper.cpp:27-82).
+ *      type: "Forward-Backward" | "RungeKutta4" | "RungeKutta2" (TimeStepper.h:64-75) ---- */
+int omg_stepper_create(const char *type, double time_step_seconds, omg_tend *t, omg_aux *a, const omg_mesh *m,
+                       omg_halo *halo, omg_tracers *tr, omg_stepper **out);
+int omg_stepper_destroy(omg_stepper *st);
+int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream);
+int omg_stepper_coeff_seconds(double mult, double time_step_seconds, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,536 @@
+"""omega_amd -- Python binding of libomega_amd.so (include/omega_amd.h).
+
+Thin ctypes plumbing used by tests/, bench.py and __graft_entry__.py: the product is the
+C++/HIP library under omega_amd/csrc (classes named after Omega's own: Decomp, Halo,
+HorzMesh, OceanState, Tracers, AuxiliaryState, Tendencies, TimeStepper).  There is no
+Python or CPU implementation of the hot path here: if the shared library is missing,
+importing the binding raises, and without a HIP device every device call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libomega_amd.so")
+
+ON_CELL, ON_EDGE, ON_VERTEX = 0, 1, 2
+
+PD = C.POINTER(C.c_double)
+PI = C.POINTER(C.c_int32)
+
+
+class OmegaAmdError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libomega_amd.so for gfx950 with hipcc (omega_amd/csrc/Makefile)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "-s"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class GlobalMeshC(C.Structure):
+    _I = ("cellsOnCell", "edgesOnCell", "verticesOnCell", "cellsOnEdge", "verticesOnEdge", "edgesOnEdge",
+          "cellsOnVertex", "edgesOnVertex")
+    _R = ("xCell", "yCell", "zCell", "lonCell", "latCell", "xEdge", "yEdge", "zEdge", "lonEdge", "latEdge",
+          "xVertex", "yVertex", "zVertex", "lonVertex", "latVertex", "areaCell", "areaTriangle",
+          "kiteAreasOnVertex", "dcEdge", "dvEdge", "angleEdge", "weightsOnEdge", "fCell", "fEdge", "fVertex",
+          "bottomDepth")
+    _fields_ = ([(n, C.c_int32) for n in ("nCells", "nEdges", "nVertices", "maxEdges", "vertexDegree")]
+                + [(n, PI) for n in _I] + [(n, PD) for n in _R])
+
+
+CONFIG_FLAGS = ("ThicknessFluxTendencyEnable", "PVTendencyEnable", "KETendencyEnable", "SSHTendencyEnable",
+                "VelDiffTendencyEnable", "VelHyperDiffTendencyEnable", "WindForcingTendencyEnable",
+                "BottomDragTendencyEnable", "TracerHorzAdvTendencyEnable", "TracerDiffTendencyEnable",
+                "TracerHyperDiffTendencyEnable", "FluxThicknessUpwind", "FluxTracerUpwind", "WindInterpIsotropic")
+CONFIG_REALS = ("ViscDel2", "ViscDel4", "DivFactor", "EddyDiff2", "EddyDiff4", "Density0", "BottomDragCoeff")
+
+
+class TendConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in CONFIG_FLAGS] + [(n, C.c_double) for n in CONFIG_REALS]
+
+
+TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, PI, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p)
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OmegaAmdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). omega_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.omg_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OmegaAmdError(lib().omg_last_error().decode())
+
+
+def _pd(a):
+    if a is None:
+        return PD()
+    assert a.dtype == np.float64 and a.flags.c_contiguous, "need C-contiguous float64"
+    return a.ctypes.data_as(PD)
+
+
+def _pi(a):
+    if a is None:
+        return PI()
+    assert a.dtype == np.int32 and a.flags.c_contiguous, "need C-contiguous int32"
+    return a.ctypes.data_as(PI)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _chk(lib().omg_device_count(C.byref(n)))
+    return n.value
+
+
+def device_init(dev: int = 0):
+    _chk(lib().omg_device_init(dev))
+
+
+def device_synchronize():
+    _chk(lib().omg_device_synchronize())
+
+
+class Stream:
+    def __init__(self, handle=None):
+        self.own = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            _chk(lib().omg_stream_create(C.byref(h)))
+            handle = h.value
+        self.h = C.c_void_p(handle)
+
+    def synchronize(self):
+        _chk(lib().omg_stream_synchronize(self.h))
+
+    def __del__(self):
+        try:
+            if self.own and self.h:
+                lib().omg_stream_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        h = C.c_void_p()
+        _chk(lib().omg_event_create(C.byref(h)))
+        self.h = h
+
+    def record(self, stream: "Stream | None"):
+        _chk(lib().omg_event_record(self.h, stream.h if stream else None))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float()
+        _chk(lib().omg_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().omg_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _sh(s):
+    return s.h if s is not None else None
+
+
+class GlobalMesh:
+    """Keeps the numpy arrays of a meshgen mesh alive behind an omg_global_mesh."""
+
+    def __init__(self, g: dict):
+        self.g = g
+        self.keep = {}
+        s = GlobalMeshC()
+        s.nCells, s.nEdges, s.nVertices = g["nCells"], g["nEdges"], g["nVertices"]
+        s.maxEdges, s.vertexDegree = g["maxEdges"], g["vertexDegree"]
+        for n in GlobalMeshC._I:
+            a = np.ascontiguousarray(g[n], dtype=np.int32)
+            self.keep[n] = a
+            setattr(s, n, _pi(a))
+        for n in GlobalMeshC._R:
+            a = np.ascontiguousarray(g[n], dtype=np.float64)
+            self.keep[n] = a
+            setattr(s, n, _pd(a))
+        self.s = s
+
+
+class Decomp:
+    def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None):
+        self.gm = gm
+        h = C.c_void_p()
+        ct = None if cell_task is None else np.ascontiguousarray(cell_task, dtype=np.int32)
+        _chk(lib().omg_decomp_create(C.byref(gm.s), nparts, mytask, halo_width, _pi(ct), C.byref(h)))
+        self.h = h
+
+    def get_int(self, name: str) -> int:
+        v = C.c_int32()
+        _chk(lib().omg_decomp_get_int(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def get_array(self, name: str) -> np.ndarray:
+        hw = self.get_int("HaloWidth")
+        shapes = {"CellID": (self.get_int("NCellsSize"),), "EdgeID": (self.get_int("NEdgesSize"),),
+                  "VertexID": (self.get_int("NVerticesSize"),), "CellLoc": (self.get_int("NCellsSize"), 2),
+                  "EdgeLoc": (self.get_int("NEdgesSize"), 2), "VertexLoc": (self.get_int("NVerticesSize"), 2),
+                  "NCellsHalo": (hw,), "NEdgesHalo": (hw,), "NVerticesHalo": (hw,),
+                  "CellTask": (self.get_int("NCellsGlobal"),)}
+        out = np.zeros(shapes[name], dtype=np.int32)
+        _chk(lib().omg_decomp_get_array(self.h, name.encode(), _pi(out), C.c_size_t(out.size)))
+        return out
+
+    def __del__(self):
+        try:
+            lib().omg_decomp_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Halo:
+    def __init__(self, decomp: Decomp):
+        self.decomp = decomp
+        h = C.c_void_p()
+        _chk(lib().omg_halo_create(decomp.h, C.byref(h)))
+        self.h = h
+        self._cb = None
+        self._bufs = None
+
+    @property
+    def neighbors(self):
+        n = C.c_int()
+        _chk(lib().omg_halo_num_neighbors(self.h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            t = C.c_int()
+            _chk(lib().omg_halo_neighbor_task(self.h, i, C.byref(t)))
+            out.append(t.value)
+        return out
+
+    def get_list(self, i: int, elem: int, recv: bool) -> np.ndarray:
+        n = C.c_int()
+        _chk(lib().omg_halo_list_size(self.h, i, elem, int(recv), C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        _chk(lib().omg_halo_get_list(self.h, i, elem, int(recv), _pi(out)))
+        return out[: n.value]
+
+    def required_bytes(self, i: int, per_cell: int, per_edge: int, per_vertex: int = 0) -> int:
+        b = C.c_size_t()
+        _chk(lib().omg_halo_required_bytes(self.h, i, C.c_size_t(per_cell), C.c_size_t(per_edge), C.c_size_t(per_vertex), C.byref(b)))
+        return b.value
+
+    def set_buffers(self, i: int, send_ptr: int, recv_ptr: int, nbytes: int):
+        _chk(lib().omg_halo_set_buffers(self.h, i, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_size_t(nbytes)))
+
+    def set_transport(self, fn):
+        """fn(tasks, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream_handle) -> int"""
+        def _cb(_ctx, n, tasks, sp, sb, rp, rb, stream):
+            try:
+                return int(fn([tasks[i] for i in range(n)], [sp[i] for i in range(n)], [sb[i] for i in range(n)],
+                              [rp[i] for i in range(n)], [rb[i] for i in range(n)], stream) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = TRANSPORT_FN(_cb)
+        _chk(lib().omg_halo_set_transport(self.h, self._cb, None))
+
+    def exchange(self, dev_ptr: int, nt: int, rows_size: int, k: int, elem: int, stream=None):
+        _chk(lib().omg_halo_exchange(self.h, C.cast(C.c_void_p(dev_ptr), PD), nt, rows_size, k, elem, _sh(stream)))
+
+    def __del__(self):
+        try:
+            lib().omg_halo_destroy(self.h)
+        except Exception:
+            pass
+
+
+_MESH_I4 = {"CellsOnCell": ("C", "ME"), "EdgesOnCell": ("C", "ME"), "NEdgesOnCell": ("C",),
+            "VerticesOnCell": ("C", "ME"), "CellsOnEdge": ("E", 2), "EdgesOnEdge": ("E", "ME2"),
+            "NEdgesOnEdge": ("E",), "VerticesOnEdge": ("E", 2), "CellsOnVertex": ("V", "VD"),
+            "EdgesOnVertex": ("V", "VD")}
+_MESH_R8 = {"AreaCell": ("C",), "AreaTriangle": ("V",), "KiteAreasOnVertex": ("V", "VD"), "DvEdge": ("E",),
+            "DcEdge": ("E",), "AngleEdge": ("E",), "WeightsOnEdge": ("E", "ME2"), "FEdge": ("E",), "FCell": ("C",),
+            "FVertex": ("V",), "BottomDepth": ("C",), "EdgeSignOnCell": ("C", "ME"), "EdgeSignOnVertex": ("V", "VD"),
+            "EdgeMask": ("E", "K"), "MeshScalingDel2": ("E",), "MeshScalingDel4": ("E",)}
+for _el, _d in (("Cell", "C"), ("Edge", "E"), ("Vertex", "V")):
+    for _p in ("X", "Y", "Z", "Lon", "Lat"):
+        _MESH_R8[_p + _el] = (_d,)
+
+
+class HorzMesh:
+    def __init__(self, decomp: Decomp, nvertlayers: int, host_only: bool = False):
+        self.decomp = decomp
+        h = C.c_void_p()
+        _chk(lib().omg_mesh_create(decomp.h, nvertlayers, int(host_only), C.byref(h)))
+        self.h = h
+        self._dims = None
+
+    def get_int(self, name: str) -> int:
+        v = C.c_int32()
+        _chk(lib().omg_mesh_get_int(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def __getattr__(self, name):
+        if name.startswith("N") or name in ("MaxEdges", "MaxEdges2", "VertexDegree"):
+            try:
+                return self.get_int(name)
+            except OmegaAmdError:
+                pass
+        raise AttributeError(name)
+
+    def _shape(self, spec):
+        if self._dims is None:
+            self._dims = {"C": self.get_int("NCellsSize"), "E": self.get_int("NEdgesSize"),
+                          "V": self.get_int("NVerticesSize"), "ME": self.get_int("MaxEdges"),
+                          "ME2": self.get_int("MaxEdges2"), "VD": self.get_int("VertexDegree"),
+                          "K": self.get_int("NVertLayers")}
+        return tuple(self._dims[s] if isinstance(s, str) else s for s in spec)
+
+    def get_array(self, name: str) -> np.ndarray:
+        if name in _MESH_I4:
+            out = np.zeros(self._shape(_MESH_I4[name]), dtype=np.int32)
+            _chk(lib().omg_mesh_get_array_i4(self.h, name.encode(), _pi(out), C.c_size_t(out.size)))
+        else:
+            out = np.zeros(self._shape(_MESH_R8[name]), dtype=np.float64)
+            _chk(lib().omg_mesh_get_array_r8(self.h, name.encode(), _pd(out), C.c_size_t(out.size)))
+        return out
+
+    def local_arrays(self) -> dict:
+        """All host arrays + sizes, in the dict form oracle.Mesh consumes (test use)."""
+        L = {n: self.get_int(n) for n in ("NCellsOwned", "NCellsAll", "NCellsSize", "NEdgesOwned", "NEdgesAll",
+                                          "NEdgesSize", "NVerticesOwned", "NVerticesAll", "NVerticesSize",
+                                          "MaxEdges", "MaxEdges2", "VertexDegree")}
+        for n in list(_MESH_I4) + [k for k in _MESH_R8 if k not in ("EdgeSignOnCell", "EdgeSignOnVertex", "EdgeMask",
+                                                                    "MeshScalingDel2", "MeshScalingDel4")]:
+            L[n] = self.get_array(n)
+        return L
+
+    def set_fvertex(self, values: np.ndarray):
+        _chk(lib().omg_mesh_set_fvertex(self.h, _pd(np.ascontiguousarray(values, dtype=np.float64))))
+
+    def __del__(self):
+        try:
+            lib().omg_mesh_destroy(self.h)
+        except Exception:
+            pass
+
+
+def default_config(**over) -> TendConfig:
+    c = TendConfig()
+    lib().omg_tend_config_default(C.byref(c))
+    for k, v in over.items():
+        if not hasattr(c, k):
+            raise KeyError(k)
+        setattr(c, k, v)
+    return c
+
+
+class OceanState:
+    def __init__(self, mesh: HorzMesh, halo: Halo | None, nvertlayers: int, ntimelevels: int = 2):
+        self.mesh, self.halo, self.K = mesh, halo, nvertlayers
+        h = C.c_void_p()
+        _chk(lib().omg_state_create(mesh.h, halo.h if halo else None, nvertlayers, ntimelevels, C.byref(h)))
+        self.h = h
+
+    def copy_to_device(self, h=None, u=None, time_level: int = 0):
+        _chk(lib().omg_state_copy_to_device(self.h, time_level, _pd(h), _pd(u)))
+
+    def copy_to_host(self, time_level: int = 0):
+        h = np.zeros((self.mesh.NCellsSize, self.K))
+        u = np.zeros((self.mesh.NEdgesSize, self.K))
+        _chk(lib().omg_state_copy_to_host(self.h, time_level, _pd(h), _pd(u)))
+        return h, u
+
+    def device_ptr(self, which: int, time_level: int = 0) -> int:
+        p = PD()
+        _chk(lib().omg_state_device_ptr(self.h, time_level, which, C.byref(p)))
+        return C.cast(p, C.c_void_p).value
+
+    def exchange_halo(self, time_level: int = 0, stream=None):
+        _chk(lib().omg_state_exchange_halo(self.h, time_level, _sh(stream)))
+
+    def update_time_levels(self, stream=None):
+        _chk(lib().omg_state_update_time_levels(self.h, _sh(stream)))
+
+    def __del__(self):
+        try:
+            lib().omg_state_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Tracers:
+    def __init__(self, mesh: HorzMesh, halo: Halo | None, nvertlayers: int, ntracers: int, ntimelevels: int = 2):
+        self.mesh, self.K, self.NT = mesh, nvertlayers, ntracers
+        h = C.c_void_p()
+        _chk(lib().omg_tracers_create(mesh.h, halo.h if halo else None, nvertlayers, ntracers, ntimelevels, C.byref(h)))
+        self.h = h
+
+    def copy_to_device(self, tr, time_level: int = 0):
+        _chk(lib().omg_tracers_copy_to_device(self.h, time_level, _pd(tr)))
+
+    def copy_to_host(self, time_level: int = 0):
+        tr = np.zeros((max(self.NT, 1), self.mesh.NCellsSize, self.K))
+        if self.NT > 0:
+            _chk(lib().omg_tracers_copy_to_host(self.h, time_level, _pd(tr)))
+        return tr
+
+    def device_ptr(self, time_level: int = 0) -> int:
+        p = PD()
+        _chk(lib().omg_tracers_device_ptr(self.h, time_level, C.byref(p)))
+        return C.cast(p, C.c_void_p).value
+
+    def exchange_halo(self, time_level: int = 0, stream=None):
+        _chk(lib().omg_tracers_exchange_halo(self.h, time_level, _sh(stream)))
+
+    def update_time_levels(self, stream=None):
+        _chk(lib().omg_tracers_update_time_levels(self.h, _sh(stream)))
+
+    def __del__(self):
+        try:
+            lib().omg_tracers_destroy(self.h)
+        except Exception:
+            pass
+
+
+AUX_SHAPES = {"KineticEnergyCell": "C", "VelocityDivCell": "C", "FluxLayerThickEdge": "E", "MeanLayerThickEdge": "E",
+              "SshCell": "C", "RelVortVertex": "V", "NormRelVortVertex": "V", "NormPlanetVortVertex": "V",
+              "NormRelVortEdge": "E", "NormPlanetVortEdge": "E", "Del2Edge": "E", "Del2DivCell": "C",
+              "Del2RelVortVertex": "V", "HTracersEdge": "TE", "Del2TracersCell": "TC", "NormalStressEdge": "E1",
+              "ZonalStressCell": "C1", "MeridStressCell": "C1"}
+
+
+class AuxiliaryState:
+    def __init__(self, mesh: HorzMesh, halo: Halo | None, nvertlayers: int, ntracers: int):
+        self.mesh, self.K, self.NT = mesh, nvertlayers, ntracers
+        h = C.c_void_p()
+        _chk(lib().omg_aux_create(mesh.h, halo.h if halo else None, nvertlayers, ntracers, C.byref(h)))
+        self.h = h
+
+    def set_options(self, flux_thickness_upwind=False, flux_tracer_upwind=False, wind_interp_isotropic=True):
+        _chk(lib().omg_aux_set_options(self.h, int(flux_thickness_upwind), int(flux_tracer_upwind),
+                                       int(wind_interp_isotropic)))
+
+    def compute_mom_aux(self, state: OceanState, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_aux_compute_mom_aux(self.h, state.h, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_all(self, state: OceanState, tracers: Tracers, tracer_tl=0, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_aux_compute_all(self.h, state.h, tracers.h, tracer_tl, thick_tl, vel_tl, _sh(stream)))
+
+    def _shape(self, name):
+        m, K, nt = self.mesh, self.K, max(self.NT, 1)
+        rows = {"C": m.NCellsSize, "E": m.NEdgesSize, "V": m.NVerticesSize}
+        s = AUX_SHAPES[name]
+        if s in rows:
+            return (rows[s], K)
+        if s[0] == "T":
+            return (nt, rows[s[1]], K)
+        return (rows[s[0]],)
+
+    def get(self, name: str) -> np.ndarray:
+        out = np.zeros(self._shape(name))
+        _chk(lib().omg_aux_copy_to_host(self.h, name.encode(), _pd(out), C.c_size_t(out.size)))
+        return out
+
+    def set(self, name: str, values: np.ndarray):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        _chk(lib().omg_aux_copy_to_device(self.h, name.encode(), _pd(v), C.c_size_t(v.size)))
+
+    def __del__(self):
+        try:
+            lib().omg_aux_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Tendencies:
+    def __init__(self, mesh: HorzMesh, nvertlayers: int, ntracers: int, config: TendConfig | None = None):
+        self.mesh, self.K, self.NT = mesh, nvertlayers, ntracers
+        self.config = config if config is not None else default_config()
+        h = C.c_void_p()
+        _chk(lib().omg_tend_create(mesh.h, nvertlayers, ntracers, C.byref(self.config), C.byref(h)))
+        self.h = h
+
+    def set_fused(self, on: bool):
+        _chk(lib().omg_tend_set_fused(self.h, int(on)))
+
+    def compute_all_tendencies(self, state, aux, tracers, tracer_tl=0, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_all(self.h, state.h, aux.h, tracers.h, tracer_tl, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_thickness_tendencies(self, state, aux, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_thickness(self.h, state.h, aux.h, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_velocity_tendencies(self, state, aux, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_velocity(self.h, state.h, aux.h, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_tracer_tendencies(self, state, aux, tracers, tracer_tl=0, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_tracer(self.h, state.h, aux.h, tracers.h, tracer_tl, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_thickness_tendencies_only(self, state, aux, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_thickness_only(self.h, state.h, aux.h, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_velocity_tendencies_only(self, state, aux, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_velocity_only(self.h, state.h, aux.h, thick_tl, vel_tl, _sh(stream)))
+
+    def compute_tracer_tendencies_only(self, state, aux, tracers, tracer_tl=0, thick_tl=0, vel_tl=0, stream=None):
+        _chk(lib().omg_tend_compute_tracer_only(self.h, state.h, aux.h, tracers.h, tracer_tl, thick_tl, vel_tl,
+                                                _sh(stream)))
+
+    def get(self, which: int) -> np.ndarray:
+        m = self.mesh
+        shape = [(m.NCellsSize, self.K), (m.NEdgesSize, self.K), (max(self.NT, 1), m.NCellsSize, self.K)][which]
+        out = np.zeros(shape)
+        _chk(lib().omg_tend_copy_to_host(self.h, which, _pd(out), C.c_size_t(out.size)))
+        return out
+
+    def __del__(self):
+        try:
+            lib().omg_tend_destroy(self.h)
+        except Exception:
+            pass
+
+
+class TimeStepper:
+    def __init__(self, kind: str, dt: float, tend: Tendencies, aux: AuxiliaryState, mesh: HorzMesh,
+                 halo: Halo | None, tracers: Tracers):
+        self.refs = (tend, aux, mesh, halo, tracers)
+        h = C.c_void_p()
+        _chk(lib().omg_stepper_create(kind.encode(), C.c_double(dt), tend.h, aux.h, mesh.h, halo.h if halo else None,
+                                      tracers.h, C.byref(h)))
+        self.h = h
+
+    def do_step(self, state: OceanState, stream=None):
+        _chk(lib().omg_stepper_do_step(self.h, state.h, _sh(stream)))
+
+    def __del__(self):
+        try:
+            lib().omg_stepper_destroy(self.h)
+        except Exception:
+            pass
+
+
+def coeff_seconds(mult: float, dt: float) -> float:
+    out = C.c_double()
+    _chk(lib().omg_stepper_coeff_seconds(C.c_double(mult), C.c_double(dt), C.byref(out)))
+    return out.value

@@ -1,0 +1,96 @@
+// AuxiliaryState.cpp -- see AuxiliaryState.h.
+#include "AuxiliaryState.h"
+#include "Halo.h"
+
+namespace OMEGA {
+
+AuxiliaryState::AuxiliaryState(const std::string &Name_, const HorzMesh *Mesh_, Halo *MeshHalo_, int K, int NT)
+    : Mesh(Mesh_), MeshHalo(MeshHalo_), Name(Name_), NVertLayers(K), NTracers(NT) {
+   const int NC = Mesh->NCellsSize, NE = Mesh->NEdgesSize, NV = Mesh->NVerticesSize;
+   const int NTa = NT > 0 ? NT : 1;
+   KineticAux.KineticEnergyCell         = Array2DReal("KineticEnergyCell", NC, K);
+   KineticAux.VelocityDivCell           = Array2DReal("VelocityDivCell", NC, K);
+   LayerThicknessAux.FluxLayerThickEdge = Array2DReal("FluxLayerThickEdge", NE, K);
+   LayerThicknessAux.MeanLayerThickEdge = Array2DReal("MeanLayerThickEdge", NE, K);
+   LayerThicknessAux.SshCell            = Array2DReal("SshCell", NC, K);
+   VorticityAux.RelVortVertex           = Array2DReal("RelVortVertex", NV, K);
+   VorticityAux.NormRelVortVertex       = Array2DReal("NormRelVortVertex", NV, K);
+   VorticityAux.NormPlanetVortVertex    = Array2DReal("NormPlanetVortVertex", NV, K);
+   VorticityAux.NormRelVortEdge         = Array2DReal("NormRelVortEdge", NE, K);
+   VorticityAux.NormPlanetVortEdge      = Array2DReal("NormPlanetVortEdge", NE, K);
+   VelocityDel2Aux.Del2Edge             = Array2DReal("Del2Edge", NE, K);
+   VelocityDel2Aux.Del2DivCell          = Array2DReal("Del2DivCell", NC, K);
+   VelocityDel2Aux.Del2RelVortVertex    = Array2DReal("Del2RelVortVertex", NV, K);
+   WindForcingAux.NormalStressEdge      = Array1DReal("NormalStressEdge", NE);
+   WindForcingAux.ZonalStressCell       = Array1DReal("ZonalStressCell", NC);
+   WindForcingAux.MeridStressCell       = Array1DReal("MeridStressCell", NC);
+   TracerAux.HTracersEdge               = Array3DReal("HTracersEdge", NTa, NE, K);
+   TracerAux.Del2TracersCell            = Array3DReal("Del2TracersCell", NTa, NC, K);
+}
+
+AuxPtrs AuxiliaryState::ptrs() const {
+   AuxPtrs A;
+   A.KineticEnergyCell    = KineticAux.KineticEnergyCell.Ptr;
+   A.VelocityDivCell      = KineticAux.VelocityDivCell.Ptr;
+   A.FluxLayerThickEdge   = LayerThicknessAux.FluxLayerThickEdge.Ptr;
+   A.MeanLayerThickEdge   = LayerThicknessAux.MeanLayerThickEdge.Ptr;
+   A.SshCell              = LayerThicknessAux.SshCell.Ptr;
+   A.RelVortVertex        = VorticityAux.RelVortVertex.Ptr;
+   A.NormRelVortVertex    = VorticityAux.NormRelVortVertex.Ptr;
+   A.NormPlanetVortVertex = VorticityAux.NormPlanetVortVertex.Ptr;
+   A.NormRelVortEdge      = VorticityAux.NormRelVortEdge.Ptr;
+   A.NormPlanetVortEdge   = VorticityAux.NormPlanetVortEdge.Ptr;
+   A.Del2Edge             = VelocityDel2Aux.Del2Edge.Ptr;
+   A.Del2DivCell          = VelocityDel2Aux.Del2DivCell.Ptr;
+   A.Del2RelVortVertex    = VelocityDel2Aux.Del2RelVortVertex.Ptr;
+   A.HTracersEdge         = TracerAux.HTracersEdge.Ptr;
+   A.Del2TracersCell      = TracerAux.Del2TracersCell.Ptr;
+   A.NormalStressEdge     = WindForcingAux.NormalStressEdge.Ptr;
+   A.ZonalStressCell      = WindForcingAux.ZonalStressCell.Ptr;
+   A.MeridStressCell      = WindForcingAux.MeridStressCell.Ptr;
+   return A;
+}
+
+void AuxiliaryState::computeMomAux(const OceanState *State, int ThickTimeLevel, int VelTimeLevel, hipStream_t S) const {
+   Array2DReal LayerThickCell, NormalVelEdge;
+   OMEGA_REQUIRE(State->getLayerThickness(LayerThickCell, ThickTimeLevel) == 0, "AuxiliaryState: bad thickness time level");
+   OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelTimeLevel) == 0, "AuxiliaryState: bad velocity time level");
+   const MeshView &M = Mesh->view();
+   const AuxPtrs A   = ptrs();
+   const int K       = NVertLayers;
+   const int Upwind  = LayerThicknessAux.FluxThickEdgeChoice == FluxThickEdgeOption::Upwind;
+   launchVertexAuxState1(M, K, A, LayerThickCell.Ptr, NormalVelEdge.Ptr, S);                  // :79-85
+   launchCellAuxState1(M, K, A, NormalVelEdge.Ptr, S);                                        // :88-93
+   launchEdgeAuxState1(M, A, WindForcingAux.InterpChoice == InterpCellToEdgeOption::Isotropic, S); // :99-103
+   launchEdgeAuxState2(M, K, A, LayerThickCell.Ptr, NormalVelEdge.Ptr, Upwind, S);            // :106-115
+   launchVertexAuxState2(M, K, A, S);                                                         // :118-123
+   launchCellAuxState2(M, K, A, S);                                                           // :126-131
+   launchCellAuxState3(M, K, A, LayerThickCell.Ptr, S);                                       // :134-140
+}
+
+void AuxiliaryState::computeAll(const OceanState *State, const Array3DReal &TracerArray, int ThickTimeLevel,
+                                int VelTimeLevel, hipStream_t S) const {
+   Array2DReal LayerThickCell, NormalVelEdge;
+   OMEGA_REQUIRE(State->getLayerThickness(LayerThickCell, ThickTimeLevel) == 0, "AuxiliaryState: bad thickness time level");
+   OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelTimeLevel) == 0, "AuxiliaryState: bad velocity time level");
+   computeMomAux(State, ThickTimeLevel, VelTimeLevel, S);
+   const MeshView &M = Mesh->view();
+   const AuxPtrs A   = ptrs();
+   const int Upwind  = TracerAux.TracersOnEdgeChoice == FluxTracerEdgeOption::Upwind;
+   launchEdgeAuxState4(M, NVertLayers, NTracers, A, NormalVelEdge.Ptr, LayerThickCell.Ptr, TracerArray.Ptr, Upwind, S); // :165-171
+   launchCellAuxState4(M, NVertLayers, NTracers, A, TracerArray.Ptr, S);                                               // :176-182
+}
+
+I4 AuxiliaryState::exchangeHalo(hipStream_t S) {
+   if (!MeshHalo)
+      return 0;
+   Array2DReal Z, Mv;
+   // 1-D arrays are exchanged as (N, 1)
+   Z.Ptr = WindForcingAux.ZonalStressCell.Ptr, Z.Ext[0] = Mesh->NCellsSize, Z.Ext[1] = 1;
+   Mv.Ptr = WindForcingAux.MeridStressCell.Ptr, Mv.Ext[0] = Mesh->NCellsSize, Mv.Ext[1] = 1;
+   I4 Err = MeshHalo->exchangeFullArrayHalo(Z, OnCell, S);
+   Err += MeshHalo->exchangeFullArrayHalo(Mv, OnCell, S);
+   return Err;
+}
+
+} // namespace OMEGA

@@ -1,0 +1,67 @@
+// AuxiliaryState.h -- diagnostic ("auxiliary") fields of the RHS.
+// Interface and array names after the reference (components/omega/src/ocn/
+// AuxiliaryState.h:37-82 and auxiliaryVars/*.h public members).
+#ifndef OMEGA_AMD_AUXILIARYSTATE_H
+#define OMEGA_AMD_AUXILIARYSTATE_H
+
+#include "Base.h"
+#include "HorzMesh.h"
+#include "OceanState.h"
+#include "kernels/Kernels.h"
+
+namespace OMEGA {
+
+enum class FluxThickEdgeOption { Center, Upwind };
+enum class FluxTracerEdgeOption { Center, Upwind };
+enum class InterpCellToEdgeOption { Anisotropic, Isotropic };
+
+struct KineticAuxVars {
+   Array2DReal KineticEnergyCell, VelocityDivCell;
+};
+struct LayerThicknessAuxVars {
+   Array2DReal FluxLayerThickEdge, MeanLayerThickEdge, SshCell;
+   FluxThickEdgeOption FluxThickEdgeChoice = FluxThickEdgeOption::Center;
+};
+struct VorticityAuxVars {
+   Array2DReal RelVortVertex, NormRelVortVertex, NormPlanetVortVertex, NormRelVortEdge, NormPlanetVortEdge;
+};
+struct VelocityDel2AuxVars {
+   Array2DReal Del2Edge, Del2DivCell, Del2RelVortVertex;
+};
+struct WindForcingAuxVars {
+   Array1DReal NormalStressEdge, ZonalStressCell, MeridStressCell;
+   InterpCellToEdgeOption InterpChoice = InterpCellToEdgeOption::Isotropic;
+};
+struct TracerAuxVars {
+   Array3DReal HTracersEdge, Del2TracersCell;
+   FluxTracerEdgeOption TracersOnEdgeChoice = FluxTracerEdgeOption::Center;
+};
+
+class AuxiliaryState {
+ public:
+   AuxiliaryState(const std::string &Name, const HorzMesh *Mesh, Halo *MeshHalo, int NVertLayers, int NTracers);
+
+   KineticAuxVars KineticAux;
+   LayerThicknessAuxVars LayerThicknessAux;
+   VorticityAuxVars VorticityAux;
+   VelocityDel2AuxVars VelocityDel2Aux;
+   WindForcingAuxVars WindForcingAux;
+   TracerAuxVars TracerAux;
+
+   /// AuxiliaryState::computeMomAux (AuxiliaryState.cpp:60-143)
+   void computeMomAux(const OceanState *State, int ThickTimeLevel, int VelTimeLevel, hipStream_t S) const;
+   /// AuxiliaryState::computeAll (AuxiliaryState.cpp:146-185)
+   void computeAll(const OceanState *State, const Array3DReal &TracerArray, int ThickTimeLevel, int VelTimeLevel,
+                   hipStream_t S) const;
+   /// exchange of the non-computed aux variables (AuxiliaryState.cpp:312-323)
+   I4 exchangeHalo(hipStream_t S);
+
+   AuxPtrs ptrs() const;
+   const HorzMesh *Mesh;
+   Halo *MeshHalo;
+   std::string Name;
+   int NVertLayers, NTracers;
+};
+
+} // namespace OMEGA
+#endif

@@ -1,0 +1,141 @@
+// Base.h -- basic types, error convention and device-array handles.
+//
+// Layout contract taken from the reference (no Kokkos here): Real = double,
+// I4 = int32, LayoutRight (last index = vertical level, contiguous), every
+// mesh-indexed array has NXxSize = NXxAll + 1 rows, the last being the zero
+// sentinel row that missing neighbours point to
+// (reference: components/omega/src/base/DataTypes.h:19-94,
+//  components/omega/src/base/Decomp.cpp:553-574, 1082).
+#ifndef OMEGA_AMD_BASE_H
+#define OMEGA_AMD_BASE_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace OMEGA {
+
+using I4   = int32_t;
+using I8   = int64_t;
+using R8   = double;
+using Real = double;
+
+/// Mesh element kinds (reference: components/omega/src/base/Halo.h:45)
+enum MeshElement { OnCell, OnEdge, OnVertex };
+
+/// Error convention: host code throws OmegaError; the C ABI catches it, stores the
+/// message (omg_last_error) and returns a non-zero int.  This mirrors the reference's
+/// ABORT_ERROR / int-return-code pair (components/omega/src/infra/Error.h:207-270)
+/// without tearing the process down inside a library.
+struct OmegaError : std::runtime_error {
+   using std::runtime_error::runtime_error;
+};
+
+[[noreturn]] void abortError(const char *File, int Line, const std::string &Msg);
+
+#define OMEGA_ABORT(msg) ::OMEGA::abortError(__FILE__, __LINE__, (msg))
+#define OMEGA_REQUIRE(cond, msg)                                               \
+   do {                                                                        \
+      if (!(cond))                                                             \
+         ::OMEGA::abortError(__FILE__, __LINE__, (msg));                       \
+   } while (0)
+#define HIP_CHECK(call)                                                        \
+   do {                                                                        \
+      hipError_t e_ = (call);                                                  \
+      if (e_ != hipSuccess)                                                    \
+         ::OMEGA::abortError(__FILE__, __LINE__,                               \
+                             std::string(#call) + ": " + hipGetErrorString(e_)); \
+   } while (0)
+
+/// Owning device allocation (zero-initialised, like a Kokkos::View).
+class DeviceBuffer {
+ public:
+   DeviceBuffer() = default;
+   explicit DeviceBuffer(size_t Bytes);
+   ~DeviceBuffer();
+   DeviceBuffer(const DeviceBuffer &)            = delete;
+   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+   void *Ptr    = nullptr;
+   size_t Bytes = 0;
+};
+
+/// Rank-N device array handle: pointer + extents, shared ownership of the
+/// allocation (copies alias, as Kokkos views do).
+template <class T, int N> struct DeviceArray {
+   T *Ptr = nullptr;
+   int Ext[N > 0 ? N : 1] = {};
+   std::string Label;
+   std::shared_ptr<DeviceBuffer> Buf;
+
+   DeviceArray() = default;
+   DeviceArray(const std::string &L, int E0, int E1 = 1, int E2 = 1) : Label(L) {
+      int E[3] = {E0, E1, E2};
+      size_t Cnt = 1;
+      for (int I = 0; I < N; ++I) {
+         Ext[I] = E[I];
+         Cnt *= (size_t)E[I];
+      }
+      Buf = std::make_shared<DeviceBuffer>(Cnt * sizeof(T));
+      Ptr = static_cast<T *>(Buf->Ptr);
+   }
+   size_t size() const {
+      size_t Cnt = Ptr ? 1 : 0;
+      for (int I = 0; I < N; ++I)
+         Cnt *= (size_t)Ext[I];
+      return Cnt;
+   }
+   size_t bytes() const { return size() * sizeof(T); }
+   int extent_int(int I) const { return Ext[I]; }
+   T *data() const { return Ptr; }
+   const std::string &label() const { return Label; }
+};
+
+using Array1DI4   = DeviceArray<I4, 1>;
+using Array2DI4   = DeviceArray<I4, 2>;
+using Array1DReal = DeviceArray<Real, 1>;
+using Array2DReal = DeviceArray<Real, 2>;
+using Array3DReal = DeviceArray<Real, 3>;
+
+/// Host arrays are plain vectors with extents.
+template <class T> struct HostArray {
+   std::vector<T> V;
+   int Ext[3] = {0, 1, 1};
+   HostArray() = default;
+   HostArray(int E0, int E1 = 1, int E2 = 1, T Fill = T()) : V((size_t)E0 * E1 * E2, Fill) {
+      Ext[0] = E0;
+      Ext[1] = E1;
+      Ext[2] = E2;
+   }
+   T &operator()(int I) { return V[I]; }
+   const T &operator()(int I) const { return V[I]; }
+   T &operator()(int I, int J) { return V[(size_t)I * Ext[1] + J]; }
+   const T &operator()(int I, int J) const { return V[(size_t)I * Ext[1] + J]; }
+   T *data() { return V.data(); }
+   const T *data() const { return V.data(); }
+   size_t size() const { return V.size(); }
+};
+using HostArrayI4   = HostArray<I4>;
+using HostArrayReal = HostArray<Real>;
+
+// ---- device helpers (Device.cpp) ----
+void deviceInit(int DeviceId);                 ///< hipSetDevice + sanity check (gfx950)
+void copyToDevice(void *Dst, const void *Src, size_t Bytes, hipStream_t S = nullptr);
+void copyToHost(void *Dst, const void *Src, size_t Bytes, hipStream_t S = nullptr);
+void deviceFill0(void *Dst, size_t Bytes, hipStream_t S);
+void deviceCopy(void *Dst, const void *Src, size_t Bytes, hipStream_t S);
+
+template <class T, int N>
+DeviceArray<T, N> createDeviceMirrorCopy(const std::string &L, const HostArray<T> &H) {
+   DeviceArray<T, N> D(L, H.Ext[0], H.Ext[1], H.Ext[2]);
+   copyToDevice(D.Ptr, H.data(), D.bytes());
+   return D;
+}
+
+} // namespace OMEGA
+#endif

@@ -1,0 +1,92 @@
+// Decomp.h -- domain decomposition of the global MPAS mesh for one rank.
+//
+// Same contract as the reference's Decomp (components/omega/src/base/Decomp.h:189-260;
+// construction flow components/omega/src/base/Decomp.cpp:444-745): cells are
+// partitioned, `HaloWidth` cell halo layers are added (each layer sorted by global
+// ID), edges / vertices are owned by the first valid cell of CellsOnEdge /
+// CellsOnVertex, local order = owned, halo-1, halo-2, ..., then one sentinel slot
+// (index NXxAll) that every missing / non-local neighbour maps to.
+//
+// MI355X-first differences (design, not numerics):
+//  * one process per GPU holds the whole global connectivity on the host, so the
+//    reference's round-robin MPI_Bcast choreography disappears: every rank derives
+//    any rank's numbering deterministically (that is also how Halo gets its send
+//    lists without an index exchange);
+//  * METIS is not available: the built-in partitioner is recursive coordinate
+//    bisection (RCB); a caller-supplied cell->task vector (e.g. a METIS
+//    graph.info.part.N file) is honoured as is.
+#ifndef OMEGA_AMD_DECOMP_H
+#define OMEGA_AMD_DECOMP_H
+
+#include "Base.h"
+
+namespace OMEGA {
+
+/// Global mesh as a mesh-file reader hands it over: host pointers, 0-based indices,
+/// -1 = missing (MPAS files: 1-based, 0 = missing; Decomp.cpp:108-395).
+struct GlobalMeshDesc {
+   I4 NCells = 0, NEdges = 0, NVertices = 0, MaxEdges = 0, VertexDegree = 3;
+   const I4 *CellsOnCell = nullptr, *EdgesOnCell = nullptr, *VerticesOnCell = nullptr;
+   const I4 *CellsOnEdge = nullptr, *VerticesOnEdge = nullptr, *EdgesOnEdge = nullptr;
+   const I4 *CellsOnVertex = nullptr, *EdgesOnVertex = nullptr;
+   // geometry (HorzMesh reads these; components/omega/src/ocn/HorzMesh.cpp:424-523)
+   const R8 *XCell = nullptr, *YCell = nullptr, *ZCell = nullptr, *LonCell = nullptr, *LatCell = nullptr;
+   const R8 *XEdge = nullptr, *YEdge = nullptr, *ZEdge = nullptr, *LonEdge = nullptr, *LatEdge = nullptr;
+   const R8 *XVertex = nullptr, *YVertex = nullptr, *ZVertex = nullptr, *LonVertex = nullptr, *LatVertex = nullptr;
+   const R8 *AreaCell = nullptr, *AreaTriangle = nullptr, *KiteAreasOnVertex = nullptr;
+   const R8 *DcEdge = nullptr, *DvEdge = nullptr, *AngleEdge = nullptr, *WeightsOnEdge = nullptr;
+   const R8 *FCell = nullptr, *FEdge = nullptr, *FVertex = nullptr, *BottomDepth = nullptr;
+};
+
+enum PartMethod { PartMethodRCB, PartMethodUser };
+
+/// Ordered local element lists of one rank (global 0-based ids) with layer bounds.
+struct LocalSets {
+   std::vector<I4> CellID, EdgeID, VertexID;
+   I4 NCellsOwned = 0, NEdgesOwned = 0, NVerticesOwned = 0;
+   std::vector<I4> NCellsHalo, NEdgesHalo, NVerticesHalo; ///< HaloWidth entries each
+};
+
+class Decomp {
+ public:
+   Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask, I4 HaloWidth,
+          const I4 *UserCellTask /* nullable */);
+
+   // ---- public data, names as in the reference (host side; "H" arrays) ----
+   I4 HaloWidth;
+   I4 NumTasks, MyTask;
+
+   I4 NCellsGlobal, NCellsOwned, NCellsAll, NCellsSize, MaxEdges;
+   HostArrayI4 NCellsHaloH; ///< [HaloWidth] owned+halo count through layer i
+   HostArrayI4 CellIDH;     ///< [NCellsSize] 1-based global id (sentinel: NCellsGlobal+1)
+   HostArrayI4 CellLocH;    ///< [NCellsSize][2] (task, local address on that task)
+
+   I4 NEdgesGlobal, NEdgesOwned, NEdgesAll, NEdgesSize, MaxCellsOnEdge = 2;
+   HostArrayI4 NEdgesHaloH, EdgeIDH, EdgeLocH;
+
+   I4 NVerticesGlobal, NVerticesOwned, NVerticesAll, NVerticesSize, VertexDegree;
+   HostArrayI4 NVerticesHaloH, VertexIDH, VertexLocH;
+
+   HostArrayI4 CellsOnCellH, EdgesOnCellH, NEdgesOnCellH, VerticesOnCellH;
+   HostArrayI4 CellsOnEdgeH, EdgesOnEdgeH, NEdgesOnEdgeH, VerticesOnEdgeH;
+   HostArrayI4 CellsOnVertexH, EdgesOnVertexH;
+
+   // ---- global tables every rank derives identically ----
+   std::vector<I4> CellTask;    ///< [NCellsGlobal] owner task of each cell
+   std::vector<I4> CellLocAll;  ///< [NCellsGlobal] local address on the owner
+   std::vector<I4> EdgeTask, EdgeLocAll, VertexTask, VertexLocAll;
+
+   /// Ordered element lists of any rank (used by Halo to build send lists).
+   LocalSets computeLocalSets(I4 Task) const;
+
+   const GlobalMeshDesc &globalMesh() const { return G; }
+
+ private:
+   GlobalMeshDesc G;
+   void partitionRCB();
+   void computeOwnership();
+   void buildLocalConnectivity(const LocalSets &S);
+};
+
+} // namespace OMEGA
+#endif

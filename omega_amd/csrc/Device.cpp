@@ -1,0 +1,64 @@
+// Device.cpp -- HIP memory helpers and the error sink.
+#include "Base.h"
+
+#include <cstring>
+#include <sstream>
+
+namespace OMEGA {
+
+void abortError(const char *File, int Line, const std::string &Msg) {
+   std::ostringstream OS;
+   OS << "[omega_amd] " << File << ":" << Line << ": " << Msg;
+   throw OmegaError(OS.str());
+}
+
+DeviceBuffer::DeviceBuffer(size_t B) : Bytes(B) {
+   if (B == 0)
+      B = 8;
+   HIP_CHECK(hipMalloc(&Ptr, B));
+   HIP_CHECK(hipMemset(Ptr, 0, B)); // Kokkos views are zero-initialised; the sentinel rows rely on it
+}
+DeviceBuffer::~DeviceBuffer() {
+   if (Ptr)
+      (void)hipFree(Ptr);
+}
+
+void deviceInit(int DeviceId) {
+   int N = 0;
+   hipError_t E = hipGetDeviceCount(&N);
+   if (E != hipSuccess || N <= 0)
+      OMEGA_ABORT("no HIP device visible: the omega_amd product path has no CPU fallback");
+   OMEGA_REQUIRE(DeviceId >= 0 && DeviceId < N, "device id out of range");
+   HIP_CHECK(hipSetDevice(DeviceId));
+}
+
+void copyToDevice(void *Dst, const void *Src, size_t Bytes, hipStream_t S) {
+   if (!Bytes)
+      return;
+   if (S) {
+      HIP_CHECK(hipMemcpyAsync(Dst, Src, Bytes, hipMemcpyHostToDevice, S));
+      HIP_CHECK(hipStreamSynchronize(S));
+   } else {
+      HIP_CHECK(hipMemcpy(Dst, Src, Bytes, hipMemcpyHostToDevice));
+   }
+}
+void copyToHost(void *Dst, const void *Src, size_t Bytes, hipStream_t S) {
+   if (!Bytes)
+      return;
+   if (S) {
+      HIP_CHECK(hipMemcpyAsync(Dst, Src, Bytes, hipMemcpyDeviceToHost, S));
+      HIP_CHECK(hipStreamSynchronize(S));
+   } else {
+      HIP_CHECK(hipMemcpy(Dst, Src, Bytes, hipMemcpyDeviceToHost));
+   }
+}
+void deviceFill0(void *Dst, size_t Bytes, hipStream_t S) {
+   if (Bytes)
+      HIP_CHECK(hipMemsetAsync(Dst, 0, Bytes, S));
+}
+void deviceCopy(void *Dst, const void *Src, size_t Bytes, hipStream_t S) {
+   if (Bytes)
+      HIP_CHECK(hipMemcpyAsync(Dst, Src, Bytes, hipMemcpyDeviceToDevice, S));
+}
+
+} // namespace OMEGA

@@ -1,0 +1,284 @@
+// HorzMesh.cpp -- see HorzMesh.h.
+#include "HorzMesh.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace OMEGA {
+
+namespace {
+// gather a global per-element array (Width values per element) into local order;
+// the sentinel row stays zero (the reference reads only NXxAll elements into
+// NXxSize-long zero-initialised arrays, HorzMesh.cpp:360-420)
+HostArrayReal gatherLocal(const R8 *Global, const HostArrayI4 &IDH, I4 NAll, int Width = 1) {
+   HostArrayReal Out(NAll + 1, Width, 1, 0.0);
+   if (!Global)
+      return Out;
+   for (I4 L = 0; L < NAll; ++L) {
+      const size_t Gid = (size_t)(IDH(L) - 1);
+      for (int J = 0; J < Width; ++J)
+         Out.V[(size_t)L * Width + J] = Global[Gid * Width + J];
+   }
+   return Out;
+}
+} // namespace
+
+HorzMesh::HorzMesh(const std::string &Name, const Decomp *D, I4 InNVertLayers, bool HostOnly_) {
+   HostOnly    = HostOnly_;
+   MeshName    = Name;
+   NVertLayers = InNVertLayers;
+   OMEGA_REQUIRE(NVertLayers >= 1, "HorzMesh: NVertLayers must be >= 1");
+
+   NCellsHaloH = D->NCellsHaloH;
+   NCellsOwned = D->NCellsOwned;
+   NCellsAll   = D->NCellsAll;
+   NCellsSize  = D->NCellsSize;
+
+   NEdgesHaloH    = D->NEdgesHaloH;
+   NEdgesOwned    = D->NEdgesOwned;
+   NEdgesAll      = D->NEdgesAll;
+   NEdgesSize     = D->NEdgesSize;
+   MaxCellsOnEdge = D->MaxCellsOnEdge;
+   MaxEdges       = D->MaxEdges;
+   MaxEdges2      = 2 * MaxEdges;
+
+   NVerticesHaloH = D->NVerticesHaloH;
+   NVerticesOwned = D->NVerticesOwned;
+   NVerticesAll   = D->NVerticesAll;
+   NVerticesSize  = D->NVerticesSize;
+   VertexDegree   = D->VertexDegree;
+
+   CellsOnCellH    = D->CellsOnCellH;
+   EdgesOnCellH    = D->EdgesOnCellH;
+   NEdgesOnCellH   = D->NEdgesOnCellH;
+   VerticesOnCellH = D->VerticesOnCellH;
+   CellsOnEdgeH    = D->CellsOnEdgeH;
+   EdgesOnEdgeH    = D->EdgesOnEdgeH;
+   NEdgesOnEdgeH   = D->NEdgesOnEdgeH;
+   VerticesOnEdgeH = D->VerticesOnEdgeH;
+   CellsOnVertexH  = D->CellsOnVertexH;
+   EdgesOnVertexH  = D->EdgesOnVertexH;
+
+   const GlobalMeshDesc &G = D->globalMesh();
+   // readCoordinates (HorzMesh.cpp:424-449)
+   XCellH     = gatherLocal(G.XCell, D->CellIDH, NCellsAll);
+   YCellH     = gatherLocal(G.YCell, D->CellIDH, NCellsAll);
+   ZCellH     = gatherLocal(G.ZCell, D->CellIDH, NCellsAll);
+   LonCellH   = gatherLocal(G.LonCell, D->CellIDH, NCellsAll);
+   LatCellH   = gatherLocal(G.LatCell, D->CellIDH, NCellsAll);
+   XEdgeH     = gatherLocal(G.XEdge, D->EdgeIDH, NEdgesAll);
+   YEdgeH     = gatherLocal(G.YEdge, D->EdgeIDH, NEdgesAll);
+   ZEdgeH     = gatherLocal(G.ZEdge, D->EdgeIDH, NEdgesAll);
+   LonEdgeH   = gatherLocal(G.LonEdge, D->EdgeIDH, NEdgesAll);
+   LatEdgeH   = gatherLocal(G.LatEdge, D->EdgeIDH, NEdgesAll);
+   XVertexH   = gatherLocal(G.XVertex, D->VertexIDH, NVerticesAll);
+   YVertexH   = gatherLocal(G.YVertex, D->VertexIDH, NVerticesAll);
+   ZVertexH   = gatherLocal(G.ZVertex, D->VertexIDH, NVerticesAll);
+   LonVertexH = gatherLocal(G.LonVertex, D->VertexIDH, NVerticesAll);
+   LatVertexH = gatherLocal(G.LatVertex, D->VertexIDH, NVerticesAll);
+   // readBottomDepth / readMeasurements / readWeights / readCoriolis (:453-523)
+   OMEGA_REQUIRE(G.AreaCell && G.AreaTriangle && G.KiteAreasOnVertex && G.DcEdge && G.DvEdge && G.WeightsOnEdge,
+                 "HorzMesh: global mesh geometry incomplete");
+   BottomDepthH       = gatherLocal(G.BottomDepth, D->CellIDH, NCellsAll);
+   AreaCellH          = gatherLocal(G.AreaCell, D->CellIDH, NCellsAll);
+   AreaTriangleH      = gatherLocal(G.AreaTriangle, D->VertexIDH, NVerticesAll);
+   DvEdgeH            = gatherLocal(G.DvEdge, D->EdgeIDH, NEdgesAll);
+   DcEdgeH            = gatherLocal(G.DcEdge, D->EdgeIDH, NEdgesAll);
+   AngleEdgeH         = gatherLocal(G.AngleEdge, D->EdgeIDH, NEdgesAll);
+   KiteAreasOnVertexH = gatherLocal(G.KiteAreasOnVertex, D->VertexIDH, NVerticesAll, VertexDegree);
+   WeightsOnEdgeH     = gatherLocal(G.WeightsOnEdge, D->EdgeIDH, NEdgesAll, MaxEdges2);
+   FCellH             = gatherLocal(G.FCell, D->CellIDH, NCellsAll);
+   FVertexH           = gatherLocal(G.FVertex, D->VertexIDH, NVerticesAll);
+   FEdgeH             = gatherLocal(G.FEdge, D->EdgeIDH, NEdgesAll);
+
+   computeEdgeSign();
+   setMasks();
+   setMeshScaling();
+   if (!HostOnly) {
+      copyToDevice();
+      buildCoefficientTables();
+   }
+}
+
+// HorzMesh::computeEdgeSign (reference HorzMesh.cpp:527-575)
+void HorzMesh::computeEdgeSign() {
+   EdgeSignOnCellH = HostArrayReal(NCellsSize, MaxEdges, 1, 0.0);
+   for (int Cell = 0; Cell < NCellsAll; ++Cell)
+      for (int I = 0; I < NEdgesOnCellH(Cell); ++I) {
+         int Edge = EdgesOnCellH(Cell, I);
+         // vector points from cell 0 to cell 1
+         EdgeSignOnCellH(Cell, I) = (Cell == CellsOnEdgeH(Edge, 0)) ? -1.0 : 1.0;
+      }
+   EdgeSignOnVertexH = HostArrayReal(NVerticesSize, VertexDegree, 1, 0.0);
+   for (int Vertex = 0; Vertex < NVerticesAll; ++Vertex)
+      for (int I = 0; I < VertexDegree; ++I) {
+         int Edge = EdgesOnVertexH(Vertex, I);
+         // vector points from vertex 0 to vertex 1
+         EdgeSignOnVertexH(Vertex, I) = (Vertex == VerticesOnEdgeH(Edge, 0)) ? -1.0 : 1.0;
+      }
+}
+
+// HorzMesh::setMasks (reference HorzMesh.cpp:581-602): 1 everywhere (sentinel row
+// included), 0 on local edges with a cell outside [0, NCellsAll)
+void HorzMesh::setMasks() {
+   EdgeMaskH = HostArrayReal(NEdgesSize, NVertLayers, 1, 1.0);
+   for (int Edge = 0; Edge < NEdgesAll; ++Edge) {
+      const I4 Cell1 = CellsOnEdgeH(Edge, 0), Cell2 = CellsOnEdgeH(Edge, 1);
+      if (!(Cell1 >= 0 && Cell1 < NCellsAll) || !(Cell2 >= 0 && Cell2 < NCellsAll))
+         for (int K = 0; K < NVertLayers; ++K)
+            EdgeMaskH(Edge, K) = 0.0;
+   }
+}
+
+// HorzMesh::setMeshScaling (reference HorzMesh.cpp:607-626): no scaling option only
+void HorzMesh::setMeshScaling() {
+   MeshScalingDel2H = HostArrayReal(NEdgesSize, 1, 1, 0.0);
+   MeshScalingDel4H = HostArrayReal(NEdgesSize, 1, 1, 0.0);
+   for (int Edge = 0; Edge < NEdgesAll; ++Edge) {
+      MeshScalingDel2H(Edge) = 1.0;
+      MeshScalingDel4H(Edge) = 1.0;
+   }
+}
+
+void HorzMesh::copyToDevice() {
+   CellsOnCell    = createDeviceMirrorCopy<I4, 2>("CellsOnCell", CellsOnCellH);
+   EdgesOnCell    = createDeviceMirrorCopy<I4, 2>("EdgesOnCell", EdgesOnCellH);
+   NEdgesOnCell   = createDeviceMirrorCopy<I4, 1>("NEdgesOnCell", NEdgesOnCellH);
+   VerticesOnCell = createDeviceMirrorCopy<I4, 2>("VerticesOnCell", VerticesOnCellH);
+   CellsOnEdge    = createDeviceMirrorCopy<I4, 2>("CellsOnEdge", CellsOnEdgeH);
+   EdgesOnEdge    = createDeviceMirrorCopy<I4, 2>("EdgesOnEdge", EdgesOnEdgeH);
+   NEdgesOnEdge   = createDeviceMirrorCopy<I4, 1>("NEdgesOnEdge", NEdgesOnEdgeH);
+   VerticesOnEdge = createDeviceMirrorCopy<I4, 2>("VerticesOnEdge", VerticesOnEdgeH);
+   CellsOnVertex  = createDeviceMirrorCopy<I4, 2>("CellsOnVertex", CellsOnVertexH);
+   EdgesOnVertex  = createDeviceMirrorCopy<I4, 2>("EdgesOnVertex", EdgesOnVertexH);
+
+   AreaCell          = createDeviceMirrorCopy<Real, 1>("AreaCell", AreaCellH);
+   AreaTriangle      = createDeviceMirrorCopy<Real, 1>("AreaTriangle", AreaTriangleH);
+   KiteAreasOnVertex = createDeviceMirrorCopy<Real, 2>("KiteAreasOnVertex", KiteAreasOnVertexH);
+   DcEdge            = createDeviceMirrorCopy<Real, 1>("DcEdge", DcEdgeH);
+   DvEdge            = createDeviceMirrorCopy<Real, 1>("DvEdge", DvEdgeH);
+   AngleEdge         = createDeviceMirrorCopy<Real, 1>("AngleEdge", AngleEdgeH);
+   WeightsOnEdge     = createDeviceMirrorCopy<Real, 2>("WeightsOnEdge", WeightsOnEdgeH);
+   FVertex           = createDeviceMirrorCopy<Real, 1>("FVertex", FVertexH);
+   BottomDepth       = createDeviceMirrorCopy<Real, 1>("BottomDepth", BottomDepthH);
+
+   EdgeSignOnCell   = createDeviceMirrorCopy<Real, 2>("EdgeSignOnCell", EdgeSignOnCellH);
+   EdgeSignOnVertex = createDeviceMirrorCopy<Real, 2>("EdgeSignOnVertex", EdgeSignOnVertexH);
+   EdgeMask         = createDeviceMirrorCopy<Real, 2>("EdgeMask", EdgeMaskH);
+   MeshScalingDel2  = createDeviceMirrorCopy<Real, 1>("MeshScalingDel2", MeshScalingDel2H);
+   MeshScalingDel4  = createDeviceMirrorCopy<Real, 1>("MeshScalingDel4", MeshScalingDel4H);
+}
+
+void HorzMesh::setFVertex(const Real *HostValues) {
+   for (int V = 0; V < NVerticesSize; ++V)
+      FVertexH(V) = HostValues[V];
+   if (!HostOnly)
+      OMEGA::copyToDevice(FVertex.Ptr, FVertexH.data(), FVertex.bytes());
+}
+
+// Level-independent prefixes of the reference's product chains, in the reference's
+// left-to-right order (file:line of each chain in the comments).
+void HorzMesh::buildCoefficientTables() {
+   const int ME = MaxEdges, ME2 = MaxEdges2, VD = VertexDegree;
+   HostArrayReal Mask1D(NEdgesSize, 1, 1, 0.0);
+   for (int E = 0; E < NEdgesSize; ++E)
+      Mask1D(E) = EdgeMaskH(E, 0);
+
+   HostArrayReal InvA(NCellsSize, 1, 1, 0.0), DvS(NCellsSize, ME, 1, 0.0), DivC(NCellsSize, ME, 1, 0.0),
+       KEC(NCellsSize, ME, 1, 0.0), MDvS(NCellsSize, ME, 1, 0.0), D2T(NCellsSize, ME, 1, 0.0),
+       Df2(NCellsSize, ME, 1, 0.0), Df4(NCellsSize, ME, 1, 0.0);
+   HostArrayI4 COEOC(NCellsSize, ME, 2, NCellsAll);
+   for (int C = 0; C < NCellsAll; ++C) {
+      const Real InvAreaCell = 1. / AreaCellH(C);
+      InvA(C)                = InvAreaCell;
+      for (int J = 0; J < NEdgesOnCellH(C); ++J) {
+         const int E     = EdgesOnCellH(C, J);
+         const Real Sign = EdgeSignOnCellH(C, J);
+         const Real Dv = DvEdgeH(E), Dc = DcEdgeH(E), M = Mask1D(E);
+         DvS(C, J)  = Dv * Sign;                 // TendencyTerms.h:48  DvEdge*EdgeSignOnCell*...
+         DivC(C, J) = Dv * InvAreaCell * Sign;   // KineticAuxVars.h:38, VelocityDel2AuxVars.h:58
+         const Real AreaEdge = 0.5 * Dv * Dc;    // KineticAuxVars.h:32
+         KEC(C, J)  = AreaEdge * 0.5 * InvAreaCell; // KineticAuxVars.h:35
+         MDvS(C, J) = M * Dv * Sign;             // TendencyTerms.h:363-364
+         const Real DvDcEdge = Dv / Dc;          // TracerAuxVars.h:76
+         D2T(C, J)           = M * Sign * DvDcEdge; // TracerAuxVars.h:81-82
+         const Real RTemp2   = MeshScalingDel2H(E) * Dv / Dc; // TendencyTerms.h:410-411
+         Df2(C, J)           = M * Sign * RTemp2;             // TendencyTerms.h:418-419
+         const Real RTemp4   = MeshScalingDel4H(E) * Dv / Dc; // TendencyTerms.h:464-465
+         Df4(C, J)           = M * Sign * RTemp4;             // TendencyTerms.h:472-473
+         COEOC.V[((size_t)C * ME + J) * 2 + 0] = CellsOnEdgeH(E, 0);
+         COEOC.V[((size_t)C * ME + J) * 2 + 1] = CellsOnEdgeH(E, 1);
+      }
+   }
+   HostArrayReal KiteC(NVerticesSize, VD, 1, 0.0), VortC(NVerticesSize, VD, 1, 0.0);
+   for (int V = 0; V < NVerticesAll; ++V) {
+      const Real InvAreaTriangle = 1. / AreaTriangleH(V);
+      for (int J = 0; J < VD; ++J) {
+         const int E = EdgesOnVertexH(V, J);
+         KiteC(V, J) = InvAreaTriangle * KiteAreasOnVertexH(V, J);              // VorticityAuxVars.h:41-42
+         VortC(V, J) = InvAreaTriangle * DcEdgeH(E) * EdgeSignOnVertexH(V, J);  // VorticityAuxVars.h:44-45
+      }
+   }
+   HostArrayReal IDc(NEdgesSize, 1, 1, 0.0), IDv(NEdgesSize, 1, 1, 0.0), IDv2(NEdgesSize, 1, 1, 0.0);
+   HostArrayI4 PVS(NEdgesSize, ME2, 4, 0);
+   for (int E = 0; E < NEdgesSize; ++E)
+      for (int J = 0; J < ME2; ++J) {
+         int *P = &PVS.V[((size_t)E * ME2 + J) * 4];
+         P[0] = P[1] = NCellsAll;
+         P[2] = P[3] = NVerticesAll;
+      }
+   for (int E = 0; E < NEdgesAll; ++E) {
+      IDc(E)  = 1. / DcEdgeH(E);                                   // TendencyTerms.h:133
+      IDv(E)  = 1. / DvEdgeH(E);                                   // TendencyTerms.h:207
+      IDv2(E) = 1. / std::max(DvEdgeH(E), 0.25 * DcEdgeH(E));      // VelocityDel2AuxVars.h:32-33
+      for (int J = 0; J < NEdgesOnEdgeH(E); ++J) {
+         const int JE = EdgesOnEdgeH(E, J);
+         int *P       = &PVS.V[((size_t)E * ME2 + J) * 4];
+         P[0]         = CellsOnEdgeH(JE, 0);
+         P[1]         = CellsOnEdgeH(JE, 1);
+         P[2]         = VerticesOnEdgeH(JE, 0);
+         P[3]         = VerticesOnEdgeH(JE, 1);
+      }
+   }
+
+   EdgeMask1D        = createDeviceMirrorCopy<Real, 1>("EdgeMask1D", Mask1D);
+   InvAreaCell       = createDeviceMirrorCopy<Real, 1>("InvAreaCell", InvA);
+   DvSignOnCell      = createDeviceMirrorCopy<Real, 2>("DvSignOnCell", DvS);
+   DivCoefOnCell     = createDeviceMirrorCopy<Real, 2>("DivCoefOnCell", DivC);
+   KECoefOnCell      = createDeviceMirrorCopy<Real, 2>("KECoefOnCell", KEC);
+   MaskDvSignOnCell  = createDeviceMirrorCopy<Real, 2>("MaskDvSignOnCell", MDvS);
+   Del2TrCoefOnCell  = createDeviceMirrorCopy<Real, 2>("Del2TrCoefOnCell", D2T);
+   Diff2CoefOnCell   = createDeviceMirrorCopy<Real, 2>("Diff2CoefOnCell", Df2);
+   Diff4CoefOnCell   = createDeviceMirrorCopy<Real, 2>("Diff4CoefOnCell", Df4);
+   CellsOnEdgeOnCell = createDeviceMirrorCopy<I4, 3>("CellsOnEdgeOnCell", COEOC);
+   KiteCoefOnVertex  = createDeviceMirrorCopy<Real, 2>("KiteCoefOnVertex", KiteC);
+   VortCoefOnVertex  = createDeviceMirrorCopy<Real, 2>("VortCoefOnVertex", VortC);
+   InvDcEdge         = createDeviceMirrorCopy<Real, 1>("InvDcEdge", IDc);
+   InvDvEdge         = createDeviceMirrorCopy<Real, 1>("InvDvEdge", IDv);
+   InvDvEdgeDel2     = createDeviceMirrorCopy<Real, 1>("InvDvEdgeDel2", IDv2);
+   PVStencil         = createDeviceMirrorCopy<I4, 3>("PVStencil", PVS);
+
+   MeshView &W = View;
+   W.NCellsOwned = NCellsOwned, W.NCellsAll = NCellsAll, W.NCellsSize = NCellsSize;
+   W.NEdgesOwned = NEdgesOwned, W.NEdgesAll = NEdgesAll, W.NEdgesSize = NEdgesSize;
+   W.NVerticesOwned = NVerticesOwned, W.NVerticesAll = NVerticesAll, W.NVerticesSize = NVerticesSize;
+   W.MaxEdges = MaxEdges, W.MaxEdges2 = MaxEdges2, W.VertexDegree = VertexDegree;
+   W.NEdgesOnCell = NEdgesOnCell.Ptr, W.EdgesOnCell = EdgesOnCell.Ptr, W.CellsOnCell = CellsOnCell.Ptr;
+   W.VerticesOnCell = VerticesOnCell.Ptr, W.CellsOnEdge = CellsOnEdge.Ptr, W.VerticesOnEdge = VerticesOnEdge.Ptr;
+   W.NEdgesOnEdge = NEdgesOnEdge.Ptr, W.EdgesOnEdge = EdgesOnEdge.Ptr, W.CellsOnVertex = CellsOnVertex.Ptr;
+   W.EdgesOnVertex = EdgesOnVertex.Ptr;
+   W.AreaCell = AreaCell.Ptr, W.AreaTriangle = AreaTriangle.Ptr, W.KiteAreasOnVertex = KiteAreasOnVertex.Ptr;
+   W.DcEdge = DcEdge.Ptr, W.DvEdge = DvEdge.Ptr, W.AngleEdge = AngleEdge.Ptr, W.WeightsOnEdge = WeightsOnEdge.Ptr;
+   W.FVertex = FVertex.Ptr, W.BottomDepth = BottomDepth.Ptr;
+   W.EdgeSignOnCell = EdgeSignOnCell.Ptr, W.EdgeSignOnVertex = EdgeSignOnVertex.Ptr, W.EdgeMask = EdgeMask.Ptr;
+   W.EdgeMask1D = EdgeMask1D.Ptr, W.MeshScalingDel2 = MeshScalingDel2.Ptr, W.MeshScalingDel4 = MeshScalingDel4.Ptr;
+   W.InvAreaCell = InvAreaCell.Ptr, W.DvSignOnCell = DvSignOnCell.Ptr, W.DivCoefOnCell = DivCoefOnCell.Ptr;
+   W.KECoefOnCell = KECoefOnCell.Ptr, W.MaskDvSignOnCell = MaskDvSignOnCell.Ptr;
+   W.Del2TrCoefOnCell = Del2TrCoefOnCell.Ptr, W.Diff2CoefOnCell = Diff2CoefOnCell.Ptr;
+   W.Diff4CoefOnCell = Diff4CoefOnCell.Ptr, W.CellsOnEdgeOnCell = CellsOnEdgeOnCell.Ptr;
+   W.KiteCoefOnVertex = KiteCoefOnVertex.Ptr, W.VortCoefOnVertex = VortCoefOnVertex.Ptr;
+   W.InvDcEdge = InvDcEdge.Ptr, W.InvDvEdge = InvDvEdge.Ptr, W.InvDvEdgeDel2 = InvDvEdgeDel2.Ptr;
+   W.PVStencil = PVStencil.Ptr;
+}
+
+} // namespace OMEGA

@@ -1,0 +1,106 @@
+// HorzMesh.h -- local horizontal mesh of one rank: connectivity from Decomp, geometry
+// from the global mesh arrays, the derived sign / mask / scaling arrays and their
+// device mirrors.  Public member names follow the reference
+// (components/omega/src/ocn/HorzMesh.h:100-265); derived arrays follow
+// components/omega/src/ocn/HorzMesh.cpp:527-626.
+//
+// MI355X-first additions: `EdgeMask1D` (the reference's EdgeMask(E,K) is level
+// independent, HorzMesh.cpp:589-598) and per-(cell,j) / per-(vertex,j) / per-(edge,j)
+// coefficient tables that hold the level-independent PREFIX of each reference product
+// chain, evaluated on the host in the same left-to-right order, so the device kernels
+// reproduce the reference arithmetic bit for bit while staging one coefficient per
+// neighbour through LDS.
+#ifndef OMEGA_AMD_HORZMESH_H
+#define OMEGA_AMD_HORZMESH_H
+
+#include "Base.h"
+#include "Decomp.h"
+
+namespace OMEGA {
+
+/// Plain device-pointer view of the mesh handed to kernels by value.
+struct MeshView {
+   I4 NCellsOwned, NCellsAll, NCellsSize, NEdgesOwned, NEdgesAll, NEdgesSize;
+   I4 NVerticesOwned, NVerticesAll, NVerticesSize, MaxEdges, MaxEdges2, VertexDegree;
+   const I4 *NEdgesOnCell, *EdgesOnCell, *CellsOnCell, *VerticesOnCell;
+   const I4 *CellsOnEdge, *VerticesOnEdge, *NEdgesOnEdge, *EdgesOnEdge;
+   const I4 *CellsOnVertex, *EdgesOnVertex;
+   const Real *AreaCell, *AreaTriangle, *KiteAreasOnVertex, *DcEdge, *DvEdge, *AngleEdge;
+   const Real *WeightsOnEdge, *FVertex, *BottomDepth;
+   const Real *EdgeSignOnCell, *EdgeSignOnVertex, *EdgeMask, *EdgeMask1D;
+   const Real *MeshScalingDel2, *MeshScalingDel4;
+   // ---- coefficient tables (see HorzMesh::buildCoefficientTables) ----
+   const Real *InvAreaCell;        // [C]      1/AreaCell
+   const Real *DvSignOnCell;       // [C][ME]  DvEdge*EdgeSignOnCell
+   const Real *DivCoefOnCell;      // [C][ME]  DvEdge*InvAreaCell*EdgeSignOnCell
+   const Real *KECoefOnCell;       // [C][ME]  (0.5*DvEdge*DcEdge)*0.5*InvAreaCell
+   const Real *MaskDvSignOnCell;   // [C][ME]  EdgeMask*DvEdge*EdgeSignOnCell
+   const Real *Del2TrCoefOnCell;   // [C][ME]  EdgeMask*EdgeSignOnCell*(DvEdge/DcEdge)
+   const Real *Diff2CoefOnCell;    // [C][ME]  EdgeMask*EdgeSignOnCell*(MeshScalingDel2*DvEdge/DcEdge)
+   const Real *Diff4CoefOnCell;    // [C][ME]  EdgeMask*EdgeSignOnCell*(MeshScalingDel4*DvEdge/DcEdge)
+   const I4 *CellsOnEdgeOnCell;    // [C][ME][2] CellsOnEdge(EdgesOnCell(c,j), 0..1)
+   const Real *KiteCoefOnVertex;   // [V][VD]  InvAreaTriangle*KiteAreasOnVertex
+   const Real *VortCoefOnVertex;   // [V][VD]  InvAreaTriangle*DcEdge*EdgeSignOnVertex
+   const Real *InvDcEdge;          // [E]      1/DcEdge
+   const Real *InvDvEdge;          // [E]      1/DvEdge
+   const Real *InvDvEdgeDel2;      // [E]      1/max(DvEdge, 0.25*DcEdge)
+   const I4 *PVStencil;            // [E][ME2][4] CellsOnEdge / VerticesOnEdge of EdgesOnEdge(e,j)
+};
+
+class HorzMesh {
+ public:
+   HorzMesh(const std::string &Name, const Decomp *MeshDecomp, I4 NVertLayers, bool HostOnly = false);
+   bool HostOnly; ///< host arrays only (no device mirrors): compute calls are rejected
+
+   std::string MeshName;
+   I4 NVertLayers;
+
+   I4 NCellsOwned, NCellsAll, NCellsSize;
+   I4 NEdgesOwned, NEdgesAll, NEdgesSize, MaxCellsOnEdge, MaxEdges, MaxEdges2;
+   I4 NVerticesOwned, NVerticesAll, NVerticesSize, VertexDegree;
+   HostArrayI4 NCellsHaloH, NEdgesHaloH, NVerticesHaloH;
+
+   // connectivity (host + device)
+   HostArrayI4 CellsOnCellH, EdgesOnCellH, NEdgesOnCellH, VerticesOnCellH, CellsOnEdgeH, EdgesOnEdgeH,
+       NEdgesOnEdgeH, VerticesOnEdgeH, CellsOnVertexH, EdgesOnVertexH;
+   Array2DI4 CellsOnCell, EdgesOnCell, VerticesOnCell, CellsOnEdge, EdgesOnEdge, VerticesOnEdge, CellsOnVertex,
+       EdgesOnVertex;
+   Array1DI4 NEdgesOnCell, NEdgesOnEdge;
+
+   // coordinates (host only, as in the reference, plus X/Y device copies)
+   HostArrayReal XCellH, YCellH, ZCellH, LonCellH, LatCellH, XEdgeH, YEdgeH, ZEdgeH, LonEdgeH, LatEdgeH, XVertexH,
+       YVertexH, ZVertexH, LonVertexH, LatVertexH;
+
+   // measurements, weights, Coriolis, depth
+   HostArrayReal AreaCellH, AreaTriangleH, KiteAreasOnVertexH, DvEdgeH, DcEdgeH, AngleEdgeH, WeightsOnEdgeH, FEdgeH,
+       FCellH, FVertexH, BottomDepthH;
+   Array1DReal AreaCell, AreaTriangle, DvEdge, DcEdge, AngleEdge, FVertex, BottomDepth;
+   Array2DReal KiteAreasOnVertex, WeightsOnEdge;
+
+   // derived
+   HostArrayReal EdgeSignOnCellH, EdgeSignOnVertexH, EdgeMaskH, MeshScalingDel2H, MeshScalingDel4H;
+   Array2DReal EdgeSignOnCell, EdgeSignOnVertex, EdgeMask;
+   Array1DReal EdgeMask1D, MeshScalingDel2, MeshScalingDel4;
+
+   /// Replace FVertex (the reference's tests override it, AuxiliaryVarsTest.cpp:333-338)
+   void setFVertex(const Real *HostValues /* NVerticesSize */);
+
+   const MeshView &view() const { return View; }
+
+ private:
+   void computeEdgeSign();   // HorzMesh.cpp:527-575
+   void setMasks();          // HorzMesh.cpp:581-602
+   void setMeshScaling();    // HorzMesh.cpp:607-626
+   void copyToDevice();      // HorzMesh.cpp:630-...
+   void buildCoefficientTables();
+
+   MeshView View;
+   // coefficient tables (device)
+   Array1DReal InvAreaCell, InvDcEdge, InvDvEdge, InvDvEdgeDel2;
+   Array2DReal DvSignOnCell, DivCoefOnCell, KECoefOnCell, MaskDvSignOnCell, Del2TrCoefOnCell, Diff2CoefOnCell,
+       Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex;
+   DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
+};
+
+} // namespace OMEGA
+#endif

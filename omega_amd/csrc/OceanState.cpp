@@ -1,0 +1,135 @@
+// OceanState.cpp -- see OceanState.h.
+#include "OceanState.h"
+#include "Halo.h"
+
+namespace OMEGA {
+
+OceanState::OceanState(const std::string &Name_, const HorzMesh *Mesh, Halo *MeshHalo_, int NVertLayers_,
+                       int NTimeLevels_)
+    : Name(Name_), MeshHalo(MeshHalo_) {
+   OMEGA_REQUIRE(NTimeLevels_ >= 1 && NTimeLevels_ <= 5, "OceanState: NTimeLevels must be in [1,5]");
+   NCellsOwned = Mesh->NCellsOwned, NCellsAll = Mesh->NCellsAll, NCellsSize = Mesh->NCellsSize;
+   NEdgesOwned = Mesh->NEdgesOwned, NEdgesAll = Mesh->NEdgesAll, NEdgesSize = Mesh->NEdgesSize;
+   NVertLayers = NVertLayers_;
+   NTimeLevels = NTimeLevels_;
+   for (int I = 0; I < NTimeLevels; ++I) {
+      LayerThickness.emplace_back("LayerThickness" + std::to_string(I), NCellsSize, NVertLayers);
+      NormalVelocity.emplace_back("NormalVelocity" + std::to_string(I), NEdgesSize, NVertLayers);
+   }
+}
+
+// OceanState::getTimeIndex (OceanState.cpp:394-407)
+I4 OceanState::getTimeIndex(I4 &TimeIndex, I4 TimeLevel) const {
+   if (NTimeLevels > 1 && (TimeLevel > 1 || (TimeLevel + NTimeLevels) <= 1))
+      return -1;
+   TimeIndex = (TimeLevel + CurTimeIndex + NTimeLevels) % NTimeLevels;
+   return 0;
+}
+I4 OceanState::getLayerThickness(Array2DReal &A, I4 TimeLevel) const {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   A = LayerThickness[Idx];
+   return 0;
+}
+I4 OceanState::getNormalVelocity(Array2DReal &A, I4 TimeLevel) const {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   A = NormalVelocity[Idx];
+   return 0;
+}
+// OceanState::exchangeHalo (OceanState.cpp:333-345)
+I4 OceanState::exchangeHalo(I4 TimeLevel, hipStream_t S) {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   if (!MeshHalo)
+      return 0;
+   I4 Err = MeshHalo->exchangeFullArrayHalo(LayerThickness[Idx], OnCell, S);
+   Err += MeshHalo->exchangeFullArrayHalo(NormalVelocity[Idx], OnEdge, S);
+   return Err;
+}
+// OceanState::updateTimeLevels (OceanState.cpp:349-365)
+void OceanState::updateTimeLevels(hipStream_t S) {
+   OMEGA_REQUIRE(NTimeLevels > 1, "OceanState: can't update time levels for NTimeLevels == 1");
+   exchangeHalo(1, S);
+   rotateTimeLevels();
+}
+void OceanState::rotateTimeLevels() { CurTimeIndex = (CurTimeIndex + 1) % NTimeLevels; }
+
+I4 OceanState::copyToDevice(const Real *HH, const Real *HU, I4 TimeLevel) {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   if (HH)
+      OMEGA::copyToDevice(LayerThickness[Idx].Ptr, HH, LayerThickness[Idx].bytes());
+   if (HU)
+      OMEGA::copyToDevice(NormalVelocity[Idx].Ptr, HU, NormalVelocity[Idx].bytes());
+   return 0;
+}
+I4 OceanState::copyToHost(Real *HH, Real *HU, I4 TimeLevel) const {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   if (HH)
+      OMEGA::copyToHost(HH, LayerThickness[Idx].Ptr, LayerThickness[Idx].bytes());
+   if (HU)
+      OMEGA::copyToHost(HU, NormalVelocity[Idx].Ptr, NormalVelocity[Idx].bytes());
+   return 0;
+}
+
+Tracers::Tracers(const HorzMesh *Mesh, Halo *MeshHalo_, int NVertLayers_, int NTracers_, int NTimeLevels_)
+    : MeshHalo(MeshHalo_) {
+   OMEGA_REQUIRE(NTimeLevels_ >= 1 && NTracers_ >= 0, "Tracers: bad sizes");
+   NTracers = NTracers_, NTimeLevels = NTimeLevels_, NVertLayers = NVertLayers_;
+   NCellsOwned = Mesh->NCellsOwned, NCellsAll = Mesh->NCellsAll, NCellsSize = Mesh->NCellsSize;
+   for (int I = 0; I < NTimeLevels; ++I)
+      TracerArrays.emplace_back("TracerArrays" + std::to_string(I), NTracers > 0 ? NTracers : 1, NCellsSize,
+                                NVertLayers);
+}
+I4 Tracers::getTimeIndex(I4 &TimeIndex, I4 TimeLevel) const {
+   if (NTimeLevels > 1 && (TimeLevel > 1 || (TimeLevel + NTimeLevels) <= 1))
+      return -1;
+   TimeIndex = (TimeLevel + CurTimeIndex + NTimeLevels) % NTimeLevels;
+   return 0;
+}
+I4 Tracers::getAll(Array3DReal &A, I4 TimeLevel) const {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   A = TracerArrays[Idx];
+   return 0;
+}
+I4 Tracers::exchangeHalo(I4 TimeLevel, hipStream_t S) {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   if (!MeshHalo || NTracers == 0)
+      return 0;
+   return MeshHalo->exchangeFullArrayHalo(TracerArrays[Idx], OnCell, S);
+}
+void Tracers::updateTimeLevels(hipStream_t S) {
+   OMEGA_REQUIRE(NTimeLevels > 1, "Tracers: can't update time levels for NTimeLevels == 1");
+   exchangeHalo(1, S);
+   rotateTimeLevels();
+}
+void Tracers::rotateTimeLevels() { CurTimeIndex = (CurTimeIndex + 1) % NTimeLevels; }
+I4 Tracers::copyToDevice(const Real *H, I4 TimeLevel) {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   if (NTracers > 0)
+      OMEGA::copyToDevice(TracerArrays[Idx].Ptr, H, (size_t)NTracers * NCellsSize * NVertLayers * sizeof(Real));
+   return 0;
+}
+I4 Tracers::copyToHost(Real *H, I4 TimeLevel) const {
+   I4 Idx;
+   if (getTimeIndex(Idx, TimeLevel) != 0)
+      return -1;
+   if (NTracers > 0)
+      OMEGA::copyToHost(H, TracerArrays[Idx].Ptr, (size_t)NTracers * NCellsSize * NVertLayers * sizeof(Real));
+   return 0;
+}
+
+} // namespace OMEGA

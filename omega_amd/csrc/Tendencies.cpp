@@ -1,0 +1,92 @@
+// Tendencies.cpp -- see Tendencies.h.
+#include "Tendencies.h"
+
+namespace OMEGA {
+
+Tendencies::Tendencies(const std::string &, const HorzMesh *Mesh_, int K, int NT, const TendParams &Options)
+    : Params(Options), Mesh(Mesh_), NVertLayers(K), NTracers(NT) {
+   // Tendency arrays (Tendencies.cpp:233-238)
+   LayerThicknessTend = Array2DReal("LayerThicknessTend", Mesh->NCellsSize, K);
+   NormalVelocityTend = Array2DReal("NormalVelocityTend", Mesh->NEdgesSize, K);
+   TracerTend         = Array3DReal("TracerTend", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+}
+
+TendParams Tendencies::paramsFor(const AuxiliaryState *Aux) const {
+   TendParams P          = Params;
+   P.FluxThicknessUpwind = Aux->LayerThicknessAux.FluxThickEdgeChoice == FluxThickEdgeOption::Upwind;
+   P.FluxTracerUpwind    = Aux->TracerAux.TracersOnEdgeChoice == FluxTracerEdgeOption::Upwind;
+   P.WindInterpIsotropic = Aux->WindForcingAux.InterpChoice == InterpCellToEdgeOption::Isotropic;
+   return P;
+}
+
+// Tendencies.cpp:257-297
+void Tendencies::computeThicknessTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int, int VelLvl,
+                                                hipStream_t S) {
+   Array2DReal NormalVelEdge;
+   OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
+   launchThicknessTendOnly(Mesh->view(), NVertLayers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
+                           NormalVelEdge.Ptr, S);
+}
+// Tendencies.cpp:301-423
+void Tendencies::computeVelocityTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int, int VelLvl,
+                                               hipStream_t S) {
+   Array2DReal NormalVelEdge;
+   OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
+   launchVelocityTendOnly(Mesh->view(), NVertLayers, paramsFor(Aux), Aux->ptrs(), NormalVelocityTend.Ptr,
+                          NormalVelEdge.Ptr, S);
+}
+// Tendencies.cpp:427-486
+void Tendencies::computeTracerTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux,
+                                             const Array3DReal &TracerArray, int, int VelLvl, hipStream_t S) {
+   Array2DReal NormalVelEdge;
+   OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
+   launchTracerTendOnly(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), TracerTend.Ptr,
+                        NormalVelEdge.Ptr, TracerArray.Ptr, S);
+}
+// Tendencies.cpp:488-519
+void Tendencies::computeThicknessTendencies(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
+                                            hipStream_t S) {
+   Array2DReal LayerThick, NormVel;
+   OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
+                 "Tendencies: bad time level");
+   const TendParams P = paramsFor(Aux);
+   launchLayerThickAuxEdge(Mesh->view(), NVertLayers, Aux->ptrs(), LayerThick.Ptr, NormVel.Ptr, P.FluxThicknessUpwind, S);
+   computeThicknessTendenciesOnly(State, Aux, ThickLvl, VelLvl, S);
+}
+// Tendencies.cpp:521-535
+void Tendencies::computeVelocityTendencies(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
+                                           hipStream_t S) {
+   Aux->computeMomAux(State, ThickLvl, VelLvl, S);
+   computeVelocityTendenciesOnly(State, Aux, ThickLvl, VelLvl, S);
+}
+// Tendencies.cpp:537-575
+void Tendencies::computeTracerTendencies(const OceanState *State, const AuxiliaryState *Aux,
+                                         const Array3DReal &TracerArray, int ThickLvl, int VelLvl, hipStream_t S) {
+   Array2DReal LayerThick, NormVel;
+   OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
+                 "Tendencies: bad time level");
+   const TendParams P = paramsFor(Aux);
+   launchEdgeAuxState4(Mesh->view(), NVertLayers, NTracers, Aux->ptrs(), NormVel.Ptr, LayerThick.Ptr, TracerArray.Ptr,
+                       P.FluxTracerUpwind, S);
+   launchCellAuxState4(Mesh->view(), NVertLayers, NTracers, Aux->ptrs(), TracerArray.Ptr, S);
+   computeTracerTendenciesOnly(State, Aux, TracerArray, ThickLvl, VelLvl, S);
+}
+// Tendencies.cpp:579-600
+void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
+                                      int ThickLvl, int VelLvl, hipStream_t S) {
+   if (UseFusedRHS && Mesh->MaxEdges <= 8) {
+      Array2DReal LayerThick, NormVel;
+      OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 &&
+                        State->getNormalVelocity(NormVel, VelLvl) == 0,
+                    "Tendencies: bad time level");
+      launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
+                     NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S);
+      return;
+   }
+   Aux->computeAll(State, TracerArray, ThickLvl, VelLvl, S);
+   computeThicknessTendenciesOnly(State, Aux, ThickLvl, VelLvl, S);
+   computeVelocityTendenciesOnly(State, Aux, ThickLvl, VelLvl, S);
+   computeTracerTendenciesOnly(State, Aux, TracerArray, ThickLvl, VelLvl, S);
+}
+
+} // namespace OMEGA

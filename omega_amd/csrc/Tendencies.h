@@ -1,0 +1,54 @@
+// Tendencies.h -- RHS tendencies of layer thickness, normal velocity and tracers.
+// Interface after the reference (components/omega/src/ocn/Tendencies.h:73-144;
+// Tendencies.cpp:217-600).  The `TimeInstant` argument of the reference is only forwarded
+// to custom-tendency hooks (Tendencies.cpp:288-293), which are out of scope here, so the
+// methods take the stream instead.
+#ifndef OMEGA_AMD_TENDENCIES_H
+#define OMEGA_AMD_TENDENCIES_H
+
+#include "AuxiliaryState.h"
+#include "Base.h"
+#include "kernels/Kernels.h"
+
+namespace OMEGA {
+
+class Tendencies {
+ public:
+   Tendencies(const std::string &Name, const HorzMesh *Mesh, int NVertLayers, int NTracers, const TendParams &Options);
+
+   Array2DReal LayerThicknessTend; ///< (NCellsSize, NVertLayers)
+   Array2DReal NormalVelocityTend; ///< (NEdgesSize, NVertLayers)
+   Array3DReal TracerTend;         ///< (NTracers, NCellsSize, NVertLayers)
+
+   TendParams Params; ///< enable flags and coefficients (readTendConfig)
+   /// Fused RHS for computeAllTendencies (default on); off = the reference's launch
+   /// structure (every AuxiliaryState array materialised).
+   bool UseFusedRHS = true;
+
+   void computeThicknessTendenciesOnly(const OceanState *State, const AuxiliaryState *AuxState, int ThickTimeLevel,
+                                       int VelTimeLevel, hipStream_t S);
+   void computeVelocityTendenciesOnly(const OceanState *State, const AuxiliaryState *AuxState, int ThickTimeLevel,
+                                      int VelTimeLevel, hipStream_t S);
+   void computeTracerTendenciesOnly(const OceanState *State, const AuxiliaryState *AuxState,
+                                    const Array3DReal &TracerArray, int ThickTimeLevel, int VelTimeLevel,
+                                    hipStream_t S);
+   void computeThicknessTendencies(const OceanState *State, const AuxiliaryState *AuxState, int ThickTimeLevel,
+                                   int VelTimeLevel, hipStream_t S);
+   void computeVelocityTendencies(const OceanState *State, const AuxiliaryState *AuxState, int ThickTimeLevel,
+                                  int VelTimeLevel, hipStream_t S);
+   void computeTracerTendencies(const OceanState *State, const AuxiliaryState *AuxState,
+                                const Array3DReal &TracerArray, int ThickTimeLevel, int VelTimeLevel, hipStream_t S);
+   void computeAllTendencies(const OceanState *State, const AuxiliaryState *AuxState, const Array3DReal &TracerArray,
+                             int ThickTimeLevel, int VelTimeLevel, hipStream_t S);
+
+   const HorzMesh *Mesh;
+   int NVertLayers, NTracers;
+
+ private:
+   /// AuxiliaryState options are read by AuxiliaryState::readConfigOptions in the reference;
+   /// the kernels take them through TendParams, so sync them from the AuxState in use.
+   TendParams paramsFor(const AuxiliaryState *AuxState) const;
+};
+
+} // namespace OMEGA
+#endif

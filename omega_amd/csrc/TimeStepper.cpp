@@ -1,0 +1,285 @@
+// TimeStepper.cpp -- see TimeStepper.h.
+#include "TimeStepper.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+
+namespace OMEGA {
+
+// ---- TimeFrac arithmetic of the reference's TimeMgr, restricted to what `Real *
+// TimeInterval` and TimeInterval::get(seconds) need ----
+namespace {
+struct TimeFrac {
+   I8 Whole = 0, Numer = 0, Denom = 1;
+};
+I8 fracGCD(I8 A, I8 B) {
+   A = std::llabs(A);
+   B = std::llabs(B);
+   if (A == 0)
+      return B ? B : 1;
+   if (B == 0)
+      return A;
+   while (B) {
+      I8 T = A % B;
+      A    = B;
+      B    = T;
+   }
+   return A;
+}
+// TimeFrac::simplify (TimeMgr.cpp:956-1000)
+void simplify(TimeFrac &F) {
+   I8 W;
+   if (std::llabs((W = F.Numer / F.Denom)) >= 1) {
+      F.Whole += W;
+      F.Numer %= F.Denom;
+   }
+   if (F.Whole > 0 && ((F.Numer < 0 && F.Denom > 0) || (F.Denom < 0 && F.Numer > 0))) {
+      F.Whole--;
+      F.Numer += F.Denom;
+   } else if ((F.Whole < 0 && (F.Numer > 0 && F.Denom > 0)) || (F.Denom < 0 && F.Numer < 0)) {
+      F.Whole++;
+      F.Numer -= F.Denom;
+   }
+   if (F.Denom < 0) {
+      F.Denom *= -1;
+      F.Numer *= -1;
+   }
+   const I8 G = fracGCD(F.Numer, F.Denom);
+   F.Numer /= G;
+   F.Denom /= G;
+}
+// TimeFrac::setSeconds (TimeMgr.cpp:193-283): continued-fraction conversion
+TimeFrac fromSeconds(R8 Seconds) {
+   TimeFrac F;
+   const R8 Rabs = std::fabs(Seconds);
+   OMEGA_REQUIRE(!((Rabs > 0.0 && Rabs < 1e-17) || Rabs > 1e18), "TimeStepper: time value out of range");
+   const int Sign = (Seconds < 0) ? -1 : 1;
+   R8 Target      = Rabs;
+   if (Target == 0.0)
+      return F;
+   if (Target >= 1.0) {
+      const I8 W = (I8)Rabs;
+      Target -= (R8)W;
+      F.Whole = Sign * W;
+      if (Target < 1e-17)
+         return F;
+   }
+   const R8 P = std::pow(10.0, -(DBL_DIG - (int)std::log10(Rabs)));
+   R8 R       = Target;
+   I8 Npp = 0, Np = 1, Dpp = 1, Dp = 0, A, N, D;
+   for (;;) {
+      A = (I8)R;
+      N = A * Np + Npp;
+      D = A * Dp + Dpp;
+      if (std::fabs((R8)N / (R8)D - Target) < P)
+         break;
+      const R8 Fr = R - (R8)A;
+      if (Fr < 1e-17)
+         break;
+      R   = 1.0 / Fr;
+      Npp = Np;
+      Np  = N;
+      Dpp = Dp;
+      Dp  = D;
+   }
+   F.Numer = N * Sign;
+   F.Denom = D;
+   simplify(F);
+   return F;
+}
+} // namespace
+
+R8 TimeStepper::coeffSeconds(R8 Mult, R8 TimeStepSeconds) {
+   const TimeFrac T = fromSeconds(TimeStepSeconds), M = fromSeconds(Mult);
+   TimeFrac P; // TimeFrac::operator*(R8) (TimeMgr.cpp:747-767)
+   P.Denom = T.Denom * M.Denom;
+   P.Numer = (T.Whole * T.Denom + T.Numer) * (M.Whole * M.Denom + M.Numer);
+   simplify(P);
+   return (R8)P.Whole + (R8)P.Numer / (R8)P.Denom; // TimeFrac::getSeconds (:382-391)
+}
+
+TimeStepper::TimeStepper(const std::string &Name_, TimeStepperType Type_, int NTimeLevels_, R8 Dt)
+    : Name(Name_), Type(Type_), NTimeLevels(NTimeLevels_), TimeStep(Dt) {
+   OMEGA_REQUIRE(Dt > 0, "TimeStepper: time step must be positive");
+}
+
+TimeStepperType TimeStepper::getFromStr(const std::string &In) {
+   if (In == "Forward-Backward")
+      return TimeStepperType::ForwardBackward;
+   if (In == "RungeKutta4")
+      return TimeStepperType::RungeKutta4;
+   if (In == "RungeKutta2")
+      return TimeStepperType::RungeKutta2;
+   return TimeStepperType::Invalid;
+}
+
+TimeStepper *TimeStepper::create(const std::string &Name, TimeStepperType Type, R8 Dt) {
+   switch (Type) {
+   case TimeStepperType::ForwardBackward:
+      return new ForwardBackwardStepper(Name, Dt);
+   case TimeStepperType::RungeKutta4:
+      return new RungeKutta4Stepper(Name, Dt);
+   case TimeStepperType::RungeKutta2:
+      return new RungeKutta2Stepper(Name, Dt);
+   default:
+      OMEGA_ABORT("TimeStepper::create: unknown time stepper type");
+   }
+}
+
+void TimeStepper::attachData(Tendencies *T, AuxiliaryState *A, const HorzMesh *M, Halo *H, Tracers *Tr) {
+   Tend     = T;
+   AuxState = A;
+   Mesh     = M;
+   MeshHalo = H;
+   Trc      = Tr;
+}
+
+// ---- update kernels ----
+void TimeStepper::updateThicknessByTend(OceanState *S1, int L1, OceanState *S2, int L2, R8 C, hipStream_t S) const {
+   Array2DReal H1, H2;
+   OMEGA_REQUIRE(S1->getLayerThickness(H1, L1) == 0 && S2->getLayerThickness(H2, L2) == 0,
+                 "TimeStepper updateThickness: error retrieving layer thick");
+   launchUpdateByTend(Mesh->NCellsAll, H1.Ext[1], H1.Ptr, H2.Ptr, Tend->LayerThicknessTend.Ptr, C, S);
+}
+void TimeStepper::updateVelocityByTend(OceanState *S1, int L1, OceanState *S2, int L2, R8 C, hipStream_t S) const {
+   Array2DReal U1, U2;
+   OMEGA_REQUIRE(S1->getNormalVelocity(U1, L1) == 0 && S2->getNormalVelocity(U2, L2) == 0,
+                 "TimeStepper updateVelocity: error retrieving velocity");
+   launchUpdateByTend(Mesh->NEdgesAll, U1.Ext[1], U1.Ptr, U2.Ptr, Tend->NormalVelocityTend.Ptr, C, S);
+}
+void TimeStepper::updateStateByTend(OceanState *S1, int L1, OceanState *S2, int L2, R8 C, hipStream_t S) const {
+   updateThicknessByTend(S1, L1, S2, L2, C, S);
+   updateVelocityByTend(S1, L1, S2, L2, C, S);
+}
+void TimeStepper::updateTracersByTend(const Array3DReal &Next, const Array3DReal &Cur, OceanState *S1, int L1,
+                                      OceanState *S2, int L2, R8 C, hipStream_t S) const {
+   Array2DReal H1, H2;
+   OMEGA_REQUIRE(S1->getLayerThickness(H1, L1) == 0 && S2->getLayerThickness(H2, L2) == 0,
+                 "TimeStepper updateTracers: error retrieving layer thick");
+   launchUpdateTracersByTend(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H1.Ext[1], Next.Ptr, Cur.Ptr,
+                             H1.Ptr, H2.Ptr, Tend->TracerTend.Ptr, C, S);
+}
+void TimeStepper::weightTracers(const Array3DReal &Next, const Array3DReal &Cur, OceanState *St, int L1,
+                                hipStream_t S) const {
+   Array2DReal H;
+   OMEGA_REQUIRE(St->getLayerThickness(H, L1) == 0, "TimeStepper weightTracers: bad time level");
+   launchWeightTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Ext[1], Next.Ptr, Cur.Ptr, H.Ptr,
+                       S);
+}
+void TimeStepper::accumulateTracersUpdate(const Array3DReal &Accum, R8 C, hipStream_t S) const {
+   launchAccumulateTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, Accum.Ext[2], Accum.Ptr,
+                           Tend->TracerTend.Ptr, C, S);
+}
+void TimeStepper::finalizeTracersUpdate(const Array3DReal &Next, OceanState *St, int L, hipStream_t S) const {
+   Array2DReal H;
+   OMEGA_REQUIRE(St->getLayerThickness(H, L) == 0, "TimeStepper finalizeTracers: bad time level");
+   launchFinalizeTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Ext[1], Next.Ptr, H.Ptr, S);
+}
+
+void TimeStepper::updateTimeLevels(OceanState *State, hipStream_t S) const {
+   if (MeshHalo && MeshHalo->NNghbr > 0) {
+      Array2DReal H, U;
+      Array3DReal Tr;
+      State->getLayerThickness(H, 1);
+      State->getNormalVelocity(U, 1);
+      const int NT = Trc ? Trc->NTracers : 0;
+      if (NT > 0)
+         Trc->getAll(Tr, 1);
+      OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? &Tr : nullptr, NT, S) == 0, "TimeStepper: halo exchange failed");
+   }
+   State->rotateTimeLevels();
+   if (Trc)
+      Trc->rotateTimeLevels();
+}
+
+// ---- ForwardBackwardStepper::doStep (ForwardBackwardStepper.cpp:27-82) ----
+void ForwardBackwardStepper::doStep(OceanState *State, hipStream_t S) {
+   const int CurLevel = 0, NextLevel = 1;
+   Array3DReal CurTracerArray, NextTracerArray;
+   OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
+                 "ForwardBackward doStep: error retrieving tracers");
+   const R8 Dt = coeff(1.0);
+   // R_h^{n} = RHS_h(u^{n}, h^{n}, t^{n});  h^{n+1} = h^{n} + R_h^{n}
+   Tend->computeThicknessTendencies(State, AuxState, CurLevel, CurLevel, S);
+   updateThicknessByTend(State, NextLevel, State, CurLevel, Dt, S);
+   // R_phi^{n};  phi^{n+1} = (phi^{n} * h^{n} + R_phi^{n}) / h^{n+1}
+   Tend->computeTracerTendencies(State, AuxState, CurTracerArray, CurLevel, CurLevel, S);
+   updateTracersByTend(NextTracerArray, CurTracerArray, State, NextLevel, State, CurLevel, Dt, S);
+   // R_u^{n+1} = RHS_u(u^{n}, h^{n+1}, t^{n+1});  u^{n+1} = u^{n} + R_u^{n+1}
+   Tend->computeVelocityTendencies(State, AuxState, NextLevel, CurLevel, S);
+   updateVelocityByTend(State, NextLevel, State, CurLevel, Dt, S);
+   updateTimeLevels(State, S);
+   ++NStepsDone;
+}
+
+// ---- RungeKutta2Stepper::doStep (RungeKutta2Stepper.cpp:27-73) ----
+void RungeKutta2Stepper::doStep(OceanState *State, hipStream_t S) {
+   const int CurLevel = 0, NextLevel = 1;
+   Array3DReal CurTracerArray, NextTracerArray;
+   OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
+                 "RungeKutta2 doStep: error retrieving tracers");
+   const R8 Half = coeff(0.5), Full = coeff(1.0);
+   Tend->computeAllTendencies(State, AuxState, CurTracerArray, CurLevel, CurLevel, S);
+   updateStateByTend(State, NextLevel, State, CurLevel, Half, S);
+   updateTracersByTend(NextTracerArray, CurTracerArray, State, NextLevel, State, CurLevel, Half, S);
+   Tend->computeAllTendencies(State, AuxState, NextTracerArray, NextLevel, NextLevel, S);
+   updateStateByTend(State, NextLevel, State, CurLevel, Full, S);
+   updateTracersByTend(NextTracerArray, CurTracerArray, State, NextLevel, State, CurLevel, Full, S);
+   updateTimeLevels(State, S);
+   ++NStepsDone;
+}
+
+// ---- RungeKutta4Stepper (RungeKutta4Stepper.cpp:17-137) ----
+RungeKutta4Stepper::RungeKutta4Stepper(const std::string &Name, R8 Dt)
+    : TimeStepper(Name, TimeStepperType::RungeKutta4, 2, Dt) {
+   RKA[0] = 0, RKA[1] = 1. / 2, RKA[2] = 1. / 2, RKA[3] = 1;
+   RKB[0] = 1. / 6, RKB[1] = 1. / 3, RKB[2] = 1. / 3, RKB[3] = 1. / 6;
+   RKC[0] = 0, RKC[1] = 1. / 2, RKC[2] = 1. / 2, RKC[3] = 1;
+}
+
+void RungeKutta4Stepper::finalizeInit() {
+   OMEGA_REQUIRE(Tend && Mesh && Trc, "RungeKutta4Stepper: attachData before finalizeInit");
+   const int K = Tend->LayerThicknessTend.Ext[1];
+   ProvisState.reset(new OceanState("Provis" + Name, Mesh, MeshHalo, K, 1)); // 1 time level (:56-60)
+   ProvisTracers = Array3DReal("ProvisTracers", Trc->NTracers > 0 ? Trc->NTracers : 1, Mesh->NCellsSize, K);
+}
+
+void RungeKutta4Stepper::doStep(OceanState *State, hipStream_t S) {
+   if (!ProvisState)
+      finalizeInit();
+   const int CurLevel = 0, NextLevel = 1;
+   Array3DReal NextTracerArray, CurTracerArray;
+   OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
+                 "RungeKutta4 doStep: error retrieving tracers");
+   const int NT = Trc->NTracers;
+   for (int Stage = 0; Stage < NStages; ++Stage) {
+      if (Stage == 0) {
+         // R^{(0)} = RHS(q^{n}, t^{n});  q^{n+1} = q^{n} + dt * RKB[0] * R^{(0)}
+         weightTracers(NextTracerArray, CurTracerArray, State, CurLevel, S);
+         Tend->computeAllTendencies(State, AuxState, CurTracerArray, CurLevel, CurLevel, S);
+         updateStateByTend(State, NextLevel, State, CurLevel, coeff(RKB[Stage]), S);
+         accumulateTracersUpdate(NextTracerArray, coeff(RKB[Stage]), S);
+      } else {
+         // q^{provis} = q^{n} + RKA[stage]*dt*R^{(s-1)};  R^{(s)} = RHS(q^{provis});  q^{n+1} += RKB[stage]*dt*R^{(s)}
+         updateStateByTend(ProvisState.get(), CurLevel, State, CurLevel, coeff(RKA[Stage]), S);
+         updateTracersByTend(ProvisTracers, CurTracerArray, ProvisState.get(), CurLevel, State, CurLevel,
+                             coeff(RKA[Stage]), S);
+         if (Stage == 2 && MeshHalo && MeshHalo->NNghbr > 0) { // depends on the halo width (:107-113)
+            Array2DReal H, U;
+            ProvisState->getLayerThickness(H, CurLevel);
+            ProvisState->getNormalVelocity(U, CurLevel);
+            OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? &ProvisTracers : nullptr, NT, S) == 0,
+                          "RungeKutta4: provisional halo exchange failed");
+         }
+         Tend->computeAllTendencies(ProvisState.get(), AuxState, ProvisTracers, CurLevel, CurLevel, S);
+         updateStateByTend(State, NextLevel, State, NextLevel, coeff(RKB[Stage]), S);
+         accumulateTracersUpdate(NextTracerArray, coeff(RKB[Stage]), S);
+      }
+   }
+   finalizeTracersUpdate(NextTracerArray, State, NextLevel, S);
+   updateTimeLevels(State, S);
+   ++NStepsDone;
+}
+
+} // namespace OMEGA

@@ -1,0 +1,98 @@
+// TimeStepper.h -- time stepping schemes built on Tendencies / AuxiliaryState / Halo.
+// Interface after the reference (components/omega/src/timeStepping/TimeStepper.h:57-237):
+// doStep, the six update kernels, and the ForwardBackward / RungeKutta2 / RungeKutta4
+// schemes (ForwardBackwardStepper.cpp:27-82, RungeKutta2Stepper.cpp:27-73,
+// RungeKutta4Stepper.cpp:25-137).  The clock / alarm machinery of the reference is out of
+// scope: the step is `TimeStepSeconds`, and `Real * TimeInterval` coefficients go through
+// the same integer-fraction arithmetic as the reference's TimeMgr so they are bit-equal.
+#ifndef OMEGA_AMD_TIMESTEPPER_H
+#define OMEGA_AMD_TIMESTEPPER_H
+
+#include "AuxiliaryState.h"
+#include "Halo.h"
+#include "OceanState.h"
+#include "Tendencies.h"
+
+namespace OMEGA {
+
+enum class TimeStepperType { ForwardBackward, RungeKutta4, RungeKutta2, Invalid };
+
+class TimeStepper {
+ public:
+   TimeStepper(const std::string &Name, TimeStepperType Type, int NTimeLevels, R8 TimeStepSeconds);
+   virtual ~TimeStepper() = default;
+
+   /// factory (TimeStepper::create, TimeStepper.h:96-107)
+   static TimeStepper *create(const std::string &Name, TimeStepperType Type, R8 TimeStepSeconds);
+   static TimeStepperType getFromStr(const std::string &In); ///< TimeStepper.h:64-75
+
+   /// attach the objects the scheme works on (TimeStepper::attachData)
+   void attachData(Tendencies *Tend, AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, Tracers *Trc);
+   virtual void finalizeInit() {}
+
+   /// advance State (and the attached Tracers) by one step on stream S
+   virtual void doStep(OceanState *State, hipStream_t S) = 0;
+
+   // update kernels (TimeStepper.cpp:378-524); Coeff is a multiple of the time step
+   void updateThicknessByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2, R8 CoeffSeconds,
+                              hipStream_t S) const;
+   void updateVelocityByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2, R8 CoeffSeconds,
+                             hipStream_t S) const;
+   void updateStateByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2, R8 CoeffSeconds,
+                          hipStream_t S) const;
+   void updateTracersByTend(const Array3DReal &NextTracers, const Array3DReal &CurTracers, OceanState *State1,
+                            int TimeLevel1, OceanState *State2, int TimeLevel2, R8 CoeffSeconds, hipStream_t S) const;
+   void weightTracers(const Array3DReal &NextTracers, const Array3DReal &CurTracers, OceanState *CurState,
+                      int TimeLevel1, hipStream_t S) const;
+   void accumulateTracersUpdate(const Array3DReal &AccumTracer, R8 CoeffSeconds, hipStream_t S) const;
+   void finalizeTracersUpdate(const Array3DReal &NextTracers, OceanState *State, int TimeLevel, hipStream_t S) const;
+
+   /// seconds of (Mult * TimeStep), through TimeFrac arithmetic
+   /// (components/omega/src/infra/TimeMgr.cpp:193-283, 747-767, 956-1000, 382-391)
+   static R8 coeffSeconds(R8 Mult, R8 TimeStepSeconds);
+   R8 coeff(R8 Mult) const { return coeffSeconds(Mult, TimeStep); }
+
+   std::string Name;
+   TimeStepperType Type;
+   int NTimeLevels;
+   R8 TimeStep;
+   I8 NStepsDone = 0;
+
+ protected:
+   /// end-of-step: halo exchange of the new level, then rotate (State->updateTimeLevels();
+   /// Tracers::updateTimeLevels()) -- h, u and tracers travel in one message per neighbour
+   void updateTimeLevels(OceanState *State, hipStream_t S) const;
+   Tendencies *Tend         = nullptr;
+   AuxiliaryState *AuxState = nullptr;
+   const HorzMesh *Mesh     = nullptr;
+   Halo *MeshHalo           = nullptr;
+   Tracers *Trc             = nullptr;
+};
+
+class ForwardBackwardStepper : public TimeStepper {
+ public:
+   ForwardBackwardStepper(const std::string &Name, R8 Dt) : TimeStepper(Name, TimeStepperType::ForwardBackward, 2, Dt) {}
+   void doStep(OceanState *State, hipStream_t S) override;
+};
+
+class RungeKutta2Stepper : public TimeStepper {
+ public:
+   RungeKutta2Stepper(const std::string &Name, R8 Dt) : TimeStepper(Name, TimeStepperType::RungeKutta2, 2, Dt) {}
+   void doStep(OceanState *State, hipStream_t S) override;
+};
+
+class RungeKutta4Stepper : public TimeStepper {
+ public:
+   RungeKutta4Stepper(const std::string &Name, R8 Dt);
+   void finalizeInit() override;
+   void doStep(OceanState *State, hipStream_t S) override;
+
+ protected:
+   static constexpr int NStages = 4;
+   R8 RKA[NStages], RKB[NStages], RKC[NStages];
+   std::unique_ptr<OceanState> ProvisState;
+   Array3DReal ProvisTracers;
+};
+
+} // namespace OMEGA
+#endif

@@ -1,0 +1,782 @@
+// capi.cpp -- extern "C" boundary of libomega_amd.so (see include/omega_amd.h).
+#include "../../include/omega_amd.h"
+
+#include "AuxiliaryState.h"
+#include "Decomp.h"
+#include "Halo.h"
+#include "HorzMesh.h"
+#include "OceanState.h"
+#include "Tendencies.h"
+#include "TimeStepper.h"
+
+#include <cstring>
+#include <map>
+#include <memory>
+
+using namespace OMEGA;
+
+struct omg_decomp {
+   std::unique_ptr<Decomp> D;
+};
+struct omg_halo {
+   std::unique_ptr<Halo> H;
+};
+struct omg_mesh {
+   std::unique_ptr<HorzMesh> M;
+};
+struct omg_state {
+   std::unique_ptr<OceanState> S;
+};
+struct omg_tracers {
+   std::unique_ptr<Tracers> T;
+};
+struct omg_aux {
+   std::unique_ptr<AuxiliaryState> A;
+};
+struct omg_tend {
+   std::unique_ptr<Tendencies> T;
+};
+struct omg_stepper {
+   std::unique_ptr<TimeStepper> St;
+};
+
+static thread_local std::string LastError;
+
+#define OMG_TRY try {
+#define OMG_CATCH                                                              \
+   }                                                                           \
+   catch (const std::exception &E) {                                           \
+      LastError = E.what();                                                    \
+      return 1;                                                                \
+   }                                                                           \
+   catch (...) {                                                               \
+      LastError = "unknown exception";                                         \
+      return 1;                                                                \
+   }                                                                           \
+   return 0;
+
+#define OMG_ARG(cond)                                                          \
+   if (!(cond))                                                                \
+   OMEGA_ABORT(std::string("invalid argument: ") + #cond)
+
+extern "C" {
+
+const char *omg_last_error(void) { return LastError.c_str(); }
+
+int omg_device_count(int *n) {
+   OMG_TRY
+   OMG_ARG(n);
+   int C = 0;
+   if (hipGetDeviceCount(&C) != hipSuccess)
+      C = 0;
+   *n = C;
+   OMG_CATCH
+}
+int omg_device_init(int device_id) {
+   OMG_TRY
+   deviceInit(device_id);
+   OMG_CATCH
+}
+int omg_device_synchronize(void) {
+   OMG_TRY
+   HIP_CHECK(hipDeviceSynchronize());
+   OMG_CATCH
+}
+int omg_stream_create(void **stream) {
+   OMG_TRY
+   OMG_ARG(stream);
+   hipStream_t S;
+   HIP_CHECK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
+   *stream = (void *)S;
+   OMG_CATCH
+}
+int omg_stream_destroy(void *stream) {
+   OMG_TRY
+   if (stream)
+      HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+   OMG_CATCH
+}
+int omg_stream_synchronize(void *stream) {
+   OMG_TRY
+   HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+   OMG_CATCH
+}
+int omg_event_create(void **event) {
+   OMG_TRY
+   OMG_ARG(event);
+   hipEvent_t E;
+   HIP_CHECK(hipEventCreate(&E));
+   *event = (void *)E;
+   OMG_CATCH
+}
+int omg_event_destroy(void *event) {
+   OMG_TRY
+   if (event)
+      HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+   OMG_CATCH
+}
+int omg_event_record(void *event, void *stream) {
+   OMG_TRY
+   HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+   OMG_CATCH
+}
+int omg_event_elapsed_ms(void *start, void *stop, float *ms) {
+   OMG_TRY
+   OMG_ARG(ms);
+   HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+   HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- Decomp
+int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo_width, const int32_t *cell_task,
+                      omg_decomp **out) {
+   OMG_TRY
+   OMG_ARG(m && out);
+   GlobalMeshDesc G;
+   G.NCells = m->nCells, G.NEdges = m->nEdges, G.NVertices = m->nVertices, G.MaxEdges = m->maxEdges;
+   G.VertexDegree = m->vertexDegree;
+   G.CellsOnCell = m->cellsOnCell, G.EdgesOnCell = m->edgesOnCell, G.VerticesOnCell = m->verticesOnCell;
+   G.CellsOnEdge = m->cellsOnEdge, G.VerticesOnEdge = m->verticesOnEdge, G.EdgesOnEdge = m->edgesOnEdge;
+   G.CellsOnVertex = m->cellsOnVertex, G.EdgesOnVertex = m->edgesOnVertex;
+   G.XCell = m->xCell, G.YCell = m->yCell, G.ZCell = m->zCell, G.LonCell = m->lonCell, G.LatCell = m->latCell;
+   G.XEdge = m->xEdge, G.YEdge = m->yEdge, G.ZEdge = m->zEdge, G.LonEdge = m->lonEdge, G.LatEdge = m->latEdge;
+   G.XVertex = m->xVertex, G.YVertex = m->yVertex, G.ZVertex = m->zVertex, G.LonVertex = m->lonVertex;
+   G.LatVertex = m->latVertex;
+   G.AreaCell = m->areaCell, G.AreaTriangle = m->areaTriangle, G.KiteAreasOnVertex = m->kiteAreasOnVertex;
+   G.DcEdge = m->dcEdge, G.DvEdge = m->dvEdge, G.AngleEdge = m->angleEdge, G.WeightsOnEdge = m->weightsOnEdge;
+   G.FCell = m->fCell, G.FEdge = m->fEdge, G.FVertex = m->fVertex, G.BottomDepth = m->bottomDepth;
+   auto *R = new omg_decomp;
+   try {
+      R->D.reset(new Decomp(G, nparts, mytask, halo_width, cell_task));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_decomp_destroy(omg_decomp *d) {
+   delete d;
+   return 0;
+}
+int omg_decomp_get_int(const omg_decomp *d, const char *name, int32_t *out) {
+   OMG_TRY
+   OMG_ARG(d && name && out);
+   const Decomp &D = *d->D;
+   const std::map<std::string, I4> V{{"NCellsGlobal", D.NCellsGlobal},
+                                     {"NCellsOwned", D.NCellsOwned},
+                                     {"NCellsAll", D.NCellsAll},
+                                     {"NCellsSize", D.NCellsSize},
+                                     {"NEdgesGlobal", D.NEdgesGlobal},
+                                     {"NEdgesOwned", D.NEdgesOwned},
+                                     {"NEdgesAll", D.NEdgesAll},
+                                     {"NEdgesSize", D.NEdgesSize},
+                                     {"NVerticesGlobal", D.NVerticesGlobal},
+                                     {"NVerticesOwned", D.NVerticesOwned},
+                                     {"NVerticesAll", D.NVerticesAll},
+                                     {"NVerticesSize", D.NVerticesSize},
+                                     {"MaxEdges", D.MaxEdges},
+                                     {"VertexDegree", D.VertexDegree},
+                                     {"HaloWidth", D.HaloWidth},
+                                     {"NumTasks", D.NumTasks},
+                                     {"MyTask", D.MyTask}};
+   auto It = V.find(name);
+   if (It == V.end())
+      OMEGA_ABORT(std::string("Decomp: no integer member named ") + name);
+   *out = It->second;
+   OMG_CATCH
+}
+static void copyOutI4(const I4 *Src, size_t Cnt, int32_t *Out, size_t N, const char *Name) {
+   if (N < Cnt)
+      OMEGA_ABORT(std::string("output buffer too small for ") + Name);
+   std::memcpy(Out, Src, Cnt * sizeof(I4));
+}
+int omg_decomp_get_array(const omg_decomp *d, const char *name, int32_t *out, size_t n) {
+   OMG_TRY
+   OMG_ARG(d && name && out);
+   const Decomp &D = *d->D;
+   const std::string S(name);
+   const std::map<std::string, const HostArrayI4 *> A{
+       {"CellID", &D.CellIDH},           {"EdgeID", &D.EdgeIDH},         {"VertexID", &D.VertexIDH},
+       {"CellLoc", &D.CellLocH},         {"EdgeLoc", &D.EdgeLocH},       {"VertexLoc", &D.VertexLocH},
+       {"NCellsHalo", &D.NCellsHaloH},   {"NEdgesHalo", &D.NEdgesHaloH}, {"NVerticesHalo", &D.NVerticesHaloH}};
+   auto It = A.find(S);
+   if (It != A.end())
+      copyOutI4(It->second->data(), It->second->size(), out, n, name);
+   else if (S == "CellTask")
+      copyOutI4(D.CellTask.data(), D.CellTask.size(), out, n, name);
+   else
+      OMEGA_ABORT("Decomp: no array member named " + S);
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- Halo
+int omg_halo_create(const omg_decomp *d, omg_halo **out) {
+   OMG_TRY
+   OMG_ARG(d && out);
+   auto *R = new omg_halo;
+   try {
+      R->H.reset(new Halo("Default", d->D.get()));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_halo_destroy(omg_halo *h) {
+   delete h;
+   return 0;
+}
+int omg_halo_num_neighbors(const omg_halo *h, int *n) {
+   OMG_TRY
+   OMG_ARG(h && n);
+   *n = h->H->NNghbr;
+   OMG_CATCH
+}
+int omg_halo_neighbor_task(const omg_halo *h, int i, int *task) {
+   OMG_TRY
+   OMG_ARG(h && task && i >= 0 && i < h->H->NNghbr);
+   *task = h->H->NeighborList[i];
+   OMG_CATCH
+}
+int omg_halo_list_size(const omg_halo *h, int i, int elem, int recv, int *n) {
+   OMG_TRY
+   OMG_ARG(h && n && i >= 0 && i < h->H->NNghbr && elem >= 0 && elem < 3);
+   *n = (int)(recv ? h->H->RecvLists[elem][i] : h->H->SendLists[elem][i]).size();
+   OMG_CATCH
+}
+int omg_halo_get_list(const omg_halo *h, int i, int elem, int recv, int32_t *out) {
+   OMG_TRY
+   OMG_ARG(h && out && i >= 0 && i < h->H->NNghbr && elem >= 0 && elem < 3);
+   const auto &L = recv ? h->H->RecvLists[elem][i] : h->H->SendLists[elem][i];
+   std::memcpy(out, L.data(), L.size() * sizeof(I4));
+   OMG_CATCH
+}
+int omg_halo_required_bytes(const omg_halo *h, int i, size_t pc, size_t pe, size_t pv, size_t *bytes) {
+   OMG_TRY
+   OMG_ARG(h && bytes && i >= 0 && i < h->H->NNghbr);
+   *bytes = h->H->requiredBytes(i, pc, pe, pv);
+   OMG_CATCH
+}
+int omg_halo_set_buffers(omg_halo *h, int i, void *send_dev, void *recv_dev, size_t bytes) {
+   OMG_TRY
+   OMG_ARG(h);
+   h->H->setBuffers(i, send_dev, recv_dev, bytes);
+   OMG_CATCH
+}
+int omg_halo_set_transport(omg_halo *h, omg_transport_fn fn, void *ctx) {
+   OMG_TRY
+   OMG_ARG(h);
+   h->H->setTransport((HaloTransportFn)fn, ctx);
+   OMG_CATCH
+}
+int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int elem, void *stream) {
+   OMG_TRY
+   OMG_ARG(h && dev_array && nt >= 1 && elem >= 0 && elem < 3);
+   Array3DReal A;
+   A.Ptr    = dev_array;
+   A.Ext[0] = nt, A.Ext[1] = rows_size, A.Ext[2] = k;
+   if (h->H->exchangeFullArrayHalo(A, (MeshElement)elem, (hipStream_t)stream) != 0)
+      OMEGA_ABORT("Halo::exchangeFullArrayHalo failed");
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- HorzMesh
+int omg_mesh_create(const omg_decomp *d, int nvertlayers, int host_only, omg_mesh **out) {
+   OMG_TRY
+   OMG_ARG(d && out);
+   auto *R = new omg_mesh;
+   try {
+      R->M.reset(new HorzMesh("Default", d->D.get(), nvertlayers, host_only != 0));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_mesh_destroy(omg_mesh *m) {
+   delete m;
+   return 0;
+}
+int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
+   OMG_TRY
+   OMG_ARG(m && name && out);
+   const HorzMesh &M = *m->M;
+   const std::map<std::string, I4> V{{"NCellsOwned", M.NCellsOwned},       {"NCellsAll", M.NCellsAll},
+                                     {"NCellsSize", M.NCellsSize},         {"NEdgesOwned", M.NEdgesOwned},
+                                     {"NEdgesAll", M.NEdgesAll},           {"NEdgesSize", M.NEdgesSize},
+                                     {"NVerticesOwned", M.NVerticesOwned}, {"NVerticesAll", M.NVerticesAll},
+                                     {"NVerticesSize", M.NVerticesSize},   {"MaxEdges", M.MaxEdges},
+                                     {"MaxEdges2", M.MaxEdges2},           {"VertexDegree", M.VertexDegree},
+                                     {"NVertLayers", M.NVertLayers},       {"MaxCellsOnEdge", M.MaxCellsOnEdge}};
+   auto It = V.find(name);
+   if (It == V.end())
+      OMEGA_ABORT(std::string("HorzMesh: no integer member named ") + name);
+   *out = It->second;
+   OMG_CATCH
+}
+int omg_mesh_get_array_i4(const omg_mesh *m, const char *name, int32_t *out, size_t n) {
+   OMG_TRY
+   OMG_ARG(m && name && out);
+   const HorzMesh &M = *m->M;
+   const std::map<std::string, const HostArrayI4 *> A{
+       {"CellsOnCell", &M.CellsOnCellH},       {"EdgesOnCell", &M.EdgesOnCellH},   {"NEdgesOnCell", &M.NEdgesOnCellH},
+       {"VerticesOnCell", &M.VerticesOnCellH}, {"CellsOnEdge", &M.CellsOnEdgeH},   {"EdgesOnEdge", &M.EdgesOnEdgeH},
+       {"NEdgesOnEdge", &M.NEdgesOnEdgeH},     {"VerticesOnEdge", &M.VerticesOnEdgeH},
+       {"CellsOnVertex", &M.CellsOnVertexH},   {"EdgesOnVertex", &M.EdgesOnVertexH},
+       {"NCellsHalo", &M.NCellsHaloH},         {"NEdgesHalo", &M.NEdgesHaloH},     {"NVerticesHalo", &M.NVerticesHaloH}};
+   auto It = A.find(name);
+   if (It == A.end())
+      OMEGA_ABORT(std::string("HorzMesh: no int array member named ") + name);
+   copyOutI4(It->second->data(), It->second->size(), out, n, name);
+   OMG_CATCH
+}
+int omg_mesh_get_array_r8(const omg_mesh *m, const char *name, double *out, size_t n) {
+   OMG_TRY
+   OMG_ARG(m && name && out);
+   const HorzMesh &M = *m->M;
+   const std::map<std::string, const HostArrayReal *> A{
+       {"XCell", &M.XCellH},           {"YCell", &M.YCellH},       {"ZCell", &M.ZCellH},
+       {"LonCell", &M.LonCellH},       {"LatCell", &M.LatCellH},   {"XEdge", &M.XEdgeH},
+       {"YEdge", &M.YEdgeH},           {"ZEdge", &M.ZEdgeH},       {"LonEdge", &M.LonEdgeH},
+       {"LatEdge", &M.LatEdgeH},       {"XVertex", &M.XVertexH},   {"YVertex", &M.YVertexH},
+       {"ZVertex", &M.ZVertexH},       {"LonVertex", &M.LonVertexH}, {"LatVertex", &M.LatVertexH},
+       {"AreaCell", &M.AreaCellH},     {"AreaTriangle", &M.AreaTriangleH},
+       {"KiteAreasOnVertex", &M.KiteAreasOnVertexH},               {"DvEdge", &M.DvEdgeH},
+       {"DcEdge", &M.DcEdgeH},         {"AngleEdge", &M.AngleEdgeH}, {"WeightsOnEdge", &M.WeightsOnEdgeH},
+       {"FEdge", &M.FEdgeH},           {"FCell", &M.FCellH},       {"FVertex", &M.FVertexH},
+       {"BottomDepth", &M.BottomDepthH}, {"EdgeSignOnCell", &M.EdgeSignOnCellH},
+       {"EdgeSignOnVertex", &M.EdgeSignOnVertexH},                 {"EdgeMask", &M.EdgeMaskH},
+       {"MeshScalingDel2", &M.MeshScalingDel2H},                   {"MeshScalingDel4", &M.MeshScalingDel4H}};
+   auto It = A.find(name);
+   if (It == A.end())
+      OMEGA_ABORT(std::string("HorzMesh: no real array member named ") + name);
+   if (n < It->second->size())
+      OMEGA_ABORT(std::string("output buffer too small for ") + name);
+   std::memcpy(out, It->second->data(), It->second->size() * sizeof(double));
+   OMG_CATCH
+}
+int omg_mesh_set_fvertex(omg_mesh *m, const double *host_values) {
+   OMG_TRY
+   OMG_ARG(m && host_values);
+   m->M->setFVertex(host_values);
+   OMG_CATCH
+}
+
+static void requireDevice(const HorzMesh *M) {
+   OMEGA_REQUIRE(!M->HostOnly, "this mesh was created host-only: no device arrays, compute is unavailable");
+}
+
+// ---------------------------------------------------------------- options
+void omg_tend_config_default(omg_tend_config *c) {
+   const TendParams P;
+   c->ThicknessFluxTendencyEnable   = P.ThicknessFluxTendencyEnable;
+   c->PVTendencyEnable              = P.PVTendencyEnable;
+   c->KETendencyEnable              = P.KETendencyEnable;
+   c->SSHTendencyEnable             = P.SSHTendencyEnable;
+   c->VelDiffTendencyEnable         = P.VelDiffTendencyEnable;
+   c->VelHyperDiffTendencyEnable    = P.VelHyperDiffTendencyEnable;
+   c->WindForcingTendencyEnable     = P.WindForcingTendencyEnable;
+   c->BottomDragTendencyEnable      = P.BottomDragTendencyEnable;
+   c->TracerHorzAdvTendencyEnable   = P.TracerHorzAdvTendencyEnable;
+   c->TracerDiffTendencyEnable      = P.TracerDiffTendencyEnable;
+   c->TracerHyperDiffTendencyEnable = P.TracerHyperDiffTendencyEnable;
+   c->FluxThicknessUpwind           = P.FluxThicknessUpwind;
+   c->FluxTracerUpwind              = P.FluxTracerUpwind;
+   c->WindInterpIsotropic           = P.WindInterpIsotropic;
+   c->ViscDel2 = P.ViscDel2, c->ViscDel4 = P.ViscDel4, c->DivFactor = P.DivFactor;
+   c->EddyDiff2 = P.EddyDiff2, c->EddyDiff4 = P.EddyDiff4, c->Density0 = P.Density0;
+   c->BottomDragCoeff = P.BottomDragCoeff;
+}
+static TendParams toParams(const omg_tend_config *c) {
+   TendParams P;
+   P.ThicknessFluxTendencyEnable   = c->ThicknessFluxTendencyEnable;
+   P.PVTendencyEnable              = c->PVTendencyEnable;
+   P.KETendencyEnable              = c->KETendencyEnable;
+   P.SSHTendencyEnable             = c->SSHTendencyEnable;
+   P.VelDiffTendencyEnable         = c->VelDiffTendencyEnable;
+   P.VelHyperDiffTendencyEnable    = c->VelHyperDiffTendencyEnable;
+   P.WindForcingTendencyEnable     = c->WindForcingTendencyEnable;
+   P.BottomDragTendencyEnable      = c->BottomDragTendencyEnable;
+   P.TracerHorzAdvTendencyEnable   = c->TracerHorzAdvTendencyEnable;
+   P.TracerDiffTendencyEnable      = c->TracerDiffTendencyEnable;
+   P.TracerHyperDiffTendencyEnable = c->TracerHyperDiffTendencyEnable;
+   P.FluxThicknessUpwind           = c->FluxThicknessUpwind;
+   P.FluxTracerUpwind              = c->FluxTracerUpwind;
+   P.WindInterpIsotropic           = c->WindInterpIsotropic;
+   P.ViscDel2 = c->ViscDel2, P.ViscDel4 = c->ViscDel4, P.DivFactor = c->DivFactor;
+   P.EddyDiff2 = c->EddyDiff2, P.EddyDiff4 = c->EddyDiff4, P.Density0 = c->Density0;
+   P.BottomDragCoeff = c->BottomDragCoeff;
+   return P;
+}
+
+// ---------------------------------------------------------------- OceanState
+int omg_state_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int ntimelevels, omg_state **out) {
+   OMG_TRY
+   OMG_ARG(m && out);
+   requireDevice(m->M.get());
+   auto *R = new omg_state;
+   try {
+      R->S.reset(new OceanState("Default", m->M.get(), halo ? halo->H.get() : nullptr, nvertlayers, ntimelevels));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_state_destroy(omg_state *s) {
+   delete s;
+   return 0;
+}
+int omg_state_copy_to_device(omg_state *s, int tl, const double *h, const double *u) {
+   OMG_TRY
+   OMG_ARG(s);
+   if (s->S->copyToDevice(h, u, tl) != 0)
+      OMEGA_ABORT("OceanState: time level out of range");
+   OMG_CATCH
+}
+int omg_state_copy_to_host(const omg_state *s, int tl, double *h, double *u) {
+   OMG_TRY
+   OMG_ARG(s);
+   if (s->S->copyToHost(h, u, tl) != 0)
+      OMEGA_ABORT("OceanState: time level out of range");
+   OMG_CATCH
+}
+int omg_state_device_ptr(const omg_state *s, int tl, int which, double **dev) {
+   OMG_TRY
+   OMG_ARG(s && dev);
+   Array2DReal A;
+   const I4 E = which == 0 ? s->S->getLayerThickness(A, tl) : s->S->getNormalVelocity(A, tl);
+   if (E != 0)
+      OMEGA_ABORT("OceanState: time level out of range");
+   *dev = A.Ptr;
+   OMG_CATCH
+}
+int omg_state_exchange_halo(omg_state *s, int tl, void *stream) {
+   OMG_TRY
+   OMG_ARG(s);
+   if (s->S->exchangeHalo(tl, (hipStream_t)stream) != 0)
+      OMEGA_ABORT("OceanState::exchangeHalo failed");
+   OMG_CATCH
+}
+int omg_state_update_time_levels(omg_state *s, void *stream) {
+   OMG_TRY
+   OMG_ARG(s);
+   s->S->updateTimeLevels((hipStream_t)stream);
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- Tracers
+int omg_tracers_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int ntracers, int ntimelevels,
+                       omg_tracers **out) {
+   OMG_TRY
+   OMG_ARG(m && out);
+   requireDevice(m->M.get());
+   auto *R = new omg_tracers;
+   try {
+      R->T.reset(new Tracers(m->M.get(), halo ? halo->H.get() : nullptr, nvertlayers, ntracers, ntimelevels));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_tracers_destroy(omg_tracers *t) {
+   delete t;
+   return 0;
+}
+int omg_tracers_copy_to_device(omg_tracers *t, int tl, const double *host) {
+   OMG_TRY
+   OMG_ARG(t && host);
+   if (t->T->copyToDevice(host, tl) != 0)
+      OMEGA_ABORT("Tracers: time level out of range");
+   OMG_CATCH
+}
+int omg_tracers_copy_to_host(const omg_tracers *t, int tl, double *host) {
+   OMG_TRY
+   OMG_ARG(t && host);
+   if (t->T->copyToHost(host, tl) != 0)
+      OMEGA_ABORT("Tracers: time level out of range");
+   OMG_CATCH
+}
+int omg_tracers_device_ptr(const omg_tracers *t, int tl, double **dev) {
+   OMG_TRY
+   OMG_ARG(t && dev);
+   Array3DReal A;
+   if (t->T->getAll(A, tl) != 0)
+      OMEGA_ABORT("Tracers: time level out of range");
+   *dev = A.Ptr;
+   OMG_CATCH
+}
+int omg_tracers_exchange_halo(omg_tracers *t, int tl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t);
+   if (t->T->exchangeHalo(tl, (hipStream_t)stream) != 0)
+      OMEGA_ABORT("Tracers::exchangeHalo failed");
+   OMG_CATCH
+}
+int omg_tracers_update_time_levels(omg_tracers *t, void *stream) {
+   OMG_TRY
+   OMG_ARG(t);
+   t->T->updateTimeLevels((hipStream_t)stream);
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- AuxiliaryState
+int omg_aux_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int ntracers, omg_aux **out) {
+   OMG_TRY
+   OMG_ARG(m && out);
+   requireDevice(m->M.get());
+   auto *R = new omg_aux;
+   try {
+      R->A.reset(new AuxiliaryState("Default", m->M.get(), halo ? halo->H.get() : nullptr, nvertlayers, ntracers));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_aux_destroy(omg_aux *a) {
+   delete a;
+   return 0;
+}
+int omg_aux_set_options(omg_aux *a, int ftu, int ftru, int wiso) {
+   OMG_TRY
+   OMG_ARG(a);
+   a->A->LayerThicknessAux.FluxThickEdgeChoice = ftu ? FluxThickEdgeOption::Upwind : FluxThickEdgeOption::Center;
+   a->A->TracerAux.TracersOnEdgeChoice         = ftru ? FluxTracerEdgeOption::Upwind : FluxTracerEdgeOption::Center;
+   a->A->WindForcingAux.InterpChoice = wiso ? InterpCellToEdgeOption::Isotropic : InterpCellToEdgeOption::Anisotropic;
+   OMG_CATCH
+}
+int omg_aux_compute_mom_aux(omg_aux *a, const omg_state *s, int ttl, int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(a && s);
+   a->A->computeMomAux(s->S.get(), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+static Array3DReal tracerArray(const omg_tracers *t, int tl) {
+   Array3DReal A;
+   OMEGA_REQUIRE(t != nullptr, "tracers handle is NULL");
+   if (t->T->getAll(A, tl) != 0)
+      OMEGA_ABORT("Tracers: time level out of range");
+   return A;
+}
+int omg_aux_compute_all(omg_aux *a, const omg_state *s, const omg_tracers *t, int trtl, int ttl, int vtl,
+                        void *stream) {
+   OMG_TRY
+   OMG_ARG(a && s);
+   a->A->computeAll(s->S.get(), tracerArray(t, trtl), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+static void auxLookup(const AuxiliaryState &A, const std::string &Name, Real *&Ptr, size_t &Cnt) {
+   const std::map<std::string, std::pair<Real *, size_t>> M{
+       {"KineticEnergyCell", {A.KineticAux.KineticEnergyCell.Ptr, A.KineticAux.KineticEnergyCell.size()}},
+       {"VelocityDivCell", {A.KineticAux.VelocityDivCell.Ptr, A.KineticAux.VelocityDivCell.size()}},
+       {"FluxLayerThickEdge", {A.LayerThicknessAux.FluxLayerThickEdge.Ptr, A.LayerThicknessAux.FluxLayerThickEdge.size()}},
+       {"MeanLayerThickEdge", {A.LayerThicknessAux.MeanLayerThickEdge.Ptr, A.LayerThicknessAux.MeanLayerThickEdge.size()}},
+       {"SshCell", {A.LayerThicknessAux.SshCell.Ptr, A.LayerThicknessAux.SshCell.size()}},
+       {"RelVortVertex", {A.VorticityAux.RelVortVertex.Ptr, A.VorticityAux.RelVortVertex.size()}},
+       {"NormRelVortVertex", {A.VorticityAux.NormRelVortVertex.Ptr, A.VorticityAux.NormRelVortVertex.size()}},
+       {"NormPlanetVortVertex", {A.VorticityAux.NormPlanetVortVertex.Ptr, A.VorticityAux.NormPlanetVortVertex.size()}},
+       {"NormRelVortEdge", {A.VorticityAux.NormRelVortEdge.Ptr, A.VorticityAux.NormRelVortEdge.size()}},
+       {"NormPlanetVortEdge", {A.VorticityAux.NormPlanetVortEdge.Ptr, A.VorticityAux.NormPlanetVortEdge.size()}},
+       {"Del2Edge", {A.VelocityDel2Aux.Del2Edge.Ptr, A.VelocityDel2Aux.Del2Edge.size()}},
+       {"Del2DivCell", {A.VelocityDel2Aux.Del2DivCell.Ptr, A.VelocityDel2Aux.Del2DivCell.size()}},
+       {"Del2RelVortVertex", {A.VelocityDel2Aux.Del2RelVortVertex.Ptr, A.VelocityDel2Aux.Del2RelVortVertex.size()}},
+       {"HTracersEdge", {A.TracerAux.HTracersEdge.Ptr, A.TracerAux.HTracersEdge.size()}},
+       {"Del2TracersCell", {A.TracerAux.Del2TracersCell.Ptr, A.TracerAux.Del2TracersCell.size()}},
+       {"NormalStressEdge", {A.WindForcingAux.NormalStressEdge.Ptr, A.WindForcingAux.NormalStressEdge.size()}},
+       {"ZonalStressCell", {A.WindForcingAux.ZonalStressCell.Ptr, A.WindForcingAux.ZonalStressCell.size()}},
+       {"MeridStressCell", {A.WindForcingAux.MeridStressCell.Ptr, A.WindForcingAux.MeridStressCell.size()}}};
+   auto It = M.find(Name);
+   if (It == M.end())
+      OMEGA_ABORT("AuxiliaryState: no array named " + Name);
+   Ptr = It->second.first;
+   Cnt = It->second.second;
+}
+int omg_aux_copy_to_host(const omg_aux *a, const char *name, double *host, size_t n) {
+   OMG_TRY
+   OMG_ARG(a && name && host);
+   Real *P;
+   size_t C;
+   auxLookup(*a->A, name, P, C);
+   if (n < C)
+      OMEGA_ABORT(std::string("output buffer too small for ") + name);
+   copyToHost(host, P, C * sizeof(Real));
+   OMG_CATCH
+}
+int omg_aux_copy_to_device(omg_aux *a, const char *name, const double *host, size_t n) {
+   OMG_TRY
+   OMG_ARG(a && name && host);
+   Real *P;
+   size_t C;
+   auxLookup(*a->A, name, P, C);
+   if (n != C)
+      OMEGA_ABORT(std::string("size mismatch for ") + name);
+   copyToDevice(P, host, C * sizeof(Real));
+   OMG_CATCH
+}
+int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t *n) {
+   OMG_TRY
+   OMG_ARG(a && name && dev);
+   Real *P;
+   size_t C;
+   auxLookup(*a->A, name, P, C);
+   *dev = P;
+   if (n)
+      *n = C;
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- Tendencies
+int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out) {
+   OMG_TRY
+   OMG_ARG(m && out);
+   requireDevice(m->M.get());
+   auto *R = new omg_tend;
+   try {
+      R->T.reset(new Tendencies("Default", m->M.get(), nvertlayers, ntracers, c ? toParams(c) : TendParams()));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_tend_destroy(omg_tend *t) {
+   delete t;
+   return 0;
+}
+int omg_tend_set_fused(omg_tend *t, int use_fused_rhs) {
+   OMG_TRY
+   OMG_ARG(t);
+   t->T->UseFusedRHS = use_fused_rhs != 0;
+   OMG_CATCH
+}
+int omg_tend_compute_all(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr, int trtl, int ttl,
+                         int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeAllTendencies(s->S.get(), a->A.get(), tracerArray(tr, trtl), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_tend_compute_thickness(omg_tend *t, const omg_state *s, omg_aux *a, int ttl, int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeThicknessTendencies(s->S.get(), a->A.get(), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_tend_compute_velocity(omg_tend *t, const omg_state *s, omg_aux *a, int ttl, int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeVelocityTendencies(s->S.get(), a->A.get(), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_tend_compute_tracer(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr, int trtl, int ttl,
+                            int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeTracerTendencies(s->S.get(), a->A.get(), tracerArray(tr, trtl), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_tend_compute_thickness_only(omg_tend *t, const omg_state *s, omg_aux *a, int ttl, int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeThicknessTendenciesOnly(s->S.get(), a->A.get(), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_tend_compute_velocity_only(omg_tend *t, const omg_state *s, omg_aux *a, int ttl, int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeVelocityTendenciesOnly(s->S.get(), a->A.get(), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr, int trtl,
+                                 int ttl, int vtl, void *stream) {
+   OMG_TRY
+   OMG_ARG(t && s && a);
+   t->T->computeTracerTendenciesOnly(s->S.get(), a->A.get(), tracerArray(tr, trtl), ttl, vtl, (hipStream_t)stream);
+   OMG_CATCH
+}
+static void tendLookup(const Tendencies &T, int Which, Real *&P, size_t &C) {
+   switch (Which) {
+   case 0:
+      P = T.LayerThicknessTend.Ptr, C = T.LayerThicknessTend.size();
+      break;
+   case 1:
+      P = T.NormalVelocityTend.Ptr, C = T.NormalVelocityTend.size();
+      break;
+   case 2:
+      P = T.TracerTend.Ptr, C = T.TracerTend.size();
+      break;
+   default:
+      OMEGA_ABORT("Tendencies: `which` must be 0, 1 or 2");
+   }
+}
+int omg_tend_copy_to_host(const omg_tend *t, int which, double *host, size_t n) {
+   OMG_TRY
+   OMG_ARG(t && host);
+   Real *P;
+   size_t C;
+   tendLookup(*t->T, which, P, C);
+   if (n < C)
+      OMEGA_ABORT("output buffer too small for tendency array");
+   copyToHost(host, P, C * sizeof(Real));
+   OMG_CATCH
+}
+int omg_tend_device_ptr(const omg_tend *t, int which, double **dev, size_t *n) {
+   OMG_TRY
+   OMG_ARG(t && dev);
+   Real *P;
+   size_t C;
+   tendLookup(*t->T, which, P, C);
+   *dev = P;
+   if (n)
+      *n = C;
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- TimeStepper
+int omg_stepper_create(const char *type, double dt, omg_tend *t, omg_aux *a, const omg_mesh *m, omg_halo *halo,
+                       omg_tracers *tr, omg_stepper **out) {
+   OMG_TRY
+   OMG_ARG(type && t && a && m && tr && out);
+   const TimeStepperType Ty = TimeStepper::getFromStr(type);
+   if (Ty == TimeStepperType::Invalid)
+      OMEGA_ABORT(std::string("TimeStepper: unknown type ") + type);
+   auto *R = new omg_stepper;
+   try {
+      R->St.reset(TimeStepper::create("Default", Ty, dt));
+      R->St->attachData(t->T.get(), a->A.get(), m->M.get(), halo ? halo->H.get() : nullptr, tr->T.get());
+      R->St->finalizeInit();
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_stepper_destroy(omg_stepper *st) {
+   delete st;
+   return 0;
+}
+int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream) {
+   OMG_TRY
+   OMG_ARG(st && s);
+   st->St->doStep(s->S.get(), (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_stepper_coeff_seconds(double mult, double dt, double *out) {
+   OMG_TRY
+   OMG_ARG(out);
+   *out = TimeStepper::coeffSeconds(mult, dt);
+   OMG_CATCH
+}
+
+} // extern "C"

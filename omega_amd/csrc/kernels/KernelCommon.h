@@ -1,0 +1,149 @@
+// KernelCommon.h -- launch geometry and device helpers shared by the HIP kernels.
+//
+// Thread mapping (all element kernels): blockDim = (TX, TY).  threadIdx.x walks the
+// vertical index (innermost / contiguous in memory, so a wavefront reads 64 consecutive
+// level-chunks = coalesced 512 B..1 KiB per gathered row), threadIdx.y walks the
+// elements of the workgroup's tile.  With K even each thread owns 2 adjacent levels and
+// moves them as one 16-byte load/store (global_load_dwordx4).  The tile's connectivity
+// and level-independent coefficients are staged once per workgroup into LDS; inside the
+// sweep every lane of a column reads the same LDS word (broadcast, conflict-free).
+//
+// blockIdx -> tile is remapped so that each XCD (blocks b, b+8, b+16, ... share one
+// XCD and its 4 MiB L2) walks ONE contiguous eighth of the element range: neighbouring
+// elements' rows are then re-read from that XCD's L2 instead of being fetched by all 8.
+#ifndef OMEGA_AMD_KERNELCOMMON_H
+#define OMEGA_AMD_KERNELCOMMON_H
+
+#include <hip/hip_runtime.h>
+
+namespace OMEGA {
+
+typedef double dv2 __attribute__((ext_vector_type(2)));
+
+template <class T> struct VecW;
+template <> struct VecW<double> {
+   static constexpr int W = 1;
+};
+template <> struct VecW<dv2> {
+   static constexpr int W = 2;
+};
+
+/// Load / store the level-chunk Kv of row `Row` of a [rows][K] array.
+template <class T> __device__ __forceinline__ T ldk(const double *P, int Row, int K, int Kv) {
+   return *reinterpret_cast<const T *>(P + (size_t)Row * K + (size_t)Kv * VecW<T>::W);
+}
+template <class T> __device__ __forceinline__ void stk(double *P, int Row, int K, int Kv, T V) {
+   *reinterpret_cast<T *>(P + (size_t)Row * K + (size_t)Kv * VecW<T>::W) = V;
+}
+
+__device__ __forceinline__ double kmax(double A, double B) { return A < B ? B : A; }
+__device__ __forceinline__ dv2 kmax(dv2 A, dv2 B) {
+   dv2 R;
+   R.x = kmax(A.x, B.x);
+   R.y = kmax(A.y, B.y);
+   return R;
+}
+/// upwind select: U > 0 -> A, U < 0 -> B, U == 0 -> max(A, B)
+__device__ __forceinline__ double upwind(double U, double A, double B) {
+   return U > 0 ? A : (U < 0 ? B : kmax(A, B));
+}
+__device__ __forceinline__ dv2 upwind(dv2 U, dv2 A, dv2 B) {
+   dv2 R;
+   R.x = upwind(U.x, A.x, B.x);
+   R.y = upwind(U.y, A.y, B.y);
+   return R;
+}
+template <class T> __device__ __forceinline__ T splat(double V);
+template <> __device__ __forceinline__ double splat<double>(double V) { return V; }
+template <> __device__ __forceinline__ dv2 splat<dv2>(double V) {
+   dv2 R;
+   R.x = V;
+   R.y = V;
+   return R;
+}
+
+__device__ __forceinline__ double getc(double V, int) { return V; }
+__device__ __forceinline__ double getc(dv2 V, int I) { return I == 0 ? V.x : V.y; }
+__device__ __forceinline__ void setc(double &V, int, double X) { V = X; }
+__device__ __forceinline__ void setc(dv2 &V, int I, double X) {
+   if (I == 0)
+      V.x = X;
+   else
+      V.y = X;
+}
+
+/// Bijective XCD-aware remap of a block id onto [0, N): blocks that share an XCD
+/// (equal b % 8) get consecutive tiles.
+__device__ __forceinline__ int xcdRemap(int B, int N) {
+   const int Q = N >> 3, R = N & 7;
+   const int Xcd = B & 7, Idx = B >> 3;
+   return (Xcd < R ? Xcd * (Q + 1) : R * (Q + 1) + (Xcd - R) * Q) + Idx;
+}
+
+/// Bump allocator over the dynamic LDS block (8-byte granules).
+struct LdsCarver {
+   unsigned char *P;
+   template <class U> __device__ __forceinline__ U *take(int N) {
+      U *R = reinterpret_cast<U *>(P);
+      P += (((size_t)N * sizeof(U) + 7) >> 3) << 3;
+      return R;
+   }
+};
+inline size_t ldsRound8(size_t B) { return ((B + 7) >> 3) << 3; }
+
+/// Launch geometry for an N-element, K-level sweep.
+struct Geom {
+   dim3 Grid, Block;
+   int KV;   ///< level-chunks per column (K / W)
+   int Tile; ///< elements per workgroup
+   int W;    ///< levels per thread (1 or 2)
+};
+inline Geom makeGeom(int N, int K) {
+   Geom G;
+   G.W  = (K % 2 == 0) ? 2 : 1;
+   G.KV = K / G.W;
+   int TX = G.KV < 64 ? G.KV : 64;
+   int TY = 256 / TX;
+   if (TY < 1)
+      TY = 1;
+   G.Block = dim3(TX, TY, 1);
+   G.Tile  = TY * 4;
+   if (G.Tile > 256)
+      G.Tile = 256;
+   int NTiles = (N + G.Tile - 1) / G.Tile;
+   G.Grid     = dim3(NTiles > 0 ? NTiles : 1, 1, 1);
+   return G;
+}
+
+/// The generic tile kernel: stage -> barrier -> column sweeps.
+template <class Body, class T> __global__ void __launch_bounds__(256) tileKernel(Body B, int N, int KV, int Tile) {
+   extern __shared__ __align__(16) unsigned char Lds[];
+   const int TileId = xcdRemap(blockIdx.x, gridDim.x);
+   const int First  = TileId * Tile;
+   int Cnt          = N - First;
+   if (Cnt > Tile)
+      Cnt = Tile;
+   typename Body::Lds L = B.carve(Lds, Tile);
+   const int Tid        = threadIdx.y * blockDim.x + threadIdx.x;
+   const int NThr       = blockDim.x * blockDim.y;
+   if (Cnt > 0)
+      B.stage(L, First, Cnt, Tid, NThr);
+   __syncthreads();
+   for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+      for (int Kv = threadIdx.x; Kv < KV; Kv += blockDim.x)
+         B.template compute<T>(L, Le, First + Le, Kv);
+}
+
+template <class Body> void launchTile(const Body &B, int N, int K, hipStream_t S) {
+   if (N <= 0)
+      return;
+   Geom G           = makeGeom(N, K);
+   const size_t Lds = B.ldsBytes(G.Tile);
+   if (G.W == 2)
+      hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+   else
+      hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+}
+
+} // namespace OMEGA
+#endif

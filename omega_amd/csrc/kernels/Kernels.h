@@ -1,0 +1,81 @@
+// Kernels.h -- host-callable launchers of the hand-written HIP kernels (gfx950).
+// Every launcher is asynchronous on the given stream and takes raw device pointers.
+#ifndef OMEGA_AMD_KERNELS_H
+#define OMEGA_AMD_KERNELS_H
+
+#include "../HorzMesh.h"
+
+namespace OMEGA {
+
+/// Device pointers of every AuxiliaryState array
+/// (reference: components/omega/src/ocn/auxiliaryVars/*.h public members).
+struct AuxPtrs {
+   Real *KineticEnergyCell, *VelocityDivCell;                      // C x K
+   Real *FluxLayerThickEdge, *MeanLayerThickEdge;                  // E x K
+   Real *SshCell;                                                  // C x K
+   Real *RelVortVertex, *NormRelVortVertex, *NormPlanetVortVertex; // V x K
+   Real *NormRelVortEdge, *NormPlanetVortEdge;                     // E x K
+   Real *Del2Edge, *Del2DivCell, *Del2RelVortVertex;               // E, C, V x K
+   Real *HTracersEdge, *Del2TracersCell;                           // NT x E x K, NT x C x K
+   Real *NormalStressEdge, *ZonalStressCell, *MeridStressCell;     // E, C, C
+};
+
+/// Enable flags and coefficients (reference: Tendencies::readTendConfig,
+/// components/omega/src/ocn/Tendencies.cpp:123-213; AuxiliaryState::readConfigOptions,
+/// components/omega/src/ocn/AuxiliaryState.cpp:259-308; defaults configs/Default.yml:25-52)
+struct TendParams {
+   int ThicknessFluxTendencyEnable = 1, PVTendencyEnable = 1, KETendencyEnable = 1, SSHTendencyEnable = 1,
+       VelDiffTendencyEnable = 1, VelHyperDiffTendencyEnable = 1, WindForcingTendencyEnable = 0,
+       BottomDragTendencyEnable = 0, TracerHorzAdvTendencyEnable = 1, TracerDiffTendencyEnable = 1,
+       TracerHyperDiffTendencyEnable = 1;
+   int FluxThicknessUpwind = 0, FluxTracerUpwind = 0, WindInterpIsotropic = 1;
+   Real ViscDel2 = 1.0e3, ViscDel4 = 1.2e11, DivFactor = 1.0, EddyDiff2 = 10.0, EddyDiff4 = 0.0, Density0 = 1026.0,
+        BottomDragCoeff = 0.0;
+};
+
+// ---- AuxiliaryState launches, one per reference parallelFor (AuxiliaryState.cpp:79-182) ----
+void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S);
+void launchCellAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *U, hipStream_t S);
+void launchEdgeAuxState1(const MeshView &M, const AuxPtrs &A, int Isotropic, hipStream_t S);
+void launchEdgeAuxState2(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, int FluxUpwind,
+                         hipStream_t S);
+void launchVertexAuxState2(const MeshView &M, int K, const AuxPtrs &A, hipStream_t S);
+void launchCellAuxState2(const MeshView &M, int K, const AuxPtrs &A, hipStream_t S);
+void launchCellAuxState3(const MeshView &M, int K, const AuxPtrs &A, const Real *H, hipStream_t S);
+void launchEdgeAuxState4(const MeshView &M, int K, int NT, const AuxPtrs &A, const Real *U, const Real *H,
+                         const Real *Tr, int TracerUpwind, hipStream_t S);
+void launchCellAuxState4(const MeshView &M, int K, int NT, const AuxPtrs &A, const Real *Tr, hipStream_t S);
+/// Tendencies::computeThicknessTendencies' computeLayerThickAux (Tendencies.cpp:507-512)
+void launchLayerThickAuxEdge(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, int FluxUpwind,
+                             hipStream_t S);
+
+// ---- Tendencies::compute*TendenciesOnly: all enabled terms of a group in one launch,
+//      accumulated in registers in the reference's term order, one store per element ----
+void launchThicknessTendOnly(const MeshView &M, int K, const TendParams &P, const AuxPtrs &A, Real *HTend,
+                             const Real *U, hipStream_t S);
+void launchVelocityTendOnly(const MeshView &M, int K, const TendParams &P, const AuxPtrs &A, Real *UTend,
+                            const Real *U, hipStream_t S);
+void launchTracerTendOnly(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *TrTend,
+                          const Real *U, const Real *Tr, hipStream_t S);
+
+// ---- fused RHS (Tendencies::computeAllTendencies): see FusedKernels.hip ----
+void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
+                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S);
+
+// ---- TimeStepper update kernels (TimeStepper.cpp:378-524) ----
+void launchUpdateByTend(int NRows, int K, Real *X1, const Real *X2, const Real *Tend, Real Coeff, hipStream_t S);
+void launchUpdateTracersByTend(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *CurTr, const Real *H1,
+                               const Real *H2, const Real *TrTend, Real Coeff, hipStream_t S);
+void launchWeightTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *CurTr, const Real *HCur,
+                         hipStream_t S);
+void launchAccumulateTracers(int NT, int NRows, int RowsSize, int K, Real *Accum, const Real *TrTend, Real Coeff,
+                             hipStream_t S);
+void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *HNext, hipStream_t S);
+
+// ---- Halo pack / unpack (Halo.h:324-414, 566-653) ----
+/// Buf[(T*NList + I)*K + k] = A[(T*RowsSize + List[I])*K + k]  (2-D: NT = 1)
+void launchHaloPack(Real *Buf, const Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S);
+void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S);
+
+} // namespace OMEGA
+#endif

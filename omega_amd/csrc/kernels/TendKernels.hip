@@ -1,0 +1,465 @@
+// TendKernels.hip -- Tendencies::compute{Thickness,Velocity,Tracer}TendenciesOnly
+// (components/omega/src/ocn/Tendencies.cpp:257-486) as one HIP kernel per group.  The
+// reference zero-fills the tendency array and then runs one parallelFor per enabled term,
+// each read-modify-writing the array; here the same terms are accumulated in registers in
+// the same order and stored once.  Term functors: components/omega/src/ocn/TendencyTerms.h.
+// Compiled with -ffp-contract=off (bit-for-bit the reference's operation order).
+#include "KernelCommon.h"
+#include "Kernels.h"
+
+namespace OMEGA {
+
+// ---------------------------------------------------------------------------------------
+// ThicknessFluxDivOnCell (TendencyTerms.h:35-58)
+struct ThickTendBody {
+   MeshView M;
+   int K;
+   int Enabled;
+   const Real *Flux, *U;
+   Real *Tend;
+   struct Lds {
+      Real *DvS, *InvA;
+      int *Edge, *N;
+   };
+   size_t ldsBytes(int Tile) const {
+      const int ME = M.MaxEdges;
+      return ldsRound8(sizeof(Real) * Tile * ME) + ldsRound8(sizeof(Real) * Tile) +
+             ldsRound8(sizeof(int) * Tile * ME) + ldsRound8(sizeof(int) * Tile);
+   }
+   __device__ Lds carve(unsigned char *P, int Tile) const {
+      const int ME = M.MaxEdges;
+      LdsCarver C{P};
+      Lds L;
+      L.DvS  = C.take<Real>(Tile * ME);
+      L.InvA = C.take<Real>(Tile);
+      L.Edge = C.take<int>(Tile * ME);
+      L.N    = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      const int ME = M.MaxEdges;
+      for (int I = Tid; I < Cnt * ME; I += NThr) {
+         const size_t G = (size_t)First * ME + I;
+         L.DvS[I]       = M.DvSignOnCell[G];
+         L.Edge[I]      = M.EdgesOnCell[G];
+      }
+      for (int I = Tid; I < Cnt; I += NThr) {
+         L.N[I]    = M.NEdgesOnCell[First + I];
+         L.InvA[I] = M.InvAreaCell[First + I];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+      const int ME = M.MaxEdges;
+      T TendV      = splat<T>(0.0);
+      if (Enabled) {
+         T DivTmp       = splat<T>(0.0);
+         const int N    = L.N[Le];
+         const Real InvA = L.InvA[Le];
+         for (int J = 0; J < N; ++J) {
+            const int JEdge = L.Edge[Le * ME + J];
+            DivTmp -= L.DvS[Le * ME + J] * ldk<T>(Flux, JEdge, K, Kv) * ldk<T>(U, JEdge, K, Kv) * InvA;
+         }
+         TendV -= DivTmp;
+      }
+      stk<T>(Tend, ICell, K, Kv, TendV);
+   }
+};
+void launchThicknessTendOnly(const MeshView &M, int K, const TendParams &P, const AuxPtrs &A, Real *HTend,
+                             const Real *U, hipStream_t S) {
+   ThickTendBody B{M, K, P.ThicknessFluxTendencyEnable, A.FluxLayerThickEdge, U, HTend};
+   launchTile(B, M.NCellsAll, K, S);
+}
+
+// ---------------------------------------------------------------------------------------
+// Velocity terms: PotentialVortHAdvOnEdge :81-108, KEGradOnEdge :127-140, SSHGradOnEdge
+// :159-173, VelocityDiffusionOnEdge :195-219, VelocityHyperDiffOnEdge :244-269,
+// WindForcingOnEdge :291-301, BottomDragOnEdge :319-334
+struct VelTendBody {
+   MeshView M;
+   int K;
+   TendParams P;
+   AuxPtrs A;
+   const Real *U;
+   Real *Tend;
+   struct Lds {
+      Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4;
+      int *EoE, *C0, *C1, *V0, *V1, *N;
+   };
+   size_t ldsBytes(int Tile) const {
+      const int ME2 = M.MaxEdges2;
+      return ldsRound8(sizeof(Real) * Tile * ME2) + ldsRound8(sizeof(Real) * Tile) * 6 +
+             ldsRound8(sizeof(int) * Tile * ME2) + ldsRound8(sizeof(int) * Tile) * 5;
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      const int ME2 = M.MaxEdges2;
+      LdsCarver C{Ptr};
+      Lds L;
+      L.W        = C.take<Real>(Tile * ME2);
+      L.InvDc    = C.take<Real>(Tile);
+      L.InvDv    = C.take<Real>(Tile);
+      L.Mask     = C.take<Real>(Tile);
+      L.MaskGrav = C.take<Real>(Tile);
+      L.C2       = C.take<Real>(Tile);
+      L.C4       = C.take<Real>(Tile);
+      L.EoE      = C.take<int>(Tile * ME2);
+      L.C0       = C.take<int>(Tile);
+      L.C1       = C.take<int>(Tile);
+      L.V0       = C.take<int>(Tile);
+      L.V1       = C.take<int>(Tile);
+      L.N        = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      const int ME2   = M.MaxEdges2;
+      const Real Grav = 9.80665; // TendencyTerms.h:176
+      for (int I = Tid; I < Cnt * ME2; I += NThr) {
+         const size_t G = (size_t)First * ME2 + I;
+         L.W[I]         = M.WeightsOnEdge[G];
+         L.EoE[I]       = M.EdgesOnEdge[G];
+      }
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int E     = First + I;
+         const Real Mask = M.EdgeMask1D[E];
+         L.InvDc[I]      = M.InvDcEdge[E];
+         L.InvDv[I]      = M.InvDvEdge[E];
+         L.Mask[I]       = Mask;
+         L.MaskGrav[I]   = Mask * Grav;                                 // :169
+         L.C2[I]         = Mask * P.ViscDel2 * M.MeshScalingDel2[E];    // :217
+         L.C4[I]         = Mask * P.ViscDel4 * M.MeshScalingDel4[E];    // :267
+         L.C0[I]         = M.CellsOnEdge[2 * E];
+         L.C1[I]         = M.CellsOnEdge[2 * E + 1];
+         L.V0[I]         = M.VerticesOnEdge[2 * E];
+         L.V1[I]         = M.VerticesOnEdge[2 * E + 1];
+         L.N[I]          = M.NEdgesOnEdge[E];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int IEdge, int Kv) const {
+      const int ME2 = M.MaxEdges2;
+      const int C0 = L.C0[Le], C1 = L.C1[Le], V0 = L.V0[Le], V1 = L.V1[Le];
+      const Real InvDc = L.InvDc[Le], InvDv = L.InvDv[Le];
+      T TendV = splat<T>(0.0);
+      if (P.PVTendencyEnable) {
+         T VortTmp   = splat<T>(0.0);
+         const T QRe = ldk<T>(A.NormRelVortEdge, IEdge, K, Kv);
+         const T QFe = ldk<T>(A.NormPlanetVortEdge, IEdge, K, Kv);
+         const int N = L.N[Le];
+         for (int J = 0; J < N; ++J) {
+            const int JEdge = L.EoE[Le * ME2 + J];
+            const T NormVort =
+                (QRe + QFe + ldk<T>(A.NormRelVortEdge, JEdge, K, Kv) + ldk<T>(A.NormPlanetVortEdge, JEdge, K, Kv)) *
+                0.5;
+            VortTmp += L.W[Le * ME2 + J] * ldk<T>(A.FluxLayerThickEdge, JEdge, K, Kv) * ldk<T>(U, JEdge, K, Kv) *
+                       NormVort;
+         }
+         TendV += L.Mask[Le] * VortTmp;
+      }
+      if (P.KETendencyEnable)
+         TendV -= L.Mask[Le] * (ldk<T>(A.KineticEnergyCell, C1, K, Kv) - ldk<T>(A.KineticEnergyCell, C0, K, Kv)) *
+                  InvDc;
+      if (P.SSHTendencyEnable)
+         TendV -= L.MaskGrav[Le] * (ldk<T>(A.SshCell, C1, K, Kv) - ldk<T>(A.SshCell, C0, K, Kv)) * InvDc;
+      if (P.VelDiffTendencyEnable) {
+         const T Del2U = ((ldk<T>(A.VelocityDivCell, C1, K, Kv) - ldk<T>(A.VelocityDivCell, C0, K, Kv)) * InvDc -
+                          (ldk<T>(A.RelVortVertex, V1, K, Kv) - ldk<T>(A.RelVortVertex, V0, K, Kv)) * InvDv);
+         TendV += L.C2[Le] * Del2U;
+      }
+      if (P.VelHyperDiffTendencyEnable) {
+         const T Del2U =
+             (P.DivFactor * (ldk<T>(A.Del2DivCell, C1, K, Kv) - ldk<T>(A.Del2DivCell, C0, K, Kv)) * InvDc -
+              (ldk<T>(A.Del2RelVortVertex, V1, K, Kv) - ldk<T>(A.Del2RelVortVertex, V0, K, Kv)) * InvDv);
+         TendV -= L.C4[Le] * Del2U;
+      }
+      constexpr int W = VecW<T>::W;
+      if (P.WindForcingTendencyEnable && Kv == 0) { // acts on level 0 only (:294)
+         const Real InvThickEdge = 1. / A.MeanLayerThickEdge[(size_t)IEdge * K];
+         setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * A.NormalStressEdge[IEdge] / P.Density0);
+      }
+      if (P.BottomDragTendencyEnable && (Kv + 1) * W >= K) { // bottom level KBot = K-1 (:323)
+         const int KBot          = K - 1;
+         const int Comp          = KBot - Kv * W;
+         const Real VelNormEdge  = sqrt(A.KineticEnergyCell[(size_t)C0 * K + KBot] + A.KineticEnergyCell[(size_t)C1 * K + KBot]);
+         const Real InvThickEdge = 1. / A.MeanLayerThickEdge[(size_t)IEdge * K + KBot];
+         setc(TendV, Comp,
+              getc(TendV, Comp) - L.Mask[Le] * P.BottomDragCoeff * VelNormEdge * InvThickEdge * U[(size_t)IEdge * K + KBot]);
+      }
+      stk<T>(Tend, IEdge, K, Kv, TendV);
+   }
+};
+void launchVelocityTendOnly(const MeshView &M, int K, const TendParams &P, const AuxPtrs &A, Real *UTend,
+                            const Real *U, hipStream_t S) {
+   VelTendBody B{M, K, P, A, U, UTend};
+   launchTile(B, M.NEdgesAll, K, S);
+}
+
+// ---------------------------------------------------------------------------------------
+// Tracer terms: TracerHorzAdvOnCell :349-373, TracerDiffOnCell :394-426,
+// TracerHyperDiffOnCell :449-480; tracer loop inside the thread.
+struct TracerTendBody {
+   MeshView M;
+   int K, NT;
+   TendParams P;
+   const Real *U, *Tr, *HTr, *HMean, *Del2Tr;
+   Real *Tend;
+   struct Lds {
+      Real *MDvS, *Df2, *Df4, *InvA;
+      int *Edge, *C0, *C1, *N;
+   };
+   size_t ldsBytes(int Tile) const {
+      const int ME = M.MaxEdges;
+      return ldsRound8(sizeof(Real) * Tile * ME) * 3 + ldsRound8(sizeof(Real) * Tile) +
+             ldsRound8(sizeof(int) * Tile * ME) * 3 + ldsRound8(sizeof(int) * Tile);
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      const int ME = M.MaxEdges;
+      LdsCarver C{Ptr};
+      Lds L;
+      L.MDvS = C.take<Real>(Tile * ME);
+      L.Df2  = C.take<Real>(Tile * ME);
+      L.Df4  = C.take<Real>(Tile * ME);
+      L.InvA = C.take<Real>(Tile);
+      L.Edge = C.take<int>(Tile * ME);
+      L.C0   = C.take<int>(Tile * ME);
+      L.C1   = C.take<int>(Tile * ME);
+      L.N    = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      const int ME = M.MaxEdges;
+      for (int I = Tid; I < Cnt * ME; I += NThr) {
+         const size_t G = (size_t)First * ME + I;
+         L.MDvS[I]      = M.MaskDvSignOnCell[G];
+         L.Df2[I]       = M.Diff2CoefOnCell[G];
+         L.Df4[I]       = M.Diff4CoefOnCell[G];
+         L.Edge[I]      = M.EdgesOnCell[G];
+         L.C0[I]        = M.CellsOnEdgeOnCell[2 * G];
+         L.C1[I]        = M.CellsOnEdgeOnCell[2 * G + 1];
+      }
+      for (int I = Tid; I < Cnt; I += NThr) {
+         L.N[I]    = M.NEdgesOnCell[First + I];
+         L.InvA[I] = M.InvAreaCell[First + I];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+      const int ME    = M.MaxEdges;
+      const int N     = L.N[Le];
+      const Real InvA = L.InvA[Le];
+      const size_t CStride = (size_t)M.NCellsSize * K, EStride = (size_t)M.NEdgesSize * K;
+      for (int Lt = 0; Lt < NT; ++Lt) {
+         T TendV = splat<T>(0.0);
+         if (P.TracerHorzAdvTendencyEnable) {
+            T HAdvTmp       = splat<T>(0.0);
+            const Real *HTrL = HTr + Lt * EStride;
+            for (int J = 0; J < N; ++J) {
+               const int JEdge = L.Edge[Le * ME + J];
+               HAdvTmp -= L.MDvS[Le * ME + J] * ldk<T>(HTrL, JEdge, K, Kv) * ldk<T>(U, JEdge, K, Kv) * InvA;
+            }
+            TendV -= HAdvTmp;
+         }
+         if (P.TracerDiffTendencyEnable) {
+            T DiffTmp       = splat<T>(0.0);
+            const Real *TrL = Tr + Lt * CStride;
+            for (int J = 0; J < N; ++J) {
+               const T Grad = ldk<T>(TrL, L.C1[Le * ME + J], K, Kv) - ldk<T>(TrL, L.C0[Le * ME + J], K, Kv);
+               DiffTmp -= L.Df2[Le * ME + J] * ldk<T>(HMean, L.Edge[Le * ME + J], K, Kv) * Grad;
+            }
+            TendV += P.EddyDiff2 * DiffTmp * InvA;
+         }
+         if (P.TracerHyperDiffTendencyEnable) {
+            T HypTmp        = splat<T>(0.0);
+            const Real *D2L = Del2Tr + Lt * CStride;
+            for (int J = 0; J < N; ++J) {
+               const T Grad = ldk<T>(D2L, L.C1[Le * ME + J], K, Kv) - ldk<T>(D2L, L.C0[Le * ME + J], K, Kv);
+               HypTmp -= L.Df4[Le * ME + J] * Grad;
+            }
+            TendV -= P.EddyDiff4 * HypTmp * InvA;
+         }
+         stk<T>(Tend + Lt * CStride, ICell, K, Kv, TendV);
+      }
+   }
+};
+void launchTracerTendOnly(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *TrTend,
+                          const Real *U, const Real *Tr, hipStream_t S) {
+   if (NT <= 0)
+      return;
+   TracerTendBody B{M, K, NT, P, U, Tr, A.HTracersEdge, A.MeanLayerThickEdge, A.Del2TracersCell, TrTend};
+   launchTile(B, M.NCellsAll, K, S);
+}
+
+// ---------------------------------------------------------------------------------------
+// TimeStepper update kernels (components/omega/src/timeStepping/TimeStepper.cpp:378-524):
+// pure streaming, 16-byte accesses, grid-stride.
+template <class F> __global__ void __launch_bounds__(256) streamKernel(F Fn, size_t NVec) {
+   for (size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x; I < NVec; I += (size_t)gridDim.x * blockDim.x)
+      Fn(I);
+}
+template <class F> static void launchStream(const F &Fn, size_t NVec, hipStream_t S) {
+   if (NVec == 0)
+      return;
+   size_t Blocks = (NVec + 255) / 256;
+   if (Blocks > 8192)
+      Blocks = 8192;
+   hipLaunchKernelGGL((streamKernel<F>), dim3((unsigned)Blocks), dim3(256), 0, S, Fn, NVec);
+}
+
+// X1 = X2 + Coeff*Tend over NRows*K contiguous values (updateThicknessByTend :378-401,
+// updateVelocityByTend :407-430)
+template <class T> struct UpdateFn {
+   Real *X1;
+   const Real *X2, *Tend;
+   Real Coeff;
+   __device__ void operator()(size_t I) const {
+      const T A = reinterpret_cast<const T *>(X2)[I], B = reinterpret_cast<const T *>(Tend)[I];
+      reinterpret_cast<T *>(X1)[I] = A + Coeff * B;
+   }
+};
+void launchUpdateByTend(int NRows, int K, Real *X1, const Real *X2, const Real *Tend, Real Coeff, hipStream_t S) {
+   const size_t N = (size_t)NRows * K;
+   if (N % 2 == 0)
+      launchStream(UpdateFn<dv2>{X1, X2, Tend, Coeff}, N / 2, S);
+   else
+      launchStream(UpdateFn<double>{X1, X2, Tend, Coeff}, N, S);
+}
+
+// tracer kernels: index I runs over NRows*K (cell, level); the tracer loop is inside so the
+// thickness arrays are read once for all tracers.
+template <class T> struct UpdateTracersFn { // updateTracersByTend :447-469
+   int NT;
+   size_t Stride; // RowsSize*K / W
+   Real *NextTr;
+   const Real *CurTr, *H1, *H2, *TrTend;
+   Real Coeff;
+   __device__ void operator()(size_t I) const {
+      const T Hn = reinterpret_cast<const T *>(H1)[I], Hc = reinterpret_cast<const T *>(H2)[I];
+      for (int L = 0; L < NT; ++L) {
+         const size_t J = L * Stride + I;
+         reinterpret_cast<T *>(NextTr)[J] =
+             (reinterpret_cast<const T *>(CurTr)[J] * Hc + Coeff * reinterpret_cast<const T *>(TrTend)[J]) / Hn;
+      }
+   }
+};
+void launchUpdateTracersByTend(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *CurTr, const Real *H1,
+                               const Real *H2, const Real *TrTend, Real Coeff, hipStream_t S) {
+   const size_t N = (size_t)NRows * K, St = (size_t)RowsSize * K;
+   if (NT <= 0)
+      return;
+   if (N % 2 == 0 && St % 2 == 0)
+      launchStream(UpdateTracersFn<dv2>{NT, St / 2, NextTr, CurTr, H1, H2, TrTend, Coeff}, N / 2, S);
+   else
+      launchStream(UpdateTracersFn<double>{NT, St, NextTr, CurTr, H1, H2, TrTend, Coeff}, N, S);
+}
+
+template <class T> struct WeightTracersFn { // weightTracers :473-487
+   int NT;
+   size_t Stride;
+   Real *NextTr;
+   const Real *CurTr, *H;
+   __device__ void operator()(size_t I) const {
+      const T Hc = reinterpret_cast<const T *>(H)[I];
+      for (int L = 0; L < NT; ++L) {
+         const size_t J                   = L * Stride + I;
+         reinterpret_cast<T *>(NextTr)[J] = reinterpret_cast<const T *>(CurTr)[J] * Hc;
+      }
+   }
+};
+void launchWeightTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *CurTr, const Real *HCur,
+                         hipStream_t S) {
+   const size_t N = (size_t)NRows * K, St = (size_t)RowsSize * K;
+   if (NT <= 0)
+      return;
+   if (N % 2 == 0 && St % 2 == 0)
+      launchStream(WeightTracersFn<dv2>{NT, St / 2, NextTr, CurTr, HCur}, N / 2, S);
+   else
+      launchStream(WeightTracersFn<double>{NT, St, NextTr, CurTr, HCur}, N, S);
+}
+
+template <class T> struct AccumTracersFn { // accumulateTracersUpdate :492-507
+   int NT;
+   size_t Stride;
+   Real *Accum;
+   const Real *TrTend;
+   Real Coeff;
+   __device__ void operator()(size_t I) const {
+      for (int L = 0; L < NT; ++L) {
+         const size_t J = L * Stride + I;
+         reinterpret_cast<T *>(Accum)[J] += Coeff * reinterpret_cast<const T *>(TrTend)[J];
+      }
+   }
+};
+void launchAccumulateTracers(int NT, int NRows, int RowsSize, int K, Real *Accum, const Real *TrTend, Real Coeff,
+                             hipStream_t S) {
+   const size_t N = (size_t)NRows * K, St = (size_t)RowsSize * K;
+   if (NT <= 0)
+      return;
+   if (N % 2 == 0 && St % 2 == 0)
+      launchStream(AccumTracersFn<dv2>{NT, St / 2, Accum, TrTend, Coeff}, N / 2, S);
+   else
+      launchStream(AccumTracersFn<double>{NT, St, Accum, TrTend, Coeff}, N, S);
+}
+
+template <class T> struct FinalizeTracersFn { // finalizeTracersUpdate :511-524
+   int NT;
+   size_t Stride;
+   Real *NextTr;
+   const Real *H;
+   __device__ void operator()(size_t I) const {
+      const T Hn = reinterpret_cast<const T *>(H)[I];
+      for (int L = 0; L < NT; ++L) {
+         const size_t J = L * Stride + I;
+         reinterpret_cast<T *>(NextTr)[J] /= Hn;
+      }
+   }
+};
+void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *HNext, hipStream_t S) {
+   const size_t N = (size_t)NRows * K, St = (size_t)RowsSize * K;
+   if (NT <= 0)
+      return;
+   if (N % 2 == 0 && St % 2 == 0)
+      launchStream(FinalizeTracersFn<dv2>{NT, St / 2, NextTr, HNext}, N / 2, S);
+   else
+      launchStream(FinalizeTracersFn<double>{NT, St, NextTr, HNext}, N, S);
+}
+
+// ---------------------------------------------------------------------------------------
+// Halo pack / unpack (components/omega/src/base/Halo.h:324-414, 566-653).  The message
+// layout is the reference's: Buf[(T*NList + I)*K + k] (2-D arrays: T = 0 only).
+template <class T, bool Pack> __global__ void __launch_bounds__(256)
+haloCopyKernel(Real *Buf, Real *A, const I4 *List, int NList, int NT, int RowsSize, int KV, int K) {
+   const size_t Total = (size_t)NT * NList * KV;
+   for (size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x; I < Total; I += (size_t)gridDim.x * blockDim.x) {
+      const int Kv    = (int)(I % KV);
+      const size_t R  = I / KV;
+      const int IExch = (int)(R % NList);
+      const int Tt    = (int)(R / NList);
+      const size_t Ai = ((size_t)Tt * RowsSize + List[IExch]) * K + (size_t)Kv * VecW<T>::W;
+      const size_t Bi = ((size_t)Tt * NList + IExch) * K + (size_t)Kv * VecW<T>::W;
+      if (Pack)
+         *reinterpret_cast<T *>(Buf + Bi) = *reinterpret_cast<const T *>(A + Ai);
+      else
+         *reinterpret_cast<T *>(A + Ai) = *reinterpret_cast<const T *>(Buf + Bi);
+   }
+}
+template <bool Pack>
+static void launchHaloCopy(Real *Buf, Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S) {
+   if (NList <= 0 || NT <= 0)
+      return;
+   const int W        = (K % 2 == 0) ? 2 : 1;
+   const int KV       = K / W;
+   const size_t Total = (size_t)NT * NList * KV;
+   size_t Blocks      = (Total + 255) / 256;
+   if (Blocks > 4096)
+      Blocks = 4096;
+   if (W == 2)
+      hipLaunchKernelGGL((haloCopyKernel<dv2, Pack>), dim3((unsigned)Blocks), dim3(256), 0, S, Buf, A, List, NList, NT,
+                         RowsSize, KV, K);
+   else
+      hipLaunchKernelGGL((haloCopyKernel<double, Pack>), dim3((unsigned)Blocks), dim3(256), 0, S, Buf, A, List, NList,
+                         NT, RowsSize, KV, K);
+}
+void launchHaloPack(Real *Buf, const Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S) {
+   launchHaloCopy<true>(Buf, const_cast<Real *>(A), List, NList, NT, RowsSize, K, S);
+}
+void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S) {
+   launchHaloCopy<false>(const_cast<Real *>(Buf), A, List, NList, NT, RowsSize, K, S);
+}
+
+} // namespace OMEGA

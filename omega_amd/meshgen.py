@@ -244,3 +244,29 @@ def permute_mesh(mesh: dict, cell_old_of_new, edge_old_of_new, vertex_old_of_new
             a = inv[target[name]][a.astype(np.int64)].astype(I4)
         out[name] = np.ascontiguousarray(a)
     return out
+
+
+def synthetic_state(mesh: dict, nvertlayers: int, ntracers: int, seed: int = 20251003):
+    """Synthetic prognostic state on the GLOBAL mesh: smooth fields
+    plus seeded noise, h strictly > 1.  Returns h [nCells,K], u [nEdges,K], tr [NT,nCells,K]."""
+    rng = np.random.default_rng(seed)
+    K = nvertlayers
+    nC, nE = mesh["nCells"], mesh["nEdges"]
+    kfac = 1.0 + 0.05 * np.arange(K)[None, :] / max(K, 1)
+    if mesh.get("on_a_sphere", False):
+        lonC, latC, lonE, latE = mesh["lonCell"], mesh["latCell"], mesh["lonEdge"], mesh["latEdge"]
+        sC = np.cos(lonC) * np.cos(latC) ** 4
+        ux = -np.sin(lonE) ** 2 * np.cos(latE) ** 3
+        uy = -4 * np.sin(lonE) * np.cos(lonE) * np.cos(latE) ** 3 * np.sin(latE)
+    else:
+        ax, ay = 2 * np.pi / mesh["x_period"], 2 * np.pi / mesh["y_period"]
+        sC = np.cos(ax * mesh["xCell"]) * np.cos(ay * mesh["yCell"])
+        ux = np.sin(ax * mesh["xEdge"]) * np.cos(ay * mesh["yEdge"])
+        uy = np.cos(ax * mesh["xEdge"]) * np.sin(ay * mesh["yEdge"])
+    h = 2.0 + 0.5 * sC[:, None] * kfac + 0.1 * rng.uniform(-1, 1, (nC, K))
+    un = np.cos(mesh["angleEdge"]) * ux + np.sin(mesh["angleEdge"]) * uy
+    u = un[:, None] * kfac + 0.01 * rng.uniform(-1, 1, (nE, K))
+    tr = np.empty((max(ntracers, 1), nC, K))
+    for l in range(max(ntracers, 1)):
+        tr[l] = 2.0 - sC[:, None] * kfac + 0.1 * l + 0.05 * rng.uniform(-1, 1, (nC, K))
+    return h, u, tr

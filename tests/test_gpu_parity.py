@@ -1,0 +1,163 @@
+"""GPU parity: every HIP kernel path against the CPU oracle on identical mesh + state.
+
+Tolerance: BASELINE.json asks for tendencies within 1e-12 relative of the CPU reference.
+The kernels are built with -ffp-contract=off and keep the reference's operation order, so
+on owned elements the results are expected to be BIT-IDENTICAL to the oracle; the tests
+assert exact equality and report the relative difference if that ever fails
+(RTOL = 1e-12 is the contractual bound, asserted as well).
+"""
+import numpy as np
+import pytest
+
+import omega_amd as oa
+from omega_amd.meshgen import planar_hex
+from oracle import oracle as O
+from tests.problem import Problem, max_rel_diff
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+AUX_2D = ("KineticEnergyCell", "VelocityDivCell", "FluxLayerThickEdge", "MeanLayerThickEdge", "SshCell",
+          "RelVortVertex", "NormRelVortVertex", "NormPlanetVortVertex", "NormRelVortEdge", "NormPlanetVortEdge",
+          "Del2Edge", "Del2DivCell", "Del2RelVortVertex")
+OWNED = {"C": "NCellsOwned", "E": "NEdgesOwned", "V": "NVerticesOwned"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert oa.device_count() > 0, "no HIP device: GPU tests need a real MI355X"
+    oa.device_init(0)
+
+
+def check(name, got, ref, n_owned):
+    g, r = got[..., :n_owned, :], ref[..., :n_owned, :]
+    rel = max_rel_diff(g, r)
+    assert rel <= RTOL, f"{name}: max rel diff {rel:.3e} > {RTOL}"
+    assert np.array_equal(g, r), f"{name}: within {RTOL} (rel {rel:.3e}) but not bit-identical"
+
+
+CASES = [
+    # (nx, ny, dc, K, NT, config overrides)
+    (16, 16, 1.0, 4, 1, {}),                                   # BASELINE configs[0]
+    (16, 16, 30e3, 5, 2, {}),                                  # odd K -> scalar (W=1) path
+    (24, 20, 30e3, 60, 2, {}),                                 # K=60 (30 level-pairs per column)
+    (20, 24, 30e3, 80, 6, {}),                                 # K=80, NT=6 as QU30
+    (16, 16, 30e3, 8, 3, {"FluxThicknessUpwind": 1, "FluxTracerUpwind": 1}),
+    (16, 16, 30e3, 8, 2, {"WindForcingTendencyEnable": 1, "BottomDragTendencyEnable": 1, "BottomDragCoeff": 1.0e-3,
+                          "WindInterpIsotropic": 0}),
+    (16, 16, 30e3, 6, 2, {"VelHyperDiffTendencyEnable": 0, "TracerHyperDiffTendencyEnable": 0, "EddyDiff4": 3.0}),
+    (16, 16, 30e3, 6, 2, {"EddyDiff4": 2.5e9, "PVTendencyEnable": 0, "KETendencyEnable": 0}),
+    (16, 16, 30e3, 130, 1, {}),                                # KV = 65 > 64: level loop inside the thread
+]
+
+
+def _mk(case):
+    nx, ny, dc, K, NT, cfg = case
+    P = Problem(planar_hex(nx, ny, dc), K, NT, config=cfg)
+    if cfg.get("WindForcingTendencyEnable"):
+        rng = np.random.default_rng(7)
+        zs = np.zeros(P.mesh.NCellsSize)
+        ms = np.zeros(P.mesh.NCellsSize)
+        zs[:-1] = rng.uniform(-0.1, 0.1, P.mesh.NCellsAll)
+        ms[:-1] = rng.uniform(-0.1, 0.1, P.mesh.NCellsAll)
+        P.aux.set("ZonalStressCell", zs)
+        P.aux.set("MeridStressCell", ms)
+        P.oracle.aux["ZonalStressCell"][:] = zs
+        P.oracle.aux["MeridStressCell"][:] = ms
+    return P
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}_K{c[3]}_NT{c[4]}_{i}" for i, c in enumerate(CASES)])
+def test_aux_state_compute_all(case):
+    """AuxiliaryState::computeAll, array by array (reference-structured kernels)."""
+    P = _mk(case)
+    P.aux.compute_all(P.state, P.tracers)
+    oa.device_synchronize()
+    P.oracle.compute_all_aux(P.h, P.u, P.tr)
+    m = P.mesh
+    for name in AUX_2D:
+        check(name, P.aux.get(name), P.oracle.aux[name], getattr(m, OWNED[oa.AUX_SHAPES[name]]))
+    check("HTracersEdge", P.aux.get("HTracersEdge"), P.oracle.aux["HTracersEdge"], m.NEdgesOwned)
+    check("Del2TracersCell", P.aux.get("Del2TracersCell"), P.oracle.aux["Del2TracersCell"], m.NCellsOwned)
+    if case[5].get("WindForcingTendencyEnable"):
+        got, ref = P.aux.get("NormalStressEdge")[: m.NEdgesOwned], P.oracle.aux["NormalStressEdge"][: m.NEdgesOwned]
+        # cos/sin come from different libms (device vs glibc): 4 ulp
+        assert np.allclose(got, ref, rtol=1e-15, atol=1e-17)
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}_K{c[3]}_NT{c[4]}_{i}" for i, c in enumerate(CASES)])
+def test_compute_all_tendencies(case, fused):
+    """Tendencies::computeAllTendencies: reference launch structure and fused RHS."""
+    P = _mk(case)
+    wind = case[5].get("WindForcingTendencyEnable")
+    P.tend.set_fused(fused)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    m = P.mesh
+    if wind:
+        # NormalStressEdge differs by libm ulps -> compare the wind-touched level loosely
+        got = P.tend.get(1)[: m.NEdgesOwned]
+        assert np.array_equal(got[:, 1:], uT[: m.NEdgesOwned, 1:])
+        assert np.allclose(got[:, 0], uT[: m.NEdgesOwned, 0], rtol=1e-13, atol=0)
+    else:
+        check("NormalVelocityTend", P.tend.get(1), uT, m.NEdgesOwned)
+    check("LayerThicknessTend", P.tend.get(0), hT, m.NCellsOwned)
+    check("TracerTend", P.tend.get(2)[: case[4]], trT[: case[4]], m.NCellsOwned)
+
+
+def test_group_tendencies_fb_path():
+    """computeThicknessTendencies / computeTracerTendencies / computeVelocityTendencies
+    (the ForwardBackward stepper's calls, Tendencies.cpp:488-575)."""
+    P = _mk((20, 16, 30e3, 10, 2, {}))
+    m = P.mesh
+    P.tend.compute_thickness_tendencies(P.state, P.aux)
+    P.tend.compute_tracer_tendencies(P.state, P.aux, P.tracers)
+    P.tend.compute_velocity_tendencies(P.state, P.aux)
+    oa.device_synchronize()
+    check("hTend", P.tend.get(0), P.oracle.compute_thickness_tendencies(P.h, P.u), m.NCellsOwned)
+    check("trTend", P.tend.get(2), P.oracle.compute_tracer_tendencies(P.h, P.u, P.tr), m.NCellsOwned)
+    check("uTend", P.tend.get(1), P.oracle.compute_velocity_tendencies(P.h, P.u), m.NEdgesOwned)
+
+
+@pytest.mark.parametrize("kind,okind", [("RungeKutta4", "rk4"), ("RungeKutta2", "rk2"), ("Forward-Backward", "fb")])
+def test_time_steppers(kind, okind):
+    """doStep x3 against the oracle's restated steppers (state + tracers, bit-exact)."""
+    P = _mk((16, 16, 30e3, 6, 2, {}))
+    dt = 600.0
+    st = oa.TimeStepper(kind, dt, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    m = P.mesh
+    for step in range(3):
+        st.do_step(P.state)
+        oa.device_synchronize()
+        P.oracle.step(okind, ost, dt)
+        h, u = P.state.copy_to_host(0)
+        tr = P.tracers.copy_to_host(0)
+        check(f"h step {step}", h, ost["h"][0], m.NCellsOwned)
+        check(f"u step {step}", u, ost["u"][0], m.NEdgesOwned)
+        check(f"tr step {step}", tr, ost["tr"][0], m.NCellsOwned)
+
+
+def test_known_answer_through_gpu():
+    """The reference's own planar-mesh answers through the HIP path: AuxiliaryVarsTest
+    KineticEnergy / VelocityDiv norms (AuxiliaryVarsTest.cpp:34-37) from the GPU arrays."""
+    from tests import ka_common as ka
+    from tests.test_oracle_known_answers import vecX, vecY, divergence
+    K = 16
+    P = Problem(planar_hex(48, 48, 1.0 / 48.0), K, 1)
+    M = P.omesh
+    n = M.NEdgesOwned
+    u = np.zeros((M.NEdgesSize, K))
+    u[:n] = (np.cos(M.AngleEdge[:n]) * vecX(M.XEdge[:n], M.YEdge[:n])
+             + np.sin(M.AngleEdge[:n]) * vecY(M.XEdge[:n], M.YEdge[:n]))[:, None]
+    P.state.copy_to_device(P.h, u, 0)
+    P.aux.compute_mom_aux(P.state)
+    oa.device_synchronize()
+    ke = ka.set_scalar(M, K, lambda X, Y: (vecX(X, Y) ** 2 + vecY(X, Y) ** 2) / 2, "Cell")
+    ka.check_errors("KineticEnergy", ka.compute_errors(M, P.aux.get("KineticEnergyCell"), ke, "Cell"),
+                    (0.00994439065100057897, 0.00703403756741667954), 2e-4)
+    ka.check_errors("VelocityDiv", ka.compute_errors(M, P.aux.get("VelocityDivCell"),
+                                                     ka.set_scalar(M, K, divergence, "Cell"), "Cell"),
+                    (0.00124886886594453264, 0.00124886886590973452), 2e-4)
