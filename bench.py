@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the Omega ocean-dycore hot path on MI355X.
+
+Metric (BASELINE.json): tendency cell-level-updates/s of the fused RHS
+(Tendencies::computeAllTendencies) and SYPD of the RK4 step, on a synthetic QU30-sized
+mesh (planar periodic 680 x 680 = 462,400 cells ~ QU30's 460k), 80 levels, 6 tracers,
+Default.yml term set (del2 + del4, center fluxes).  One process per GPU; for N > 1 the mesh
+is partitioned N ways (strong scaling) and halos travel as RCCL send/recv over xGMI.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full RHS evaluation over the whole mesh (all N ranks).  The JSON line also
+carries `sypd` (RK4 steps, halo exchanges included), `roofline` (dominant kernel, live HIP
+events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a
+bounded sample of the same workload on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import omega_amd as oa  # noqa: E402
+from omega_amd.meshgen import planar_hex, reorder_cells_blocked, synthetic_state  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (nx, ny, dc [m], levels, tracers, description)
+    "qu30": (680, 680, 30.0e3, 80, 6, "QU30-sized planar periodic hex mesh 680x680 (462400 cells), 80L, 6 tracers"),
+    "qu240": (84, 84, 240.0e3, 60, 2, "QU240-sized planar periodic hex mesh 84x84 (7056 cells), 60L, 2 tracers"),
+    "ec30to60": (484, 484, 45.0e3, 60, 2, "EC30to60-sized planar mesh 484x484 (234256 cells), 60L, 2 tracers"),
+    "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
+}
+
+
+def algorithmic_bytes_per_cell_level(nt, kernel=None):
+    """SURVEY.md 8(d) B_staged = 8*(39 + 5*NT) B per cell-level for the whole RHS (NE = 3NC,
+    NV = 2NC); per kernel: the arrays that kernel must read / write once."""
+    per_kernel = {
+        "VortVertexBody(L1 vertex)": 8 * (1 + 3 + 3 * 2),             # h, u -> 3 vertex arrays
+        "FusedCell1Body(L1 cell)": 8 * (3 + 1 + nt + 3 + nt),          # u, h, tr -> KE, Div, hTend, Del2Tr
+        "FusedDel2CellBody(L2 cell)": 8 * (1 + 2 + 1),                 # Div, RelVort -> Del2Div
+        "FusedDel2VertexBody(L2 vertex)": 8 * (1 + 2 + 2),             # Div, RelVort -> Del2RelVort
+        "FusedEdgeBody(L3 edge)": 8 * (3 + 1 + 3 * 2 + 3 + 2 + 3),     # u,h,3V,KE,Div,Del2Div,Del2RV -> uTend
+        "FusedCell3Body(L3 cell)": 8 * (nt + nt + 1 + 3 + nt),         # tr, Del2Tr, h, u -> trTend
+    }
+    if kernel is None:
+        return 8 * (39 + 5 * nt)
+    return per_kernel[kernel]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("OMEGA_BENCH_WORKLOAD", "qu30"), choices=sorted(WORKLOADS))
+    ap.add_argument("--rk4-steps", type=int, default=-1, help="RK4 steps for SYPD (default: max(2, steps//4))")
+    ap.add_argument("--dt", type=float, default=600.0, help="time step [s] (Default.yml TimeStep 10 min)")
+    ap.add_argument("--block", type=int, default=16, help="cell-ordering block size of the synthetic mesh")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="time the reference-structured launch sequence instead")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    N = world
+
+    nx, ny, dc, K, NT, desc = WORKLOADS[args.workload]
+    dist = torch = None
+    stream = None
+    if N > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    oa.device_init(local_rank)
+
+    t0 = time.time()
+    g = planar_hex(nx, ny, dc)
+    if args.block > 1:
+        g = reorder_cells_blocked(g, args.block)
+    gm = oa.GlobalMesh(g)
+    decomp = oa.Decomp(gm, N, rank, 3)
+    mesh = oa.HorzMesh(decomp, K)
+    halo = oa.Halo(decomp) if N > 1 else None
+    cell_id, edge_id = decomp.get_array("CellID"), decomp.get_array("EdgeID")
+    hg, ug, trg = synthetic_state(g, K, NT)
+
+    def to_local(glob, ids, rows):
+        out = np.zeros(glob.shape[:-2] + (rows, glob.shape[-1]))
+        out[..., : rows - 1, :] = glob[..., ids[: rows - 1] - 1, :]
+        return out
+
+    h = to_local(hg, cell_id, mesh.NCellsSize)
+    u = to_local(ug, edge_id, mesh.NEdgesSize)
+    tr = to_local(trg, cell_id, mesh.NCellsSize)
+    del hg, ug, trg
+
+    if N > 1:
+        tstream = torch.cuda.Stream()
+        stream = oa.Stream(handle=tstream.cuda_stream)
+        from omega_amd.transport import TorchTransport
+        transport = TorchTransport(halo, per_cell=K * (1 + NT), per_edge=K, device=f"cuda:{local_rank}", stream=tstream)
+    else:
+        stream = oa.Stream()
+
+    cfg = oa.default_config()
+    state = oa.OceanState(mesh, halo, K, 2)
+    tracers = oa.Tracers(mesh, halo, K, NT, 2)
+    aux = oa.AuxiliaryState(mesh, halo, K, NT)
+    tend = oa.Tendencies(mesh, K, NT, cfg)
+    tend.set_fused(not args.unfused)
+    state.copy_to_device(h, u, 0)
+    tracers.copy_to_device(tr, 0)
+    setup_s = time.time() - t0
+
+    def barrier():
+        oa.device_synchronize()
+        if N > 1:
+            dist.barrier()
+            oa.device_synchronize()
+
+    def allmax(x):
+        if N == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------ RHS: W warm-up + K timed steps
+    for _ in range(args.warmup):
+        tend.compute_all_tendencies(state, aux, tracers, stream=stream)
+    barrier()
+    tend.kernel_timing(True)
+    ev0, ev1 = oa.Event(), oa.Event()
+    t_start = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        tend.compute_all_tendencies(state, aux, tracers, stream=stream)
+    ev1.record(stream)
+    barrier()
+    wall_rhs = time.perf_counter() - t_start
+    dev_ms = ev0.elapsed_ms(ev1)
+    tend.kernel_timing(False)
+    ktimes = tend.collect_kernel_times()
+    wall_rhs = allmax(wall_rhs)
+    ms_per_step = 1e3 * wall_rhs / args.steps
+
+    n_cells_global = g["nCells"]
+    cell_levels = n_cells_global * K
+    value = cell_levels / (wall_rhs / args.steps)
+
+    # ------------------------------------------------ RK4 steps (SYPD)
+    nrk = args.rk4_steps if args.rk4_steps >= 0 else max(2, args.steps // 4)
+    sypd = t_rk4 = None
+    if nrk > 0:
+        stepper = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
+        stepper.do_step(state, stream=stream)  # warm-up (allocations, RCCL connections)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nrk):
+            stepper.do_step(state, stream=stream)
+        barrier()
+        t_rk4 = allmax(time.perf_counter() - t1) / nrk
+        sypd = (args.dt / t_rk4) / 365.0
+        hh, _ = state.copy_to_host(0)
+        assert np.isfinite(hh[: mesh.NCellsOwned]).all(), "state went non-finite during the RK4 steps"
+
+    # ------------------------------------------------ roofline of the dominant kernel (rank 0's view)
+    roofline = None
+    if ktimes:
+        name, ms = max(ktimes, key=lambda kv: kv[1])
+        local_cell_levels = mesh.NCellsAll * K  # every launch sweeps owned + halo elements
+        ach = algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels / (ms * 1e-3) / 1e9
+        rhs_ms = sum(m for _, m in ktimes)
+        rhs_ach = algorithmic_bytes_per_cell_level(NT) * local_cell_levels / (rhs_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(ms, 4),
+                    "kernels_ms": {k: round(v, 4) for k, v in ktimes},
+                    "rhs": {"algorithmic_bytes_per_cell_level": algorithmic_bytes_per_cell_level(NT),
+                            "ms": round(rhs_ms, 4), "achieved": round(rhs_ach, 1),
+                            "frac": round(rhs_ach / HBM_PEAK_GBS, 4)}}
+
+    # ------------------------------------------------ CPU baseline (rank 0, N = 1 only): the oracle
+    cpu = None
+    if N == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(K, NT, dc)
+
+    if rank == 0:
+        out = {"metric": "tendency_cell_level_updates_per_sec", "value": value, "unit": "cell-level-updates/s",
+               "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
+                          "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
+                          "partition": f"rcb{N}", "halo_width": 3, "mesh_order": f"blocked{args.block}",
+                          "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1)},
+               "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(K, NT, dc):
+    """The CPU oracle (kind "port": restatement of the reference functors, OpenMP over elements)
+    timed on a bounded sample: a 1/16-size mesh of the same shape, same levels / tracers."""
+    from oracle import oracle as O
+    nxs = nys = 170
+    gs = planar_hex(nxs, nys, dc)
+    M = O.Mesh.single_rank(gs, K)
+    hs, us, trs = synthetic_state(gs, K, NT)
+
+    def pad(a):
+        out = np.zeros(a.shape[:-2] + (a.shape[-2] + 1, a.shape[-1]))
+        out[..., :-1, :] = a
+        return out
+    hs, us, trs = pad(hs), pad(us), pad(trs)
+    cores = min(os.cpu_count() or 1, 64)
+    O.lib().orc_set_num_threads(cores)
+    orc = O.Oracle(M, NT)
+    orc.compute_all_tendencies(hs, us, trs)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.compute_all_tendencies(hs, us, trs)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 50:
+            break
+    v = gs["nCells"] * K * n / el
+    return {"value": v, "unit": "cell-level-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{n} RHS evaluations of a {nxs}x{nys}-cell ({gs['nCells']} cells = 1/16 of the workload) x {K}L x "
+                      f"{NT} tracers mesh, reference launch structure (23 passes), OpenMP threads = cores"}
+
+
+if __name__ == "__main__":
+    main()

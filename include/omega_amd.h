@@ -174,6 +174,11 @@ int omg_tend_compute_velocity_only(omg_tend *t, const omg_state *s, omg_aux *a, 
                                    int vel_time_level, void *stream);
 int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr,
                                  int tracer_time_level, int thick_time_level, int vel_time_level, void *stream);
+/* per-kernel timing of the fused RHS with HIP events on the launch stream (Pacer "Tend:*" timers,
+ * O/src/ocn/Tendencies.cpp:280-481).  names[i] / ms_sum[i] for i < *n_kernels (<= 8). */
+int omg_tend_kernel_timing(omg_tend *t, int enable);
+int omg_tend_collect_kernel_times(omg_tend *t, double *ms_sum, int *n_kernels, int *n_samples);
+const char *omg_tend_kernel_name(int i);
 /* which: 0 LayerThicknessTend [NCellsSize][K], 1 NormalVelocityTend [NEdgesSize][K],
  *        2 TracerTend [NT][NCellsSize][K] */
 int omg_tend_copy_to_host(const omg_tend *t, int which, double *host, size_t n);

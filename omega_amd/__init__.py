@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libomega_amd.so")
+LIB_PATH = os.environ.get("OMEGA_AMD_LIB", os.path.join(_HERE, "lib", "libomega_amd.so"))
 
 ON_CELL, ON_EDGE, ON_VERTEX = 0, 1, 2
 
@@ -496,6 +496,20 @@ class Tendencies:
     def compute_tracer_tendencies_only(self, state, aux, tracers, tracer_tl=0, thick_tl=0, vel_tl=0, stream=None):
         _chk(lib().omg_tend_compute_tracer_only(self.h, state.h, aux.h, tracers.h, tracer_tl, thick_tl, vel_tl,
                                                 _sh(stream)))
+
+    def kernel_timing(self, on: bool):
+        _chk(lib().omg_tend_kernel_timing(self.h, int(on)))
+
+    def collect_kernel_times(self):
+        """[(kernel name, mean ms)] over the RHS evaluations recorded since kernel_timing(True)."""
+        ms = (C.c_double * 8)()
+        nk, ns = C.c_int(), C.c_int()
+        _chk(lib().omg_tend_collect_kernel_times(self.h, ms, C.byref(nk), C.byref(ns)))
+        L = lib()
+        L.omg_tend_kernel_name.restype = C.c_char_p
+        if ns.value == 0:
+            return []
+        return [(L.omg_tend_kernel_name(i).decode(), ms[i] / ns.value) for i in range(nk.value)]
 
     def get(self, which: int) -> np.ndarray:
         m = self.mesh

@@ -121,13 +121,20 @@ void HorzMesh::computeEdgeSign() {
 // HorzMesh::setMasks (reference HorzMesh.cpp:581-602): 1 everywhere (sentinel row
 // included), 0 on local edges with a cell outside [0, NCellsAll)
 void HorzMesh::setMasks() {
-   EdgeMaskH = HostArrayReal(NEdgesSize, NVertLayers, 1, 1.0);
+   EdgeMask1DH = HostArrayReal(NEdgesSize, 1, 1, 1.0);
    for (int Edge = 0; Edge < NEdgesAll; ++Edge) {
       const I4 Cell1 = CellsOnEdgeH(Edge, 0), Cell2 = CellsOnEdgeH(Edge, 1);
       if (!(Cell1 >= 0 && Cell1 < NCellsAll) || !(Cell2 >= 0 && Cell2 < NCellsAll))
-         for (int K = 0; K < NVertLayers; ++K)
-            EdgeMaskH(Edge, K) = 0.0;
+         EdgeMask1DH(Edge) = 0.0;
    }
+}
+
+HostArrayReal HorzMesh::edgeMask2D() const {
+   HostArrayReal M2(NEdgesSize, NVertLayers, 1, 1.0);
+   for (int Edge = 0; Edge < NEdgesSize; ++Edge)
+      for (int K = 0; K < NVertLayers; ++K)
+         M2(Edge, K) = EdgeMask1DH(Edge);
+   return M2;
 }
 
 // HorzMesh::setMeshScaling (reference HorzMesh.cpp:607-626): no scaling option only
@@ -164,7 +171,6 @@ void HorzMesh::copyToDevice() {
 
    EdgeSignOnCell   = createDeviceMirrorCopy<Real, 2>("EdgeSignOnCell", EdgeSignOnCellH);
    EdgeSignOnVertex = createDeviceMirrorCopy<Real, 2>("EdgeSignOnVertex", EdgeSignOnVertexH);
-   EdgeMask         = createDeviceMirrorCopy<Real, 2>("EdgeMask", EdgeMaskH);
    MeshScalingDel2  = createDeviceMirrorCopy<Real, 1>("MeshScalingDel2", MeshScalingDel2H);
    MeshScalingDel4  = createDeviceMirrorCopy<Real, 1>("MeshScalingDel4", MeshScalingDel4H);
 }
@@ -180,14 +186,14 @@ void HorzMesh::setFVertex(const Real *HostValues) {
 // left-to-right order (file:line of each chain in the comments).
 void HorzMesh::buildCoefficientTables() {
    const int ME = MaxEdges, ME2 = MaxEdges2, VD = VertexDegree;
-   HostArrayReal Mask1D(NEdgesSize, 1, 1, 0.0);
-   for (int E = 0; E < NEdgesSize; ++E)
-      Mask1D(E) = EdgeMaskH(E, 0);
+   const HostArrayReal &Mask1D = EdgeMask1DH;
 
    HostArrayReal InvA(NCellsSize, 1, 1, 0.0), DvS(NCellsSize, ME, 1, 0.0), DivC(NCellsSize, ME, 1, 0.0),
        KEC(NCellsSize, ME, 1, 0.0), MDvS(NCellsSize, ME, 1, 0.0), D2T(NCellsSize, ME, 1, 0.0),
-       Df2(NCellsSize, ME, 1, 0.0), Df4(NCellsSize, ME, 1, 0.0);
+       Df2(NCellsSize, ME, 1, 0.0), Df4(NCellsSize, ME, 1, 0.0), D2TS(NCellsSize, ME, 1, 0.0),
+       Df2S(NCellsSize, ME, 1, 0.0), Df4S(NCellsSize, ME, 1, 0.0);
    HostArrayI4 COEOC(NCellsSize, ME, 2, NCellsAll);
+   HostArrayI4 NbrF(NCellsSize, ME, 1, NCellsAll);
    for (int C = 0; C < NCellsAll; ++C) {
       const Real InvAreaCell = 1. / AreaCellH(C);
       InvA(C)                = InvAreaCell;
@@ -208,6 +214,15 @@ void HorzMesh::buildCoefficientTables() {
          Df4(C, J)           = M * Sign * RTemp4;             // TendencyTerms.h:472-473
          COEOC.V[((size_t)C * ME + J) * 2 + 0] = CellsOnEdgeH(E, 0);
          COEOC.V[((size_t)C * ME + J) * 2 + 1] = CellsOnEdgeH(E, 1);
+         // neighbour across edge J; bit 30 set when this cell is the edge's first cell
+         // (EdgeSignOnCell = -1).  Edges that do not hold this cell at all (the sentinel edge of
+         // outer-halo cells) count as "cell is second".
+         const bool SelfIsC0 = CellsOnEdgeH(E, 0) == C;
+         NbrF(C, J)          = (SelfIsC0 ? CellsOnEdgeH(E, 1) : CellsOnEdgeH(E, 0)) | (SelfIsC0 ? (1 << 30) : 0);
+         const Real Orient   = SelfIsC0 ? 1.0 : -1.0; // (T1 - T0) = Orient * (Tneighbour - Tself), exactly
+         D2TS(C, J)          = D2T(C, J) * Orient;
+         Df2S(C, J)          = Df2(C, J) * Orient;
+         Df4S(C, J)          = Df4(C, J) * Orient;
       }
    }
    HostArrayReal KiteC(NVerticesSize, VD, 1, 0.0), VortC(NVerticesSize, VD, 1, 0.0);
@@ -241,6 +256,80 @@ void HorzMesh::buildCoefficientTables() {
       }
    }
 
+   // ---- chain form of the PV stencil (see HorzMesh.h) ----
+   const int MEm1 = ME - 1;
+   HostArrayI4 ChV(NEdgesSize, 2, ME, NVerticesAll), ChF(NEdgesSize, 2, MEm1, NCellsAll),
+       ChE(NEdgesSize, 2, MEm1, NEdgesAll);
+   HostArrayReal ChW(NEdgesSize, 2, MEm1, 0.0);
+   bool ChainOK = true;
+   auto SharedVertex = [&](int E1, int E2) {
+      for (int A = 0; A < 2; ++A)
+         for (int B = 0; B < 2; ++B)
+            if (VerticesOnEdgeH(E1, A) == VerticesOnEdgeH(E2, B) && VerticesOnEdgeH(E1, A) < NVerticesAll)
+               return (int)VerticesOnEdgeH(E1, A);
+      return -1;
+   };
+   for (int E = 0; E < NEdgesAll && ChainOK; ++E) {
+      // an edge with a missing cell (coast line, outermost halo rim) has EdgeMask 0: its PV term is
+      // mask * (finite sum) = 0 whatever the stencil, so its tables stay at the zero-weight padding
+      if (Mask1D(E) == 0.0)
+         continue;
+      int Pos = 0; // running position in EdgesOnEdge(E, .)
+      for (int Sd = 0; Sd < 2; ++Sd) {
+         const int Cs = CellsOnEdgeH(E, Sd);
+         if (Cs < 0 || Cs >= NCellsAll)
+            continue; // no cell on this side: no stencil entries
+         const int N = NEdgesOnCellH(Cs);
+         int P0 = -1;
+         for (int J = 0; J < N; ++J)
+            if (EdgesOnCellH(Cs, J) == E)
+               P0 = J;
+         if (P0 < 0 || N > ME) {
+            ChainOK = false;
+            break;
+         }
+         int Prev = E;
+         for (int Kk = 1; Kk < N; ++Kk) {
+            const int Ep = EdgesOnCellH(Cs, (P0 + Kk) % N);
+            // the walk must reproduce EdgesOnEdge(E, :) entry by entry
+            if (Pos >= ME2 || EdgesOnEdgeH(E, Pos) != Ep) {
+               ChainOK = false;
+               break;
+            }
+            const int V = SharedVertex(Prev, Ep);
+            if (V < 0) {
+               ChainOK = false;
+               break;
+            }
+            const size_t Bv = ((size_t)E * 2 + Sd) * ME, Bm = ((size_t)E * 2 + Sd) * MEm1;
+            ChV.V[Bv + Kk - 1] = V;
+            const bool SideIsC0 = CellsOnEdgeH(Ep, 0) == Cs;
+            const int Far       = SideIsC0 ? CellsOnEdgeH(Ep, 1) : CellsOnEdgeH(Ep, 0);
+            ChF.V[Bm + Kk - 1]  = Far | (SideIsC0 ? (1 << 30) : 0);
+            ChE.V[Bm + Kk - 1]  = Ep;
+            ChW.V[Bm + Kk - 1]  = WeightsOnEdgeH(E, Pos);
+            if (Kk == N - 1) { // closing vertex: shared by the last edge and E
+               const int Vl = SharedVertex(Ep, E);
+               if (Vl < 0) {
+                  ChainOK = false;
+                  break;
+               }
+               ChV.V[Bv + Kk] = Vl;
+            }
+            Prev = Ep;
+            ++Pos;
+         }
+         if (!ChainOK)
+            break;
+      }
+      if (ChainOK && Pos != NEdgesOnEdgeH(E))
+         ChainOK = false; // EdgesOnEdge is not [other edges of cell 0, other edges of cell 1]
+   }
+   PVChainVert   = createDeviceMirrorCopy<I4, 3>("PVChainVert", ChV);
+   PVChainFar    = createDeviceMirrorCopy<I4, 3>("PVChainFar", ChF);
+   PVChainEdge   = createDeviceMirrorCopy<I4, 3>("PVChainEdge", ChE);
+   PVChainWeight = createDeviceMirrorCopy<Real, 3>("PVChainWeight", ChW);
+
    EdgeMask1D        = createDeviceMirrorCopy<Real, 1>("EdgeMask1D", Mask1D);
    InvAreaCell       = createDeviceMirrorCopy<Real, 1>("InvAreaCell", InvA);
    DvSignOnCell      = createDeviceMirrorCopy<Real, 2>("DvSignOnCell", DvS);
@@ -251,6 +340,10 @@ void HorzMesh::buildCoefficientTables() {
    Diff2CoefOnCell   = createDeviceMirrorCopy<Real, 2>("Diff2CoefOnCell", Df2);
    Diff4CoefOnCell   = createDeviceMirrorCopy<Real, 2>("Diff4CoefOnCell", Df4);
    CellsOnEdgeOnCell = createDeviceMirrorCopy<I4, 3>("CellsOnEdgeOnCell", COEOC);
+   NbrFlagOnCell     = createDeviceMirrorCopy<I4, 2>("NbrFlagOnCell", NbrF);
+   Del2TrCoefSOnCell = createDeviceMirrorCopy<Real, 2>("Del2TrCoefSOnCell", D2TS);
+   Diff2CoefSOnCell  = createDeviceMirrorCopy<Real, 2>("Diff2CoefSOnCell", Df2S);
+   Diff4CoefSOnCell  = createDeviceMirrorCopy<Real, 2>("Diff4CoefSOnCell", Df4S);
    KiteCoefOnVertex  = createDeviceMirrorCopy<Real, 2>("KiteCoefOnVertex", KiteC);
    VortCoefOnVertex  = createDeviceMirrorCopy<Real, 2>("VortCoefOnVertex", VortC);
    InvDcEdge         = createDeviceMirrorCopy<Real, 1>("InvDcEdge", IDc);
@@ -270,15 +363,21 @@ void HorzMesh::buildCoefficientTables() {
    W.AreaCell = AreaCell.Ptr, W.AreaTriangle = AreaTriangle.Ptr, W.KiteAreasOnVertex = KiteAreasOnVertex.Ptr;
    W.DcEdge = DcEdge.Ptr, W.DvEdge = DvEdge.Ptr, W.AngleEdge = AngleEdge.Ptr, W.WeightsOnEdge = WeightsOnEdge.Ptr;
    W.FVertex = FVertex.Ptr, W.BottomDepth = BottomDepth.Ptr;
-   W.EdgeSignOnCell = EdgeSignOnCell.Ptr, W.EdgeSignOnVertex = EdgeSignOnVertex.Ptr, W.EdgeMask = EdgeMask.Ptr;
+   W.EdgeSignOnCell = EdgeSignOnCell.Ptr, W.EdgeSignOnVertex = EdgeSignOnVertex.Ptr;
    W.EdgeMask1D = EdgeMask1D.Ptr, W.MeshScalingDel2 = MeshScalingDel2.Ptr, W.MeshScalingDel4 = MeshScalingDel4.Ptr;
    W.InvAreaCell = InvAreaCell.Ptr, W.DvSignOnCell = DvSignOnCell.Ptr, W.DivCoefOnCell = DivCoefOnCell.Ptr;
    W.KECoefOnCell = KECoefOnCell.Ptr, W.MaskDvSignOnCell = MaskDvSignOnCell.Ptr;
    W.Del2TrCoefOnCell = Del2TrCoefOnCell.Ptr, W.Diff2CoefOnCell = Diff2CoefOnCell.Ptr;
    W.Diff4CoefOnCell = Diff4CoefOnCell.Ptr, W.CellsOnEdgeOnCell = CellsOnEdgeOnCell.Ptr;
+   W.NbrFlagOnCell = NbrFlagOnCell.Ptr;
+   W.Del2TrCoefSOnCell = Del2TrCoefSOnCell.Ptr, W.Diff2CoefSOnCell = Diff2CoefSOnCell.Ptr;
+   W.Diff4CoefSOnCell = Diff4CoefSOnCell.Ptr;
    W.KiteCoefOnVertex = KiteCoefOnVertex.Ptr, W.VortCoefOnVertex = VortCoefOnVertex.Ptr;
    W.InvDcEdge = InvDcEdge.Ptr, W.InvDvEdge = InvDvEdge.Ptr, W.InvDvEdgeDel2 = InvDvEdgeDel2.Ptr;
    W.PVStencil = PVStencil.Ptr;
+   W.PVChainOK = ChainOK ? 1 : 0;
+   W.PVChainVert = PVChainVert.Ptr, W.PVChainFar = PVChainFar.Ptr, W.PVChainEdge = PVChainEdge.Ptr;
+   W.PVChainWeight = PVChainWeight.Ptr;
 }
 
 } // namespace OMEGA

@@ -27,7 +27,7 @@ struct MeshView {
    const I4 *CellsOnVertex, *EdgesOnVertex;
    const Real *AreaCell, *AreaTriangle, *KiteAreasOnVertex, *DcEdge, *DvEdge, *AngleEdge;
    const Real *WeightsOnEdge, *FVertex, *BottomDepth;
-   const Real *EdgeSignOnCell, *EdgeSignOnVertex, *EdgeMask, *EdgeMask1D;
+   const Real *EdgeSignOnCell, *EdgeSignOnVertex, *EdgeMask1D;
    const Real *MeshScalingDel2, *MeshScalingDel4;
    // ---- coefficient tables (see HorzMesh::buildCoefficientTables) ----
    const Real *InvAreaCell;        // [C]      1/AreaCell
@@ -38,13 +38,27 @@ struct MeshView {
    const Real *Del2TrCoefOnCell;   // [C][ME]  EdgeMask*EdgeSignOnCell*(DvEdge/DcEdge)
    const Real *Diff2CoefOnCell;    // [C][ME]  EdgeMask*EdgeSignOnCell*(MeshScalingDel2*DvEdge/DcEdge)
    const Real *Diff4CoefOnCell;    // [C][ME]  EdgeMask*EdgeSignOnCell*(MeshScalingDel4*DvEdge/DcEdge)
+   // the same three with the orientation folded in (x +1 if this cell is the edge's first cell,
+   // else -1), to be used with (neighbour - self) differences: coef*(T1-T0) == coefS*(Tn-Ts) exactly
+   const Real *Del2TrCoefSOnCell, *Diff2CoefSOnCell, *Diff4CoefSOnCell; // [C][ME]
    const I4 *CellsOnEdgeOnCell;    // [C][ME][2] CellsOnEdge(EdgesOnCell(c,j), 0..1)
+   const I4 *NbrFlagOnCell;        // [C][ME]  cell across edge j, | (1<<30) if this cell is CellsOnEdge(e,0)
    const Real *KiteCoefOnVertex;   // [V][VD]  InvAreaTriangle*KiteAreasOnVertex
    const Real *VortCoefOnVertex;   // [V][VD]  InvAreaTriangle*DcEdge*EdgeSignOnVertex
    const Real *InvDcEdge;          // [E]      1/DcEdge
    const Real *InvDvEdge;          // [E]      1/DvEdge
    const Real *InvDvEdgeDel2;      // [E]      1/max(DvEdge, 0.25*DcEdge)
    const I4 *PVStencil;            // [E][ME2][4] CellsOnEdge / VerticesOnEdge of EdgesOnEdge(e,j)
+   // Chain form of the PotentialVortHAdvOnEdge stencil (valid when PVChainOK): side s = 0,1 is
+   // cell CellsOnEdge(e,s); its other edges e'_1..e'_{n-1} in EdgesOnEdge order are
+   // PVChainEdge[e][s][j-1] with weight PVChainWeight[e][s][j-1]; e'_j has end vertices
+   // PVChainVert[e][s][j-1], PVChainVert[e][s][j] and far cell PVChainFar[e][s][j-1]
+   // (| 1<<30 when the side cell is CellsOnEdge(e'_j, 0)).  Padding: zero weight, sentinel rows.
+   I4 PVChainOK;
+   const I4 *PVChainVert;          // [E][2][ME]
+   const I4 *PVChainFar;           // [E][2][ME-1]
+   const I4 *PVChainEdge;          // [E][2][ME-1]
+   const Real *PVChainWeight;      // [E][2][ME-1]
 };
 
 class HorzMesh {
@@ -78,9 +92,12 @@ class HorzMesh {
    Array2DReal KiteAreasOnVertex, WeightsOnEdge;
 
    // derived
-   HostArrayReal EdgeSignOnCellH, EdgeSignOnVertexH, EdgeMaskH, MeshScalingDel2H, MeshScalingDel4H;
-   Array2DReal EdgeSignOnCell, EdgeSignOnVertex, EdgeMask;
+   /// EdgeMask: the reference stores EdgeMask(NEdgesSize, NVertLayers) but sets it level-independent
+   /// (HorzMesh.cpp:589-598); here it is kept per edge and expanded on request (edgeMask2D()).
+   HostArrayReal EdgeSignOnCellH, EdgeSignOnVertexH, EdgeMask1DH, MeshScalingDel2H, MeshScalingDel4H;
+   Array2DReal EdgeSignOnCell, EdgeSignOnVertex;
    Array1DReal EdgeMask1D, MeshScalingDel2, MeshScalingDel4;
+   HostArrayReal edgeMask2D() const; ///< (NEdgesSize, NVertLayers) as in the reference
 
    /// Replace FVertex (the reference's tests override it, AuxiliaryVarsTest.cpp:333-338)
    void setFVertex(const Real *HostValues /* NVerticesSize */);
@@ -98,8 +115,11 @@ class HorzMesh {
    // coefficient tables (device)
    Array1DReal InvAreaCell, InvDcEdge, InvDvEdge, InvDvEdgeDel2;
    Array2DReal DvSignOnCell, DivCoefOnCell, KECoefOnCell, MaskDvSignOnCell, Del2TrCoefOnCell, Diff2CoefOnCell,
-       Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex;
+       Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex, Del2TrCoefSOnCell, Diff2CoefSOnCell, Diff4CoefSOnCell;
    DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
+   Array2DI4 NbrFlagOnCell;
+   DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;
+   Array3DReal PVChainWeight;
 };
 
 } // namespace OMEGA

@@ -11,6 +11,32 @@ Tendencies::Tendencies(const std::string &, const HorzMesh *Mesh_, int K, int NT
    TracerTend         = Array3DReal("TracerTend", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
 }
 
+Tendencies::~Tendencies() {
+   for (auto &Set : TimingEvents)
+      for (auto &E : Set)
+         (void)hipEventDestroy(E);
+}
+
+void Tendencies::enableKernelTiming(bool On) { TimingOn = On; }
+
+int Tendencies::collectKernelTimes(double *MsSum) {
+   for (int I = 0; I < FusedNumKernels; ++I)
+      MsSum[I] = 0.0;
+   const int N = (int)TimingEvents.size();
+   for (auto &Set : TimingEvents) {
+      HIP_CHECK(hipEventSynchronize(Set[FusedNumKernels]));
+      for (int I = 0; I < FusedNumKernels; ++I) {
+         float Ms = 0.f;
+         HIP_CHECK(hipEventElapsedTime(&Ms, Set[I], Set[I + 1]));
+         MsSum[I] += Ms;
+      }
+      for (auto &E : Set)
+         (void)hipEventDestroy(E);
+   }
+   TimingEvents.clear();
+   return N;
+}
+
 TendParams Tendencies::paramsFor(const AuxiliaryState *Aux) const {
    TendParams P          = Params;
    P.FluxThicknessUpwind = Aux->LayerThicknessAux.FluxThickEdgeChoice == FluxThickEdgeOption::Upwind;
@@ -74,13 +100,20 @@ void Tendencies::computeTracerTendencies(const OceanState *State, const Auxiliar
 // Tendencies.cpp:579-600
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
                                       int ThickLvl, int VelLvl, hipStream_t S) {
-   if (UseFusedRHS && Mesh->MaxEdges <= 8) {
+   if (UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)) {
       Array2DReal LayerThick, NormVel;
       OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 &&
                         State->getNormalVelocity(NormVel, VelLvl) == 0,
                     "Tendencies: bad time level");
+      hipEvent_t *Ev = nullptr;
+      if (TimingOn && TimingEvents.size() < 4096) {
+         TimingEvents.emplace_back(FusedNumKernels + 1);
+         for (auto &E : TimingEvents.back())
+            HIP_CHECK(hipEventCreate(&E));
+         Ev = TimingEvents.back().data();
+      }
       launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
-                     NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S);
+                     NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev);
       return;
    }
    Aux->computeAll(State, TracerArray, ThickLvl, VelLvl, S);

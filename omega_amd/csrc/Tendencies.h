@@ -41,10 +41,20 @@ class Tendencies {
    void computeAllTendencies(const OceanState *State, const AuxiliaryState *AuxState, const Array3DReal &TracerArray,
                              int ThickTimeLevel, int VelTimeLevel, hipStream_t S);
 
+   /// Per-kernel timing of the fused RHS with HIP events on the launch stream (bench.py's
+   /// roofline leg): while enabled every computeAllTendencies call records 7 events.
+   void enableKernelTiming(bool On);
+   /// Sum of the recorded durations per kernel [FusedNumKernels] in ms and the number of
+   /// recorded RHS evaluations; synchronises, then clears the recordings.
+   int collectKernelTimes(double *MsSum);
+   ~Tendencies();
+
    const HorzMesh *Mesh;
    int NVertLayers, NTracers;
 
  private:
+   bool TimingOn = false;
+   std::vector<std::vector<hipEvent_t>> TimingEvents;
    /// AuxiliaryState options are read by AuxiliaryState::readConfigOptions in the reference;
    /// the kernels take them through TendParams, so sync them from the AuxState in use.
    TendParams paramsFor(const AuxiliaryState *AuxState) const;

@@ -349,8 +349,15 @@ int omg_mesh_get_array_r8(const omg_mesh *m, const char *name, double *out, size
        {"DcEdge", &M.DcEdgeH},         {"AngleEdge", &M.AngleEdgeH}, {"WeightsOnEdge", &M.WeightsOnEdgeH},
        {"FEdge", &M.FEdgeH},           {"FCell", &M.FCellH},       {"FVertex", &M.FVertexH},
        {"BottomDepth", &M.BottomDepthH}, {"EdgeSignOnCell", &M.EdgeSignOnCellH},
-       {"EdgeSignOnVertex", &M.EdgeSignOnVertexH},                 {"EdgeMask", &M.EdgeMaskH},
+       {"EdgeSignOnVertex", &M.EdgeSignOnVertexH},                 {"EdgeMask1D", &M.EdgeMask1DH},
        {"MeshScalingDel2", &M.MeshScalingDel2H},                   {"MeshScalingDel4", &M.MeshScalingDel4H}};
+   if (std::string(name) == "EdgeMask") { // expanded to the reference's (NEdgesSize, NVertLayers) shape
+      const HostArrayReal M2 = M.edgeMask2D();
+      if (n < M2.size())
+         OMEGA_ABORT("output buffer too small for EdgeMask");
+      std::memcpy(out, M2.data(), M2.size() * sizeof(double));
+      return 0;
+   }
    auto It = A.find(name);
    if (It == A.end())
       OMEGA_ABORT(std::string("HorzMesh: no real array member named ") + name);
@@ -704,6 +711,20 @@ int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, co
    t->T->computeTracerTendenciesOnly(s->S.get(), a->A.get(), tracerArray(tr, trtl), ttl, vtl, (hipStream_t)stream);
    OMG_CATCH
 }
+int omg_tend_kernel_timing(omg_tend *t, int enable) {
+   OMG_TRY
+   OMG_ARG(t);
+   t->T->enableKernelTiming(enable != 0);
+   OMG_CATCH
+}
+int omg_tend_collect_kernel_times(omg_tend *t, double *ms_sum, int *n_kernels, int *n_samples) {
+   OMG_TRY
+   OMG_ARG(t && ms_sum && n_kernels && n_samples);
+   *n_samples = t->T->collectKernelTimes(ms_sum);
+   *n_kernels = FusedNumKernels;
+   OMG_CATCH
+}
+const char *omg_tend_kernel_name(int i) { return (i >= 0 && i < FusedNumKernels) ? FusedKernelNames[i] : ""; }
 static void tendLookup(const Tendencies &T, int Which, Real *&P, size_t &C) {
    switch (Which) {
    case 0:

@@ -19,16 +19,71 @@
 #include "KernelCommon.h"
 #include "Kernels.h"
 
+// tuning knobs of the tracer cell kernels (VGPR budget / levels per thread)
+#ifndef OMEGA_CELL_MINW
+#define OMEGA_CELL_MINW 2
+#endif
+#ifndef OMEGA_CELL_MAXW
+#define OMEGA_CELL_MAXW 2
+#endif
+
+#ifndef OMEGA_EDGE_MINW
+#define OMEGA_EDGE_MINW 2
+#endif
+#ifndef OMEGA_EDGE_MAXW
+#define OMEGA_EDGE_MAXW 2
+#endif
+
 namespace OMEGA {
 
-constexpr int MEMAX = 8; // register-array bound on edges per cell in the fused kernels
+// ---------------------------------------------------------------------------------------
+// Addressing.  Inside one array plane ([rows][K] doubles) an element is addressed by a 32-bit
+// BYTE offset from the plane's base pointer.  The base is wave-uniform (kernel argument, or
+// argument + tracer * plane size), so the compiler emits `global_load_dwordx4 v, v_off, s[base]`
+// and a gather costs one 32-bit VGPR per neighbour, shared by every array of that index space
+// (h, each tracer, each Del2Tracers plane, ...).  launchFusedRHS checks planes are < 4 GiB.
+template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned ByteOff) {
+   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(Base) + ByteOff);
+}
+template <class T> __device__ __forceinline__ void sto(Real *Base, unsigned ByteOff, T V) {
+   *reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff) = V;
+}
+template <class T> __device__ __forceinline__ unsigned rowOff(int Row, int K, int Kv) {
+   return ((unsigned)Row * (unsigned)K + (unsigned)Kv * (unsigned)VecW<T>::W) * 8u;
+}
+/// make a wave-uniform pointer provably scalar (SGPR pair) so gathers use the
+/// `saddr + 32-bit voffset` form instead of per-lane 64-bit pointers
+__device__ __forceinline__ const Real *uniformPtr(const Real *P) {
+   const unsigned long long V = reinterpret_cast<unsigned long long>(P);
+   const unsigned Lo = __builtin_amdgcn_readfirstlane((unsigned)V);
+   const unsigned Hi = __builtin_amdgcn_readfirstlane((unsigned)(V >> 32));
+   return reinterpret_cast<const Real *>(((unsigned long long)Hi << 32) | Lo);
+}
+__device__ __forceinline__ Real *uniformPtr(Real *P) {
+   return const_cast<Real *>(uniformPtr(const_cast<const Real *>(P)));
+}
+__device__ __forceinline__ double pick(bool C, double A, double B) { return C ? A : B; }
+__device__ __forceinline__ dv2 pick(bool C, dv2 A, dv2 B) { return C ? A : B; }
+
+// Cell kernels work on the TME (= MaxEdges, compile time) edge slots of a cell; slots past
+// NEdgesOnCell carry zero coefficients and point at the zero sentinel rows, so the sweep is
+// branch-free, all gathers of a sweep are in flight together, and padded slots add exact zeros.
+// For each slot the cell across the edge and whether this cell is the edge's first cell come
+// packed from NbrFlagOnCell: the value at "this" cell is loaded once and the (cell0, cell1)
+// pair the reference indexes is rebuilt with a select.
+//
+// `Fast` = Default.yml term set (every term on, center fluxes, no wind / drag): the option
+// flags fold at compile time and the loops carry no branches; otherwise they are read at run
+// time (same arithmetic, more control flow).
 
 // ---------------------------------------------------------------------------------------
 // L1 cell pass: KineticAuxVars::computeVarsOnCell (KineticAuxVars.h:20-47),
 // LayerThicknessAuxVars::computeVarsOnEdge inline (LayerThicknessAuxVars.h:25-61) feeding
 // ThicknessFluxDivOnCell (TendencyTerms.h:35-58), TracerAuxVars::computeVarsOnCells
 // (TracerAuxVars.h:61-91).
-struct FusedCell1Body {
+template <int TME, bool Fast> struct FusedCell1Body {
+   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int MaxW     = OMEGA_CELL_MAXW;
    MeshView M;
    int K, NT;
    TendParams P;
@@ -37,85 +92,91 @@ struct FusedCell1Body {
    Real *KE, *Div, *HTend, *Del2Tr;
    struct Lds {
       Real *KEC, *DivC, *DvS, *D2T, *InvA;
-      int *Edge, *C0, *C1, *N;
+      int *Edge, *NbrF;
    };
    size_t ldsBytes(int Tile) const {
-      const int ME = M.MaxEdges;
-      return ldsRound8(sizeof(Real) * Tile * ME) * 4 + ldsRound8(sizeof(Real) * Tile) +
-             ldsRound8(sizeof(int) * Tile * ME) * 3 + ldsRound8(sizeof(int) * Tile);
+      return ldsRound8(sizeof(Real) * Tile * TME) * 4 + ldsRound8(sizeof(Real) * Tile) +
+             ldsRound8(sizeof(int) * Tile * TME) * 2;
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
-      const int ME = M.MaxEdges;
       LdsCarver C{Ptr};
       Lds L;
-      L.KEC  = C.take<Real>(Tile * ME);
-      L.DivC = C.take<Real>(Tile * ME);
-      L.DvS  = C.take<Real>(Tile * ME);
-      L.D2T  = C.take<Real>(Tile * ME);
+      L.KEC  = C.take<Real>(Tile * TME);
+      L.DivC = C.take<Real>(Tile * TME);
+      L.DvS  = C.take<Real>(Tile * TME);
+      L.D2T  = C.take<Real>(Tile * TME);
       L.InvA = C.take<Real>(Tile);
-      L.Edge = C.take<int>(Tile * ME);
-      L.C0   = C.take<int>(Tile * ME);
-      L.C1   = C.take<int>(Tile * ME);
-      L.N    = C.take<int>(Tile);
+      L.Edge = C.take<int>(Tile * TME);
+      L.NbrF = C.take<int>(Tile * TME);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
-      const int ME = M.MaxEdges;
-      for (int I = Tid; I < Cnt * ME; I += NThr) {
-         const size_t G = (size_t)First * ME + I;
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const size_t G = (size_t)First * TME + I;
          L.KEC[I]       = M.KECoefOnCell[G];
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.DvS[I]       = M.DvSignOnCell[G];
-         L.D2T[I]       = M.Del2TrCoefOnCell[G];
+         L.D2T[I]       = Fast ? M.Del2TrCoefSOnCell[G] : M.Del2TrCoefOnCell[G];
          L.Edge[I]      = M.EdgesOnCell[G];
-         L.C0[I]        = M.CellsOnEdgeOnCell[2 * G];
-         L.C1[I]        = M.CellsOnEdgeOnCell[2 * G + 1];
+         L.NbrF[I]      = M.NbrFlagOnCell[G];
       }
-      for (int I = Tid; I < Cnt; I += NThr) {
-         L.N[I]    = M.NEdgesOnCell[First + I];
+      for (int I = Tid; I < Cnt; I += NThr)
          L.InvA[I] = M.InvAreaCell[First + I];
-      }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
-      const int ME    = M.MaxEdges;
-      const int N     = L.N[Le];
-      const Real InvA = L.InvA[Le];
-      T KETmp = splat<T>(0.0), DivTmp = splat<T>(0.0), HDivTmp = splat<T>(0.0);
-      T HMeanJ[MEMAX];
+      const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
+      const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
+      const Real InvA       = L.InvA[Le];
+      const unsigned OffS   = rowOff<T>(ICell, K, Kv);
+      unsigned OffN[TME];
+      bool IsC0[TME];
+      T Ue[TME], Hn[TME];
 #pragma unroll
-      for (int J = 0; J < MEMAX; ++J) {
-         HMeanJ[J] = splat<T>(0.0);
-         if (J < N) {
-            const int JEdge = L.Edge[Le * ME + J];
-            const T Ue      = ldk<T>(U, JEdge, K, Kv);
-            const T H0 = ldk<T>(H, L.C0[Le * ME + J], K, Kv), H1 = ldk<T>(H, L.C1[Le * ME + J], K, Kv);
-            const T Mean = 0.5 * (H0 + H1);
-            HMeanJ[J]    = Mean;
-            const T Flux = P.FluxThicknessUpwind ? upwind(Ue, H0, H1) : Mean;
-            KETmp += L.KEC[Le * ME + J] * Ue * Ue;
-            DivTmp -= L.DivC[Le * ME + J] * Ue;
-            HDivTmp -= L.DvS[Le * ME + J] * Flux * Ue * InvA;
-         }
+      for (int J = 0; J < TME; ++J) {
+         const int F = L.NbrF[Le * TME + J];
+         OffN[J]     = rowOff<T>(F & 0x3fffffff, K, Kv);
+         IsC0[J]     = (F >> 30) != 0;
+         Ue[J]       = ldo<T>(U, rowOff<T>(L.Edge[Le * TME + J], K, Kv));
+         Hn[J]       = ldo<T>(H, OffN[J]);
       }
-      stk<T>(KE, ICell, K, Kv, KETmp);
-      stk<T>(Div, ICell, K, Kv, DivTmp);
+      const T Hs = ldo<T>(H, OffS);
+      T KETmp = splat<T>(0.0), DivTmp = splat<T>(0.0), HDivTmp = splat<T>(0.0);
+      T HMeanJ[TME];
+#pragma unroll
+      for (int J = 0; J < TME; ++J) {
+         const T Mean = 0.5 * (Hs + Hn[J]); // 0.5*(h(c0)+h(c1)): a+b == b+a
+         HMeanJ[J]    = Mean;
+         T Flux       = Mean;
+         if (FluxUpwind)
+            Flux = upwind(Ue[J], pick(IsC0[J], Hs, Hn[J]), pick(IsC0[J], Hn[J], Hs));
+         KETmp += L.KEC[Le * TME + J] * Ue[J] * Ue[J];
+         DivTmp -= L.DivC[Le * TME + J] * Ue[J];
+         HDivTmp -= L.DvS[Le * TME + J] * Flux * Ue[J] * InvA;
+      }
+      sto<T>(KE, OffS, KETmp);
+      sto<T>(Div, OffS, DivTmp);
       T HT = splat<T>(0.0);
-      if (P.ThicknessFluxTendencyEnable)
+      if (ThickOn)
          HT -= HDivTmp;
-      stk<T>(HTend, ICell, K, Kv, HT);
+      sto<T>(HTend, OffS, HT);
       if (DoDel2Tr) {
          const size_t CStride = (size_t)M.NCellsSize * K;
+#pragma nounroll
          for (int Lt = 0; Lt < NT; ++Lt) {
-            const Real *TrL = Tr + Lt * CStride;
-            T Tmp           = splat<T>(0.0);
+            const Real *TrL = uniformPtr(Tr + Lt * CStride);
+            T Tn[TME];
 #pragma unroll
-            for (int J = 0; J < MEMAX; ++J) {
-               if (J < N) {
-                  const T Grad = ldk<T>(TrL, L.C1[Le * ME + J], K, Kv) - ldk<T>(TrL, L.C0[Le * ME + J], K, Kv);
-                  Tmp -= L.D2T[Le * ME + J] * HMeanJ[J] * Grad;
-               }
+            for (int J = 0; J < TME; ++J)
+               Tn[J] = ldo<T>(TrL, OffN[J]);
+            const T Ts = ldo<T>(TrL, OffS);
+            T Tmp      = splat<T>(0.0);
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               // Fast: the staged coefficient carries the orientation, (T1-T0) == +-(Tn-Ts) exactly
+               const T Grad = Fast ? T(Tn[J] - Ts) : T(pick(IsC0[J], Tn[J], Ts) - pick(IsC0[J], Ts, Tn[J]));
+               Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
             }
-            stk<T>(Del2Tr + Lt * CStride, ICell, K, Kv, Tmp * InvA);
+            sto<T>(uniformPtr(Del2Tr + Lt * CStride), OffS, Tmp * InvA);
          }
       }
    }
@@ -378,9 +439,175 @@ struct FusedEdgeBody {
 };
 
 // ---------------------------------------------------------------------------------------
+// L3 edge pass: every velocity term (TendencyTerms.h:81-334) in registers.  The edge-located
+// inputs of PotentialVortHAdvOnEdge at each EdgesOnEdge neighbour (FluxLayerThickEdge,
+// NormRelVortEdge, NormPlanetVortEdge) are rebuilt from h at its two cells and the normalised
+// vorticities at its two vertices (LayerThicknessAuxVars.h:25-61, VorticityAuxVars.h:61-76);
+// SshCell from h - BottomDepth (LayerThicknessAuxVars.h:63-82).
+//
+// The stencil is walked in chain form (HorzMesh.h PVChain*): the other edges of each of the two
+// cells of the edge, in EdgesOnEdge order, share end vertices with their successors and all have
+// that cell as one of their two cells, so per side only the chain's vertices and the far cells
+// are gathered (a+b == b+a exactly, so which end vertex / cell comes first does not matter for
+// the means; the upwind choice keeps its flag).
+template <int TME, bool Fast> struct FusedEdgeChainBody {
+   static constexpr int MinWaves = OMEGA_EDGE_MINW;
+   static constexpr int MaxW     = OMEGA_EDGE_MAXW;
+   static constexpr int TM1      = TME - 1;
+   MeshView M;
+   int K;
+   TendParams P;
+   const Real *H, *U;
+   const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
+   Real *Tend;
+   struct Lds {
+      Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
+      int *ChV, *ChF, *ChE, *C0, *C1, *V0, *V1;
+   };
+   size_t ldsBytes(int Tile) const {
+      return ldsRound8(sizeof(Real) * Tile * 2 * TM1) + ldsRound8(sizeof(Real) * Tile) * 8 +
+             ldsRound8(sizeof(int) * Tile * 2 * TME) + ldsRound8(sizeof(int) * Tile * 2 * TM1) * 2 +
+             ldsRound8(sizeof(int) * Tile) * 4;
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.W        = C.take<Real>(Tile * 2 * TM1);
+      L.InvDc    = C.take<Real>(Tile);
+      L.InvDv    = C.take<Real>(Tile);
+      L.Mask     = C.take<Real>(Tile);
+      L.MaskGrav = C.take<Real>(Tile);
+      L.C2       = C.take<Real>(Tile);
+      L.C4       = C.take<Real>(Tile);
+      L.BD0      = C.take<Real>(Tile);
+      L.BD1      = C.take<Real>(Tile);
+      L.ChV      = C.take<int>(Tile * 2 * TME);
+      L.ChF      = C.take<int>(Tile * 2 * TM1);
+      L.ChE      = C.take<int>(Tile * 2 * TM1);
+      L.C0       = C.take<int>(Tile);
+      L.C1       = C.take<int>(Tile);
+      L.V0       = C.take<int>(Tile);
+      L.V1       = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      const Real Grav = 9.80665; // TendencyTerms.h:176
+      for (int I = Tid; I < Cnt * 2 * TM1; I += NThr) {
+         const size_t G = (size_t)First * 2 * TM1 + I;
+         L.W[I]         = M.PVChainWeight[G];
+         L.ChF[I]       = M.PVChainFar[G];
+         L.ChE[I]       = M.PVChainEdge[G];
+      }
+      for (int I = Tid; I < Cnt * 2 * TME; I += NThr)
+         L.ChV[I] = M.PVChainVert[(size_t)First * 2 * TME + I];
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int E     = First + I;
+         const Real Mask = M.EdgeMask1D[E];
+         const int C0 = M.CellsOnEdge[2 * E], C1 = M.CellsOnEdge[2 * E + 1];
+         L.InvDc[I]    = M.InvDcEdge[E];
+         L.InvDv[I]    = M.InvDvEdge[E];
+         L.Mask[I]     = Mask;
+         L.MaskGrav[I] = Mask * Grav;
+         L.C2[I]       = Mask * P.ViscDel2 * M.MeshScalingDel2[E];
+         L.C4[I]       = Mask * P.ViscDel4 * M.MeshScalingDel4[E];
+         L.BD0[I]      = M.BottomDepth[C0];
+         L.BD1[I]      = M.BottomDepth[C1];
+         L.C0[I]       = C0;
+         L.C1[I]       = C1;
+         L.V0[I]       = M.VerticesOnEdge[2 * E];
+         L.V1[I]       = M.VerticesOnEdge[2 * E + 1];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int IEdge, int Kv) const {
+      const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
+      const bool PVOn = Fast ? true : (P.PVTendencyEnable != 0), KEOn = Fast ? true : (P.KETendencyEnable != 0);
+      const bool SSHOn = Fast ? true : (P.SSHTendencyEnable != 0), D2On = Fast ? true : (P.VelDiffTendencyEnable != 0);
+      const bool D4On   = Fast ? true : (P.VelHyperDiffTendencyEnable != 0);
+      const bool WindOn = Fast ? false : (P.WindForcingTendencyEnable != 0);
+      const bool DragOn = Fast ? false : (P.BottomDragTendencyEnable != 0);
+      const unsigned OffC0 = rowOff<T>(L.C0[Le], K, Kv), OffC1 = rowOff<T>(L.C1[Le], K, Kv);
+      const unsigned OffV0 = rowOff<T>(L.V0[Le], K, Kv), OffV1 = rowOff<T>(L.V1[Le], K, Kv);
+      const Real InvDc = L.InvDc[Le], InvDv = L.InvDv[Le];
+      const T H0 = ldo<T>(H, OffC0), H1 = ldo<T>(H, OffC1);
+      T TendV = splat<T>(0.0);
+      if (PVOn) {
+         // NormRelVortEdge / NormPlanetVortEdge of this edge (VorticityAuxVars.h:68-74)
+         const T QRe = 0.5 * (ldo<T>(NormRelVortV, OffV0) + ldo<T>(NormRelVortV, OffV1));
+         const T QFe = 0.5 * (ldo<T>(NormPlanetVortV, OffV0) + ldo<T>(NormPlanetVortV, OffV1));
+         T VortTmp   = splat<T>(0.0);
+#pragma unroll
+         for (int Sd = 0; Sd < 2; ++Sd) {
+            const T Hs    = Sd == 0 ? H0 : H1;
+            const int BV  = (Le * 2 + Sd) * TME, BM = (Le * 2 + Sd) * TM1;
+            T QR[TME], QF[TME], Uj[TM1], Hf[TM1];
+            bool First[TM1];
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const unsigned Off = rowOff<T>(L.ChV[BV + J], K, Kv);
+               QR[J]              = ldo<T>(NormRelVortV, Off);
+               QF[J]              = ldo<T>(NormPlanetVortV, Off);
+            }
+#pragma unroll
+            for (int J = 0; J < TM1; ++J) {
+               const int F = L.ChF[BM + J];
+               First[J]    = (F >> 30) != 0;
+               Uj[J]       = ldo<T>(U, rowOff<T>(L.ChE[BM + J], K, Kv));
+               Hf[J]       = ldo<T>(H, rowOff<T>(F & 0x3fffffff, K, Kv));
+            }
+#pragma unroll
+            for (int J = 0; J < TM1; ++J) {
+               T Flux = 0.5 * (Hs + Hf[J]);
+               if (FluxUpwind)
+                  Flux = upwind(Uj[J], pick(First[J], Hs, Hf[J]), pick(First[J], Hf[J], Hs));
+               const T QRj  = 0.5 * (QR[J] + QR[J + 1]);
+               const T QFj  = 0.5 * (QF[J] + QF[J + 1]);
+               const T NormVort = (QRe + QFe + QRj + QFj) * 0.5;
+               VortTmp += L.W[BM + J] * Flux * Uj[J] * NormVort;
+            }
+         }
+         TendV += L.Mask[Le] * VortTmp;
+      }
+      if (KEOn)
+         TendV -= L.Mask[Le] * (ldo<T>(KE, OffC1) - ldo<T>(KE, OffC0)) * InvDc;
+      if (SSHOn) {
+         const T Ssh0 = H0 - L.BD0[Le], Ssh1 = H1 - L.BD1[Le];
+         TendV -= L.MaskGrav[Le] * (Ssh1 - Ssh0) * InvDc;
+      }
+      if (D2On) {
+         const T Del2U = ((ldo<T>(Div, OffC1) - ldo<T>(Div, OffC0)) * InvDc -
+                          (ldo<T>(RelVort, OffV1) - ldo<T>(RelVort, OffV0)) * InvDv);
+         TendV += L.C2[Le] * Del2U;
+      }
+      if (D4On) {
+         const T Del2U = (P.DivFactor * (ldo<T>(Del2Div, OffC1) - ldo<T>(Del2Div, OffC0)) * InvDc -
+                          (ldo<T>(Del2RelVort, OffV1) - ldo<T>(Del2RelVort, OffV0)) * InvDv);
+         TendV -= L.C4[Le] * Del2U;
+      }
+      constexpr int W = VecW<T>::W;
+      if (WindOn && Kv == 0) {
+         const Real HMean0       = 0.5 * (getc(H0, 0) + getc(H1, 0));
+         const Real InvThickEdge = 1. / HMean0;
+         setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * NormalStress[IEdge] / P.Density0);
+      }
+      if (DragOn && (Kv + 1) * W >= K) {
+         const int KBot          = K - 1;
+         const int Comp          = KBot - Kv * W;
+         const Real VelNormEdge  = sqrt(KE[(size_t)L.C0[Le] * K + KBot] + KE[(size_t)L.C1[Le] * K + KBot]);
+         const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
+         const Real InvThickEdge = 1. / HMeanB;
+         setc(TendV, Comp,
+              getc(TendV, Comp) - L.Mask[Le] * P.BottomDragCoeff * VelNormEdge * InvThickEdge * U[(size_t)IEdge * K + KBot]);
+      }
+      sto<T>(Tend, rowOff<T>(IEdge, K, Kv), TendV);
+   }
+};
+
+// ---------------------------------------------------------------------------------------
 // L3 cell pass: tracer tendencies (TendencyTerms.h:349-480) with HTracersEdge
 // (TracerAuxVars.h:25-59) and MeanLayerThickEdge rebuilt inline; tracer loop inside.
-struct FusedCell3Body {
+template <int TME, bool Fast> struct FusedCell3Body {
+   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int MaxW     = OMEGA_CELL_MAXW;
    MeshView M;
    int K, NT;
    TendParams P;
@@ -388,123 +615,215 @@ struct FusedCell3Body {
    Real *Tend;
    struct Lds {
       Real *MDvS, *Df2, *Df4, *InvA;
-      int *Edge, *C0, *C1, *N;
+      int *Edge, *NbrF;
    };
    size_t ldsBytes(int Tile) const {
-      const int ME = M.MaxEdges;
-      return ldsRound8(sizeof(Real) * Tile * ME) * 3 + ldsRound8(sizeof(Real) * Tile) +
-             ldsRound8(sizeof(int) * Tile * ME) * 3 + ldsRound8(sizeof(int) * Tile);
+      return ldsRound8(sizeof(Real) * Tile * TME) * 3 + ldsRound8(sizeof(Real) * Tile) +
+             ldsRound8(sizeof(int) * Tile * TME) * 2;
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
-      const int ME = M.MaxEdges;
       LdsCarver C{Ptr};
       Lds L;
-      L.MDvS = C.take<Real>(Tile * ME);
-      L.Df2  = C.take<Real>(Tile * ME);
-      L.Df4  = C.take<Real>(Tile * ME);
+      L.MDvS = C.take<Real>(Tile * TME);
+      L.Df2  = C.take<Real>(Tile * TME);
+      L.Df4  = C.take<Real>(Tile * TME);
       L.InvA = C.take<Real>(Tile);
-      L.Edge = C.take<int>(Tile * ME);
-      L.C0   = C.take<int>(Tile * ME);
-      L.C1   = C.take<int>(Tile * ME);
-      L.N    = C.take<int>(Tile);
+      L.Edge = C.take<int>(Tile * TME);
+      L.NbrF = C.take<int>(Tile * TME);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
-      const int ME = M.MaxEdges;
-      for (int I = Tid; I < Cnt * ME; I += NThr) {
-         const size_t G = (size_t)First * ME + I;
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const size_t G = (size_t)First * TME + I;
          L.MDvS[I]      = M.MaskDvSignOnCell[G];
-         L.Df2[I]       = M.Diff2CoefOnCell[G];
-         L.Df4[I]       = M.Diff4CoefOnCell[G];
+         L.Df2[I]       = Fast ? M.Diff2CoefSOnCell[G] : M.Diff2CoefOnCell[G];
+         L.Df4[I]       = Fast ? M.Diff4CoefSOnCell[G] : M.Diff4CoefOnCell[G];
          L.Edge[I]      = M.EdgesOnCell[G];
-         L.C0[I]        = M.CellsOnEdgeOnCell[2 * G];
-         L.C1[I]        = M.CellsOnEdgeOnCell[2 * G + 1];
+         L.NbrF[I]      = M.NbrFlagOnCell[G];
       }
-      for (int I = Tid; I < Cnt; I += NThr) {
-         L.N[I]    = M.NEdgesOnCell[First + I];
+      for (int I = Tid; I < Cnt; I += NThr)
          L.InvA[I] = M.InvAreaCell[First + I];
-      }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
-      const int ME    = M.MaxEdges;
-      const int N     = L.N[Le];
-      const Real InvA = L.InvA[Le];
-      T UJ[MEMAX], H0J[MEMAX], H1J[MEMAX];
+      const bool TrUpwind = Fast ? false : (P.FluxTracerUpwind != 0);
+      const bool AdvOn = Fast ? true : (P.TracerHorzAdvTendencyEnable != 0);
+      const bool DiffOn = Fast ? true : (P.TracerDiffTendencyEnable != 0);
+      const bool HypOn  = Fast ? true : (P.TracerHyperDiffTendencyEnable != 0);
+      const Real InvA     = L.InvA[Le];
+      const unsigned OffS = rowOff<T>(ICell, K, Kv);
+      unsigned OffN[TME];
+      bool IsC0[TME];
+      T UJ[TME], Hn[TME];
 #pragma unroll
-      for (int J = 0; J < MEMAX; ++J) {
-         UJ[J] = H0J[J] = H1J[J] = splat<T>(0.0);
-         if (J < N) {
-            UJ[J]  = ldk<T>(U, L.Edge[Le * ME + J], K, Kv);
-            H0J[J] = ldk<T>(H, L.C0[Le * ME + J], K, Kv);
-            H1J[J] = ldk<T>(H, L.C1[Le * ME + J], K, Kv);
-         }
+      for (int J = 0; J < TME; ++J) {
+         const int F = L.NbrF[Le * TME + J];
+         OffN[J]     = rowOff<T>(F & 0x3fffffff, K, Kv);
+         IsC0[J]     = (F >> 30) != 0;
+         UJ[J]       = ldo<T>(U, rowOff<T>(L.Edge[Le * TME + J], K, Kv));
+         Hn[J]       = ldo<T>(H, OffN[J]);
       }
+      const T Hs = ldo<T>(H, OffS);
       const size_t CStride = (size_t)M.NCellsSize * K;
+#pragma nounroll
       for (int Lt = 0; Lt < NT; ++Lt) {
-         const Real *TrL = Tr + Lt * CStride;
-         const Real *D2L = Del2Tr + Lt * CStride;
-         T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
+         const Real *TrL = uniformPtr(Tr + Lt * CStride);
+         const Real *D2L = uniformPtr(Del2Tr + Lt * CStride);
+         T Tn[TME], Dn[TME];
 #pragma unroll
-         for (int J = 0; J < MEMAX; ++J) {
-            if (J < N) {
-               const int I   = Le * ME + J;
-               const int JC0 = L.C0[I], JC1 = L.C1[I];
-               const T T0 = ldk<T>(TrL, JC0, K, Kv), T1 = ldk<T>(TrL, JC1, K, Kv);
-               if (P.TracerHorzAdvTendencyEnable) {
-                  const T HT0 = H0J[J] * T0, HT1 = H1J[J] * T1;
-                  const T HTr = P.FluxTracerUpwind ? upwind(UJ[J], HT0, HT1) : T(0.5 * (HT0 + HT1));
+         for (int J = 0; J < TME; ++J) {
+            Tn[J] = ldo<T>(TrL, OffN[J]);
+            Dn[J] = HypOn ? ldo<T>(D2L, OffN[J]) : splat<T>(0.0);
+         }
+         const T Ts = ldo<T>(TrL, OffS);
+         const T Ds = HypOn ? ldo<T>(D2L, OffS) : splat<T>(0.0);
+         T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
+         if (Fast) {
+            // center fluxes: h(c0)*tr(c0) + h(c1)*tr(c1) and h(c0)+h(c1) do not depend on which
+            // of the two cells is "this" one (a+b == b+a), and the staged diffusion coefficients
+            // carry the orientation of (T1-T0) = +-(Tn-Ts)
+            const T HsTs = Hs * Ts;
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const int I  = Le * TME + J;
+               const T HTr  = 0.5 * (HsTs + Hn[J] * Tn[J]);
+               HAdvTmp -= L.MDvS[I] * HTr * UJ[J] * InvA;
+               const T Mean = 0.5 * (Hs + Hn[J]);
+               DiffTmp -= L.Df2[I] * Mean * (Tn[J] - Ts);
+               HypTmp -= L.Df4[I] * (Dn[J] - Ds);
+            }
+         } else {
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const int I = Le * TME + J;
+               const T H0 = pick(IsC0[J], Hs, Hn[J]), H1 = pick(IsC0[J], Hn[J], Hs);
+               const T T0 = pick(IsC0[J], Ts, Tn[J]), T1 = pick(IsC0[J], Tn[J], Ts);
+               if (AdvOn) {
+                  const T HT0 = H0 * T0, HT1 = H1 * T1;
+                  const T HTr = TrUpwind ? upwind(UJ[J], HT0, HT1) : T(0.5 * (HT0 + HT1));
                   HAdvTmp -= L.MDvS[I] * HTr * UJ[J] * InvA;
                }
-               if (P.TracerDiffTendencyEnable) {
-                  const T Mean = 0.5 * (H0J[J] + H1J[J]);
+               if (DiffOn) {
+                  const T Mean = 0.5 * (H0 + H1);
                   DiffTmp -= L.Df2[I] * Mean * (T1 - T0);
                }
-               if (P.TracerHyperDiffTendencyEnable)
-                  HypTmp -= L.Df4[I] * (ldk<T>(D2L, JC1, K, Kv) - ldk<T>(D2L, JC0, K, Kv));
+               if (HypOn) {
+                  const T D0 = pick(IsC0[J], Ds, Dn[J]), D1 = pick(IsC0[J], Dn[J], Ds);
+                  HypTmp -= L.Df4[I] * (D1 - D0);
+               }
             }
          }
          T TendV = splat<T>(0.0);
-         if (P.TracerHorzAdvTendencyEnable)
+         if (AdvOn)
             TendV -= HAdvTmp;
-         if (P.TracerDiffTendencyEnable)
+         if (DiffOn)
             TendV += P.EddyDiff2 * DiffTmp * InvA;
-         if (P.TracerHyperDiffTendencyEnable)
+         if (HypOn)
             TendV -= P.EddyDiff4 * HypTmp * InvA;
-         stk<T>(Tend + Lt * CStride, ICell, K, Kv, TendV);
+         sto<T>(uniformPtr(Tend + Lt * CStride), OffS, TendV);
       }
    }
 };
 
-// ---------------------------------------------------------------------------------------
-void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
-                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S) {
+const char *const FusedKernelNames[FusedNumKernels] = {"VortVertexBody(L1 vertex)", "FusedCell1Body(L1 cell)",
+                                                       "FusedDel2CellBody(L2 cell)", "FusedDel2VertexBody(L2 vertex)",
+                                                       "FusedEdgeBody(L3 edge)", "FusedCell3Body(L3 cell)"};
+
+/// Default.yml term set: every flag folds at compile time (see `Fast` above)
+static bool isDefaultTermSet(const TendParams &P) {
+   return P.ThicknessFluxTendencyEnable && P.PVTendencyEnable && P.KETendencyEnable && P.SSHTendencyEnable &&
+          P.VelDiffTendencyEnable && P.VelHyperDiffTendencyEnable && !P.WindForcingTendencyEnable &&
+          !P.BottomDragTendencyEnable && P.TracerHorzAdvTendencyEnable && P.TracerDiffTendencyEnable &&
+          P.TracerHyperDiffTendencyEnable && !P.FluxThicknessUpwind && !P.FluxTracerUpwind;
+}
+
+bool fusedRHSSupported(const MeshView &M, int K) {
+   const size_t MaxRows = (size_t)(M.NEdgesSize > M.NCellsSize ? M.NEdgesSize : M.NCellsSize);
+   const size_t Rows    = MaxRows > (size_t)M.NVerticesSize ? MaxRows : (size_t)M.NVerticesSize;
+   return M.MaxEdges >= 5 && M.MaxEdges <= 8 && Rows * (size_t)K * 8 < ((size_t)1 << 32);
+}
+
+template <int TME, bool Fast>
+static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
+                         Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
+                         hipEvent_t *Ev) {
+   auto Mark = [&](int I) {
+      if (Ev)
+         (void)hipEventRecord(Ev[I], S);
+   };
    // L1
+   Mark(0);
    launchVertexAuxState1(M, K, A, H, U, S);
+   Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    {
-      FusedCell1Body B{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell};
+      FusedCell1Body<TME, Fast> B{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend,
+                                  A.Del2TracersCell};
       launchTile(B, M.NCellsAll, K, S);
    }
    if (P.WindForcingTendencyEnable)
       launchEdgeAuxState1(M, A, P.WindInterpIsotropic, S);
    // L2 (only the del4 term consumes it)
+   Mark(2);
    if (P.VelHyperDiffTendencyEnable) {
       FusedDel2CellBody BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
       launchTile(BC, M.NCellsAll, K, S);
+   }
+   Mark(3);
+   if (P.VelHyperDiffTendencyEnable) {
       FusedDel2VertexBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
       launchTile(BV, M.NVerticesAll, K, S);
    }
    // L3
-   {
+   Mark(4);
+   if (M.PVChainOK) {
+      FusedEdgeChainBody<TME, Fast> B{M,
+                                      K,
+                                      P,
+                                      H,
+                                      U,
+                                      A.RelVortVertex,
+                                      A.NormRelVortVertex,
+                                      A.NormPlanetVortVertex,
+                                      A.KineticEnergyCell,
+                                      A.VelocityDivCell,
+                                      A.Del2DivCell,
+                                      A.Del2RelVortVertex,
+                                      A.NormalStressEdge,
+                                      UTend};
+      launchTile(B, M.NEdgesAll, K, S);
+   } else {
       FusedEdgeBody B{M,       K,           P,           H,           U,
                       A.RelVortVertex, A.NormRelVortVertex, A.NormPlanetVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
                       A.Del2DivCell,   A.Del2RelVortVertex, A.NormalStressEdge,     UTend};
       launchTile(B, M.NEdgesAll, K, S);
    }
+   Mark(5);
    if (NT > 0) {
-      FusedCell3Body B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
+      FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
       launchTile(B, M.NCellsAll, K, S);
    }
+   Mark(6);
+}
+
+void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
+                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S, hipEvent_t *Ev) {
+   const bool Fast = isDefaultTermSet(P);
+#define OMEGA_CASE(ME_)                                                                                            \
+   case ME_:                                                                                                       \
+      if (Fast)                                                                                                    \
+         launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev);                           \
+      else                                                                                                         \
+         launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev);                          \
+      break;
+   switch (M.MaxEdges) {
+      OMEGA_CASE(5)
+      OMEGA_CASE(6)
+      OMEGA_CASE(7)
+      OMEGA_CASE(8)
+   default:
+      break; // callers check fusedRHSSupported()
+   }
+#undef OMEGA_CASE
 }
 
 } // namespace OMEGA

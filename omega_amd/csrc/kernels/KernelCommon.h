@@ -98,9 +98,9 @@ struct Geom {
    int Tile; ///< elements per workgroup
    int W;    ///< levels per thread (1 or 2)
 };
-inline Geom makeGeom(int N, int K) {
+inline Geom makeGeom(int N, int K, int MaxW = 2) {
    Geom G;
-   G.W  = (K % 2 == 0) ? 2 : 1;
+   G.W  = (K % 2 == 0 && MaxW >= 2) ? 2 : 1;
    G.KV = K / G.W;
    int TX = G.KV < 64 ? G.KV : 64;
    int TY = 256 / TX;
@@ -116,7 +116,23 @@ inline Geom makeGeom(int N, int K) {
 }
 
 /// The generic tile kernel: stage -> barrier -> column sweeps.
-template <class Body, class T> __global__ void __launch_bounds__(256) tileKernel(Body B, int N, int KV, int Tile) {
+/// Bodies may define `static constexpr int MinWaves` (2nd __launch_bounds__ argument: minimum
+/// waves per SIMD, i.e. the VGPR budget) and `static constexpr int MaxW` (levels per thread).
+template <class B, class = void> struct BodyMinWaves {
+   static constexpr int V = 1;
+};
+template <class B> struct BodyMinWaves<B, decltype((void)B::MinWaves)> {
+   static constexpr int V = B::MinWaves;
+};
+template <class B, class = void> struct BodyMaxW {
+   static constexpr int V = 2;
+};
+template <class B> struct BodyMaxW<B, decltype((void)B::MaxW)> {
+   static constexpr int V = B::MaxW;
+};
+
+template <class Body, class T>
+__global__ void __launch_bounds__(256, BodyMinWaves<Body>::V) tileKernel(Body B, int N, int KV, int Tile) {
    extern __shared__ __align__(16) unsigned char Lds[];
    const int TileId = xcdRemap(blockIdx.x, gridDim.x);
    const int First  = TileId * Tile;
@@ -137,12 +153,15 @@ template <class Body, class T> __global__ void __launch_bounds__(256) tileKernel
 template <class Body> void launchTile(const Body &B, int N, int K, hipStream_t S) {
    if (N <= 0)
       return;
-   Geom G           = makeGeom(N, K);
+   Geom G           = makeGeom(N, K, BodyMaxW<Body>::V);
    const size_t Lds = B.ldsBytes(G.Tile);
-   if (G.W == 2)
-      hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
-   else
-      hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+   if constexpr (BodyMaxW<Body>::V >= 2) {
+      if (G.W == 2) {
+         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+         return;
+      }
+   }
+   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
 }
 
 } // namespace OMEGA

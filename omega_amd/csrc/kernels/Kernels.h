@@ -59,8 +59,15 @@ void launchTracerTendOnly(const MeshView &M, int K, int NT, const TendParams &P,
                           const Real *U, const Real *Tr, hipStream_t S);
 
 // ---- fused RHS (Tendencies::computeAllTendencies): see FusedKernels.hip ----
+/// Kernel order (also the index of the optional timing events, Ev[i] recorded BEFORE kernel i,
+/// Ev[6] after the last): 0 vertex L1, 1 cell L1, 2 cell L2, 3 vertex L2, 4 edge L3, 5 cell L3.
+constexpr int FusedNumKernels = 6;
+/// MaxEdges in [5,8] and every array plane < 4 GiB (32-bit byte offsets inside a plane)
+bool fusedRHSSupported(const MeshView &M, int K);
+extern const char *const FusedKernelNames[FusedNumKernels];
 void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
-                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S);
+                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
+                    hipEvent_t *Ev = nullptr);
 
 // ---- TimeStepper update kernels (TimeStepper.cpp:378-524) ----
 void launchUpdateByTend(int NRows, int K, Real *X1, const Real *X2, const Real *Tend, Real Coeff, hipStream_t S);

@@ -263,10 +263,35 @@ def synthetic_state(mesh: dict, nvertlayers: int, ntracers: int, seed: int = 202
         sC = np.cos(ax * mesh["xCell"]) * np.cos(ay * mesh["yCell"])
         ux = np.sin(ax * mesh["xEdge"]) * np.cos(ay * mesh["yEdge"])
         uy = np.cos(ax * mesh["xEdge"]) * np.sin(ay * mesh["yEdge"])
-    h = 2.0 + 0.5 * sC[:, None] * kfac + 0.1 * rng.uniform(-1, 1, (nC, K))
+    # noise is drawn in 8 fixed row-chunks, each from its own child stream of the seed, so the
+    # result does not depend on how many threads fill it
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=8)
+    NCH = 8
+
+    def fill(out, col_base, lev, amp, offset, stream_id):
+        """out[i,k] = offset + col_base[i]*lev[k] + amp*U(-1,1)"""
+        n = out.shape[0]
+        seeds = np.random.SeedSequence([seed, stream_id]).spawn(NCH)
+        bounds = np.linspace(0, n, NCH + 1).astype(np.int64)
+
+        def work(c):
+            lo, hi = bounds[c], bounds[c + 1]
+            blk = out[lo:hi]
+            np.random.default_rng(seeds[c]).random(out=blk)
+            blk *= 2.0 * amp
+            blk += offset - amp
+            blk += col_base[lo:hi, None] * lev
+        list(pool.map(work, range(NCH)))
+
+    lev = kfac[0]
+    h = np.empty((nC, K))
+    fill(h, 0.5 * sC, lev, 0.1, 2.0, 0)
     un = np.cos(mesh["angleEdge"]) * ux + np.sin(mesh["angleEdge"]) * uy
-    u = un[:, None] * kfac + 0.01 * rng.uniform(-1, 1, (nE, K))
+    u = np.empty((nE, K))
+    fill(u, un, lev, 0.01, 0.0, 1)
     tr = np.empty((max(ntracers, 1), nC, K))
     for l in range(max(ntracers, 1)):
-        tr[l] = 2.0 - sC[:, None] * kfac + 0.1 * l + 0.05 * rng.uniform(-1, 1, (nC, K))
+        fill(tr[l], -sC, lev, 0.05, 2.0 + 0.1 * l, 2 + l)
+    pool.shutdown()
     return h, u, tr
