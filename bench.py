@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--block", type=int, default=16, help="cell-ordering block size of the synthetic mesh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the reference-structured launch sequence instead")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production); gloo = host-staged rehearsal of the N>1 code path")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,8 +86,13 @@ def main():
     if N > 1:
         import torch
         import torch.distributed as dist
+        if args.single_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     oa.device_init(local_rank)
 
     t0 = time.time()
@@ -108,11 +116,15 @@ def main():
     tr = to_local(trg, cell_id, mesh.NCellsSize)
     del hg, ug, trg
 
-    if N > 1:
+    if N > 1 and args.backend == "nccl":
         tstream = torch.cuda.Stream()
         stream = oa.Stream(handle=tstream.cuda_stream)
         from omega_amd.transport import TorchTransport
         transport = TorchTransport(halo, per_cell=K * (1 + NT), per_edge=K, device=f"cuda:{local_rank}", stream=tstream)
+    elif N > 1:  # gloo rehearsal: host-staged messages, default stream (torch's .cpu() orders on it)
+        stream = None
+        from omega_amd.transport import TorchTransport
+        transport = TorchTransport(halo, per_cell=K * (1 + NT), per_edge=K, device=f"cuda:{local_rank}", stream=None)
     else:
         stream = oa.Stream()
 
@@ -135,7 +147,7 @@ def main():
     def allmax(x):
         if N == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -229,7 +241,11 @@ def cpu_baseline(K, NT, dc):
         out[..., :-1, :] = a
         return out
     hs, us, trs = pad(hs), pad(us), pad(trs)
-    cores = min(os.cpu_count() or 1, 64)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # a one-GPU box's CPU share is 16 cores
     O.lib().orc_set_num_threads(cores)
     orc = O.Oracle(M, NT)
     orc.compute_all_tendencies(hs, us, trs)  # warm-up

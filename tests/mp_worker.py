@@ -1,0 +1,150 @@
+"""One rank of a multi-rank test (launched by tests/test_multirank_*.py as a child process).
+
+mode cpu: Decomp + Halo exchange lists from the product's HOST code (no device), the
+          arithmetic by the CPU oracle, messages over gloo.  Checks (a) HaloTest-style
+          exchange of global-ID arrays (reference test/base/HaloTest.cpp:41-100) and (b) two
+          RK4 steps of the partitioned run against the single-rank oracle on owned elements.
+mode gpu: the full product path on the GPU -- C++ Halo::exchange* with HIP pack/unpack kernels,
+          RungeKutta4Stepper::doStep -- with the messages staged through gloo (both ranks may
+          share one GPU), against the same single-rank oracle.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["cpu", "gpu"], required=True)
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--nx", type=int, default=16)
+    ap.add_argument("--ny", type=int, default=16)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--tracers", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--stepper", default="RungeKutta4")
+    ap.add_argument("--halo-width", type=int, default=3)
+    ap.add_argument("--no-del4", action="store_true", help="disable the two radius-2 (del4) terms")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
+    dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+
+    import omega_amd as oa
+    from omega_amd.meshgen import planar_hex, synthetic_state
+    from oracle import oracle as O
+    from tests.problem import Problem
+
+    g = planar_hex(a.nx, a.ny, 30.0e3)
+    K, NT, dt = a.levels, a.tracers, 600.0
+    gpu = a.mode == "gpu"
+    if gpu:
+        oa.device_init(0)
+    cfg = {"VelHyperDiffTendencyEnable": 0, "TracerHyperDiffTendencyEnable": 0} if a.no_del4 else {}
+    P = Problem(g, K, NT, nparts=a.world, rank=a.rank, device=gpu, config=cfg, halo_width=a.halo_width)
+    m = P.mesh
+    halo = P.halo if gpu else oa.Halo(P.decomp)
+    nbrs = halo.neighbors
+    ids = {0: P.cell_id, 1: P.edge_id, 2: P.vertex_id}
+    owned = {0: m.NCellsOwned, 1: m.NEdgesOwned, 2: m.NVerticesOwned}
+    nall = {0: m.NCellsAll, 1: m.NEdgesAll, 2: m.NVerticesAll}
+    sizes = {0: m.NCellsSize, 1: m.NEdgesSize, 2: m.NVerticesSize}
+
+    # ---------------- host exchange over gloo using the product's lists (cpu mode) ----------------
+    def host_exchange(arr, elem):
+        """arr: [rows, K] or [NT, rows, K] numpy, in place."""
+        a3 = arr if arr.ndim == 3 else arr[None]
+        ops, recvs = [], []
+        for i, t in enumerate(nbrs):
+            sl, rl = halo.get_list(i, elem, False), halo.get_list(i, elem, True)
+            sb = torch.from_numpy(np.ascontiguousarray(a3[:, sl, :]))
+            rb = torch.empty((a3.shape[0], len(rl), a3.shape[2]), dtype=torch.float64)
+            recvs.append((rl, rb))
+            if rb.numel():
+                ops.append(dist.P2POp(dist.irecv, rb, t))
+            if sb.numel():
+                ops.append(dist.P2POp(dist.isend, sb, t))
+        for r in dist.batch_isend_irecv(ops) if ops else []:
+            r.wait()
+        for rl, rb in recvs:
+            a3[:, rl, :] = rb.numpy()
+
+    if gpu:
+        from omega_amd.transport import TorchTransport
+        TorchTransport(halo, per_cell=max(K * (1 + NT), 3 * K), per_edge=3 * K, per_vertex=3 * K, device="cuda:0")
+
+    # ---------------- (a) HaloTest: global ids on owned, garbage on halo, exchange, compare ----------------
+    for elem in (0, 1, 2):
+        for nt in (1, 3):
+            ref = np.zeros((nt, sizes[elem], K))
+            for t in range(nt):
+                ref[t, : nall[elem], :] = (ids[elem][: nall[elem], None] * 10.0 + t) + 0.001 * np.arange(K)[None, :]
+            arr = ref.copy()
+            arr[:, owned[elem]: nall[elem], :] = -999.0
+            if gpu:
+                import ctypes as C
+                t_dev = torch.from_numpy(arr).to("cuda:0")
+                torch.cuda.synchronize()
+                halo.exchange(t_dev.data_ptr(), nt, sizes[elem], K, elem)
+                torch.cuda.synchronize()
+                arr = t_dev.cpu().numpy()
+            else:
+                host_exchange(arr if nt > 1 else arr[0], elem)
+            assert np.array_equal(arr, ref), f"rank {a.rank}: halo exchange mismatch elem {elem} nt {nt}"
+
+    # ---------------- (b) time stepping: partitioned run vs single-rank oracle ----------------
+    okind = {"RungeKutta4": "rk4", "RungeKutta2": "rk2", "Forward-Backward": "fb"}[a.stepper]
+    Mg = O.Mesh.single_rank(g, K)
+    og = O.Oracle(Mg, NT, O.default_config(**cfg))
+    hg, ug, trg = synthetic_state(g, K, NT)
+
+    def pad(x):
+        out = np.zeros(x.shape[:-2] + (x.shape[-2] + 1, x.shape[-1]))
+        out[..., :-1, :] = x
+        return out
+    stg = og.make_state(pad(hg), pad(ug), pad(trg))
+    for _ in range(a.steps):
+        og.step(okind, stg, dt)
+
+    if gpu:
+        st = oa.TimeStepper(a.stepper, dt, P.tend, P.aux, P.mesh, halo, P.tracers)
+        for _ in range(a.steps):
+            st.do_step(P.state)
+        oa.device_synchronize()
+        h, u = P.state.copy_to_host(0)
+        tr = P.tracers.copy_to_host(0)
+    else:
+        stl = P.oracle.make_state(P.h, P.u, P.tr)
+
+        def ex(hh, uu, tt):
+            host_exchange(hh, 0)
+            host_exchange(uu, 1)
+            host_exchange(tt, 0)
+        for _ in range(a.steps):
+            P.oracle.step(okind, stl, dt, exchange=ex)
+        h, u, tr = stl["h"][0], stl["u"][0], stl["tr"][0]
+
+    nc, ne = m.NCellsOwned, m.NEdgesOwned
+    gh = stg["h"][0][P.cell_id[:nc] - 1]
+    gu = stg["u"][0][P.edge_id[:ne] - 1]
+    gtr = stg["tr"][0][:, P.cell_id[:nc] - 1]
+    assert np.isfinite(gh).all() and np.isfinite(gu).all()
+    assert np.array_equal(h[:nc], gh), f"rank {a.rank}: h differs from the single-rank run (max {np.abs(h[:nc]-gh).max()})"
+    assert np.array_equal(u[:ne], gu), f"rank {a.rank}: u differs from the single-rank run (max {np.abs(u[:ne]-gu).max()})"
+    assert np.array_equal(tr[:NT, :nc], gtr[:NT]), f"rank {a.rank}: tracers differ from the single-rank run"
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {a.rank}/{a.world} OK ({a.mode}, {a.stepper}, {len(nbrs)} neighbours)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+"""2-rank run of the full product path on the GPU: C++ Decomp / Halo with HIP pack / unpack
+kernels, RungeKutta4Stepper::doStep with its two exchange points, one process per rank, both on
+GPU 0 (this pool's test boxes have one GPU), messages staged through gloo (omega_amd/transport.py
+test mode).  Must reproduce the single-rank CPU oracle bit for bit on owned elements.
+
+File name sorts first on purpose: the ranks are child processes, and this pool forbids starting
+a new program from a process that has already initialised the GPU -- so it runs before the
+in-process GPU tests touch the device.
+"""
+import pytest
+
+from tests.test_multirank_cpu import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [
+    ["--no-del4"],
+    ["--halo-width", 4, "--nx", 24, "--ny", 24, "--levels", 6],
+    ["--no-del4", "--stepper", "Forward-Backward", "--levels", 5, "--tracers", 1],
+])
+def test_two_ranks_one_gpu(extra):
+    outs = run_ranks("gpu", 2, extra, timeout=900)
+    assert all("OK" in o for o in outs)

@@ -1,0 +1,79 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/omega_amd.h
+declares; host-only entry points work without a device; device entry points fail loudly
+(non-zero + message), never fall back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import omega_amd as oa
+from omega_amd.meshgen import planar_hex
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "omega_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(omg_[a-z0-9_]+)\s*\(", src))
+    names.discard("omg_transport_fn")
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported():
+    L = oa.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 70
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, f"declared in include/omega_amd.h but not exported: {missing}"
+
+
+def test_oracle_is_not_linked_into_the_product():
+    """The product library must not depend on the oracle (test infrastructure)."""
+    import subprocess
+    out = subprocess.run(["ldd", oa.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    nm = subprocess.run(["nm", "-D", oa.LIB_PATH], capture_output=True, text=True).stdout
+    assert " orc_" not in nm
+
+
+def test_host_only_objects_and_loud_device_failures():
+    g = planar_hex(8, 8, 1.0)
+    gm = oa.GlobalMesh(g)
+    d = oa.Decomp(gm, 1, 0, 3)
+    m = oa.HorzMesh(d, 4, host_only=True)
+    assert m.NCellsAll == 64 and m.NEdgesAll == 192 and m.NVerticesAll == 128
+    em = m.get_array("EdgeMask")
+    assert em.shape == (193, 4) and np.all(em == 1.0)
+    # compute objects need device arrays: must fail with a message, not silently run on the CPU
+    with pytest.raises(oa.OmegaAmdError, match="host-only"):
+        oa.OceanState(m, None, 4, 2)
+    with pytest.raises(oa.OmegaAmdError, match="host-only"):
+        oa.Tendencies(m, 4, 1)
+    if oa.device_count() == 0:
+        with pytest.raises(oa.OmegaAmdError):
+            oa.device_init(0)
+        with pytest.raises(oa.OmegaAmdError):
+            oa.HorzMesh(d, 4)  # device mirrors cannot be allocated without a GPU
+
+
+def test_bad_arguments_return_errors():
+    g = planar_hex(8, 8, 1.0)
+    gm = oa.GlobalMesh(g)
+    with pytest.raises(oa.OmegaAmdError):
+        oa.Decomp(gm, 2, 5, 3)          # task out of range
+    with pytest.raises(oa.OmegaAmdError):
+        oa.Decomp(gm, 1, 0, 0)          # halo width must be >= 1
+    d = oa.Decomp(gm, 1, 0, 3)
+    with pytest.raises(oa.OmegaAmdError, match="no integer member"):
+        d.get_int("NoSuchThing")
+    assert oa.coeff_seconds(1. / 3, 600.0) == 200.0  # TimeMgr integer-fraction arithmetic
+
+
+def test_time_stepper_coefficients_match_oracle():
+    from oracle import oracle as O
+    for mult in (1. / 6, 1. / 3, 0.5, 1.0):
+        for dt in (600.0, 0.2, 0.1, 37.5, 1800.0):
+            assert oa.coeff_seconds(mult, dt) == O.coeff_seconds(mult, dt)
