@@ -59,6 +59,32 @@ struct MeshView {
    const I4 *PVChainFar;           // [E][2][ME-1]
    const I4 *PVChainEdge;          // [E][2][ME-1]
    const Real *PVChainWeight;      // [E][2][ME-1]
+   // ---- cell-centric form of the PV stencil (valid when CellPVOK; HorzMesh::buildCellPV) ----
+   // A "regular" edge has EdgeMask 1 and two MaxEdges-gons as cells.  For such an edge the side-s
+   // part of the PotentialVortHAdvOnEdge sum only needs data on the ring of cell s (its edges,
+   // neighbour cells and vertices), so one thread per cell can produce the side sums of all its
+   // edges from 4*MaxEdges+1 gathers.  Side 0 sums start from zero, side 1 sums continue from the
+   // stored side 0 value: the additions happen in the reference's order.
+   I4 CellPVOK, NIrregularEdges;
+   const I4 *RingVertOnCell;       // [C][ME] vertex shared by edge slots k and k+1 (cyclic)
+   const I4 *PVRoleOnCell;         // [C][ME] 0 none, 1 this cell is cell 0 of a regular edge, 2 cell 1
+   const Real *PVWeightOnCell;     // [C][ME][ME-1] WeightsOnEdge of edge slot k, this cell's side, in walk order
+   const I4 *EdgeRegular;          // [E] 1 regular, 0 handled by the edge-centric kernel
+   const I4 *IrregularEdges;       // [NIrregularEdges]
+   // ---- LDS patches (HorzMesh::buildPatches): consecutive target elements grouped into patches;
+   // per patch the UNIQUE rows its stencils reference, and per target element the stencil
+   // re-expressed as indices into those lists, so a workgroup stages each row once in LDS ----
+   // edge patches (PotentialVortHAdvOnEdge stencil): lists of cells, vertices, edges
+   I4 EPSize, EPCount, EPMaxC, EPMaxV, EPMaxE, EPLocStride;
+   const I4 *EPListOff;            // [EPCount][4] start of the cell / vertex / edge list, end
+   const I4 *EPList;               // concatenated lists (local mesh indices)
+   const unsigned short *EPLocal;  // [EPCount*EPSize][EPLocStride]: c0, c1, ChV[2][ME], ChF[2][ME-1]
+                                   //   (bit 15 = side cell is first), ChE[2][ME-1], v0, v1
+   // cell patches (tracer stencils): list of cells (own cells first), neighbour slots
+   I4 CPSize, CPCount, CPMaxC;
+   const I4 *CPListOff;            // [CPCount][2] start, end
+   const I4 *CPList;
+   const unsigned short *CPLocal;  // [CPCount*CPSize][ME] local index of the cell across slot j
 };
 
 class HorzMesh {
@@ -120,6 +146,15 @@ class HorzMesh {
    Array2DI4 NbrFlagOnCell;
    DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;
    Array3DReal PVChainWeight;
+   Array1DI4 EPListOff, EPList, CPListOff, CPList;
+   DeviceArray<unsigned short, 1> EPLocal, CPLocal;
+   void buildPatches();
+   void buildCellPV();
+   Array2DI4 RingVertOnCell, PVRoleOnCell;
+   Array3DReal PVWeightOnCell;
+   Array1DI4 EdgeRegular, IrregularEdges;
+   HostArrayI4 HostChV, HostChF, HostChE, HostNbrF;
+   HostArrayReal HostChW;
 };
 
 } // namespace OMEGA

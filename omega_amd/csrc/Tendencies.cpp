@@ -105,6 +105,8 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
       OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 &&
                         State->getNormalVelocity(NormVel, VelLvl) == 0,
                     "Tendencies: bad time level");
+      if (!EdgeScratch.Ptr)
+         EdgeScratch = Array2DReal("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
       hipEvent_t *Ev = nullptr;
       if (TimingOn && TimingEvents.size() < 4096) {
          TimingEvents.emplace_back(FusedNumKernels + 1);
@@ -113,7 +115,8 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
          Ev = TimingEvents.back().data();
       }
       launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
-                     NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev);
+                     NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
+                     EdgeScratch.Ptr);
       return;
    }
    Aux->computeAll(State, TracerArray, ThickLvl, VelLvl, S);

@@ -53,6 +53,7 @@ class Tendencies {
    int NVertLayers, NTracers;
 
  private:
+   Array2DReal EdgeScratch; ///< running PV sums of the fused RHS (allocated on first use)
    bool TimingOn = false;
    std::vector<std::vector<hipEvent_t>> TimingEvents;
    /// AuxiliaryState options are read by AuxiliaryState::readConfigOptions in the reference;

@@ -312,6 +312,17 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                      {"NVerticesSize", M.NVerticesSize},   {"MaxEdges", M.MaxEdges},
                                      {"MaxEdges2", M.MaxEdges2},           {"VertexDegree", M.VertexDegree},
                                      {"NVertLayers", M.NVertLayers},       {"MaxCellsOnEdge", M.MaxCellsOnEdge}};
+   if (!M.HostOnly) { // kernel-side table statistics (diagnostics)
+      const MeshView &W = M.view();
+      const std::map<std::string, I4> D{{"PVChainOK", W.PVChainOK}, {"EPSize", W.EPSize},   {"EPCount", W.EPCount},
+                                        {"EPMaxC", W.EPMaxC},       {"EPMaxV", W.EPMaxV},   {"EPMaxE", W.EPMaxE},
+                                        {"CPSize", W.CPSize},       {"CPCount", W.CPCount}, {"CPMaxC", W.CPMaxC}};
+      auto Jt = D.find(name);
+      if (Jt != D.end()) {
+         *out = Jt->second;
+         return 0;
+      }
+   }
    auto It = V.find(name);
    if (It == V.end())
       OMEGA_ABORT(std::string("HorzMesh: no integer member named ") + name);

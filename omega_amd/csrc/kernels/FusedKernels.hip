@@ -19,6 +19,8 @@
 #include "KernelCommon.h"
 #include "Kernels.h"
 
+#include <cstdlib>
+
 // tuning knobs of the tracer cell kernels (VGPR budget / levels per thread)
 #ifndef OMEGA_CELL_MINW
 #define OMEGA_CELL_MINW 2
@@ -47,6 +49,15 @@ template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned B
 }
 template <class T> __device__ __forceinline__ void sto(Real *Base, unsigned ByteOff, T V) {
    *reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff) = V;
+}
+/// streaming store for outputs nobody re-reads inside the same kernel: keeps the XCD's L2 for the
+/// gathered inputs
+template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned ByteOff, T V) {
+#ifdef OMEGA_NO_NT_STORES
+   *reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff) = V;
+#else
+   __builtin_nontemporal_store(V, reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff));
+#endif
 }
 template <class T> __device__ __forceinline__ unsigned rowOff(int Row, int K, int Kv) {
    return ((unsigned)Row * (unsigned)K + (unsigned)Kv * (unsigned)VecW<T>::W) * 8u;
@@ -153,12 +164,12 @@ template <int TME, bool Fast> struct FusedCell1Body {
          DivTmp -= L.DivC[Le * TME + J] * Ue[J];
          HDivTmp -= L.DvS[Le * TME + J] * Flux * Ue[J] * InvA;
       }
-      sto<T>(KE, OffS, KETmp);
-      sto<T>(Div, OffS, DivTmp);
+      stnt<T>(KE, OffS, KETmp);
+      stnt<T>(Div, OffS, DivTmp);
       T HT = splat<T>(0.0);
       if (ThickOn)
          HT -= HDivTmp;
-      sto<T>(HTend, OffS, HT);
+      stnt<T>(HTend, OffS, HT);
       if (DoDel2Tr) {
          const size_t CStride = (size_t)M.NCellsSize * K;
 #pragma nounroll
@@ -176,7 +187,7 @@ template <int TME, bool Fast> struct FusedCell1Body {
                const T Grad = Fast ? T(Tn[J] - Ts) : T(pick(IsC0[J], Tn[J], Ts) - pick(IsC0[J], Ts, Tn[J]));
                Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
             }
-            sto<T>(uniformPtr(Del2Tr + Lt * CStride), OffS, Tmp * InvA);
+            stnt<T>(uniformPtr(Del2Tr + Lt * CStride), OffS, Tmp * InvA);
          }
       }
    }
@@ -460,6 +471,8 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
    const Real *H, *U;
    const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
    Real *Tend;
+   const I4 *EdgeList = nullptr; ///< if set, element i of the sweep is edge EdgeList[i]
+   __device__ int edgeOf(int I) const { return EdgeList ? EdgeList[I] : I; }
    struct Lds {
       Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
       int *ChV, *ChF, *ChE, *C0, *C1, *V0, *V1;
@@ -493,15 +506,18 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       const Real Grav = 9.80665; // TendencyTerms.h:176
       for (int I = Tid; I < Cnt * 2 * TM1; I += NThr) {
-         const size_t G = (size_t)First * 2 * TM1 + I;
+         const int Ei   = I / (2 * TM1);
+         const size_t G = (size_t)edgeOf(First + Ei) * 2 * TM1 + (I - Ei * 2 * TM1);
          L.W[I]         = M.PVChainWeight[G];
          L.ChF[I]       = M.PVChainFar[G];
          L.ChE[I]       = M.PVChainEdge[G];
       }
-      for (int I = Tid; I < Cnt * 2 * TME; I += NThr)
-         L.ChV[I] = M.PVChainVert[(size_t)First * 2 * TME + I];
+      for (int I = Tid; I < Cnt * 2 * TME; I += NThr) {
+         const int Ei = I / (2 * TME);
+         L.ChV[I]     = M.PVChainVert[(size_t)edgeOf(First + Ei) * 2 * TME + (I - Ei * 2 * TME)];
+      }
       for (int I = Tid; I < Cnt; I += NThr) {
-         const int E     = First + I;
+         const int E     = edgeOf(First + I);
          const Real Mask = M.EdgeMask1D[E];
          const int C0 = M.CellsOnEdge[2 * E], C1 = M.CellsOnEdge[2 * E + 1];
          L.InvDc[I]    = M.InvDcEdge[E];
@@ -518,7 +534,8 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
          L.V1[I]       = M.VerticesOnEdge[2 * E + 1];
       }
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int IEdge, int Kv) const {
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      const int IEdge       = edgeOf(IElem);
       const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
       const bool PVOn = Fast ? true : (P.PVTendencyEnable != 0), KEOn = Fast ? true : (P.KETendencyEnable != 0);
       const bool SSHOn = Fast ? true : (P.SSHTendencyEnable != 0), D2On = Fast ? true : (P.VelDiffTendencyEnable != 0);
@@ -601,6 +618,439 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
       sto<T>(Tend, rowOff<T>(IEdge, K, Kv), TendV);
    }
 };
+
+// ---------------------------------------------------------------------------------------
+// PotentialVortHAdvOnEdge (TendencyTerms.h:81-108), cell-centric.  For a regular edge (HorzMesh.h
+// CellPV) the reference's sum runs first over the other edges of cell 0, then over the other edges
+// of cell 1.  Everything the cell-s part needs lives on the ring of cell s, so a thread owning
+// (cell, levels) gathers the ring once -- u on its ME edges, h on its ME neighbours and itself,
+// NormRelVort / NormPlanetVort on its ME vertices: 4*ME+1 gathers -- and produces the partial sums
+// of ALL its edges (ME*(ME-1) terms), instead of 7..11 gathers per single term in the edge-centric
+// form.  Side = 0 launches first and stores the running sums; Side = 1 continues each sum from the
+// stored value, so the additions happen in exactly the reference's order.
+template <int TME, bool Fast, int Side> struct CellPVBody {
+   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int TM1      = TME - 1;
+   MeshView M;
+   int K;
+   TendParams P;
+   const Real *H, *U, *NormRelVortV, *NormPlanetVortV;
+   Real *Partial; // [NEdgesSize][K] running PV sums
+   struct Lds {
+      Real *Wt;
+      int *Edge, *NbrF, *Ring, *Role;
+   };
+   size_t ldsBytes(int Tile) const {
+      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(int) * Tile * TME) * 4;
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.Wt   = C.take<Real>(Tile * TME * TM1);
+      L.Edge = C.take<int>(Tile * TME);
+      L.NbrF = C.take<int>(Tile * TME);
+      L.Ring = C.take<int>(Tile * TME);
+      L.Role = C.take<int>(Tile * TME);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
+         L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const size_t G = (size_t)First * TME + I;
+         L.Edge[I]      = M.EdgesOnCell[G];
+         L.NbrF[I]      = M.NbrFlagOnCell[G];
+         L.Ring[I]      = M.RingVertOnCell[G];
+         L.Role[I]      = M.PVRoleOnCell[G];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+      const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
+      // does this cell own any side-`Side` sum?  (wave-uniform per column)
+      bool Any = false;
+#pragma unroll
+      for (int J = 0; J < TME; ++J)
+         Any |= L.Role[Le * TME + J] == Side + 1;
+      if (!Any)
+         return;
+      unsigned OffE[TME];
+      T Uj[TME], Flux[TME], QRe[TME], QFe[TME];
+      {
+         T Hn[TME], QR[TME], QF[TME];
+         bool IsC0[TME];
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            const int F = L.NbrF[Le * TME + J];
+            IsC0[J]     = (F >> 30) != 0;
+            OffE[J]     = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
+            Uj[J]       = ldo<T>(U, OffE[J]);
+            Hn[J]       = ldo<T>(H, rowOff<T>(F & 0x3fffffff, K, Kv));
+            const unsigned OffV = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
+            QR[J]               = ldo<T>(NormRelVortV, OffV);
+            QF[J]               = ldo<T>(NormPlanetVortV, OffV);
+         }
+         const T Hs = ldo<T>(H, rowOff<T>(ICell, K, Kv));
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            // FluxLayerThickEdge of edge slot J (LayerThicknessAuxVars.h:25-61)
+            Flux[J] = 0.5 * (Hs + Hn[J]);
+            if (FluxUpwind)
+               Flux[J] = upwind(Uj[J], pick(IsC0[J], Hs, Hn[J]), pick(IsC0[J], Hn[J], Hs));
+            // NormRelVortEdge / NormPlanetVortEdge of edge slot J: mean over its two end vertices,
+            // ring vertices J-1 and J (VorticityAuxVars.h:61-76)
+            constexpr int Dummy = 0;
+            (void)Dummy;
+            const int Jm = (J + TME - 1) % TME;
+            QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
+            QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
+         }
+      }
+#pragma unroll
+      for (int I = 0; I < TME; ++I) {
+         if (L.Role[Le * TME + I] != Side + 1)
+            continue;
+         T Acc = splat<T>(0.0);
+         if (Side == 1)
+            Acc = ldo<T>(Partial, OffE[I]);
+#pragma unroll
+         for (int J = 1; J < TME; ++J) {
+            const int Kk       = (I + J) % TME;
+            const T NormVort   = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
+            Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
+         }
+         sto<T>(Partial, OffE[I], Acc);
+      }
+   }
+};
+
+// L3 edge pass after the cell-centric PV sums: the remaining velocity terms for regular edges,
+// with the finished PV sum read from `Partial`.
+template <bool Fast> struct EdgeFinalBody {
+   MeshView M;
+   int K;
+   TendParams P;
+   const Real *H, *U, *Partial;
+   const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
+   Real *Tend;
+   struct Lds {
+      Real *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
+      int *C0, *C1, *V0, *V1, *Reg;
+   };
+   size_t ldsBytes(int Tile) const { return ldsRound8(sizeof(Real) * Tile) * 8 + ldsRound8(sizeof(int) * Tile) * 5; }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.InvDc    = C.take<Real>(Tile);
+      L.InvDv    = C.take<Real>(Tile);
+      L.Mask     = C.take<Real>(Tile);
+      L.MaskGrav = C.take<Real>(Tile);
+      L.C2       = C.take<Real>(Tile);
+      L.C4       = C.take<Real>(Tile);
+      L.BD0      = C.take<Real>(Tile);
+      L.BD1      = C.take<Real>(Tile);
+      L.C0       = C.take<int>(Tile);
+      L.C1       = C.take<int>(Tile);
+      L.V0       = C.take<int>(Tile);
+      L.V1       = C.take<int>(Tile);
+      L.Reg      = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      const Real Grav = 9.80665; // TendencyTerms.h:176
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int E     = First + I;
+         const Real Mask = M.EdgeMask1D[E];
+         const int C0 = M.CellsOnEdge[2 * E], C1 = M.CellsOnEdge[2 * E + 1];
+         L.InvDc[I]    = M.InvDcEdge[E];
+         L.InvDv[I]    = M.InvDvEdge[E];
+         L.Mask[I]     = Mask;
+         L.MaskGrav[I] = Mask * Grav;
+         L.C2[I]       = Mask * P.ViscDel2 * M.MeshScalingDel2[E];
+         L.C4[I]       = Mask * P.ViscDel4 * M.MeshScalingDel4[E];
+         L.BD0[I]      = M.BottomDepth[C0];
+         L.BD1[I]      = M.BottomDepth[C1];
+         L.C0[I]       = C0;
+         L.C1[I]       = C1;
+         L.V0[I]       = M.VerticesOnEdge[2 * E];
+         L.V1[I]       = M.VerticesOnEdge[2 * E + 1];
+         L.Reg[I]      = M.EdgeRegular[E];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int IEdge, int Kv) const {
+      if (!L.Reg[Le])
+         return; // irregular edges are written by the edge-centric kernel
+      const bool PVOn = Fast ? true : (P.PVTendencyEnable != 0), KEOn = Fast ? true : (P.KETendencyEnable != 0);
+      const bool SSHOn = Fast ? true : (P.SSHTendencyEnable != 0), D2On = Fast ? true : (P.VelDiffTendencyEnable != 0);
+      const bool D4On   = Fast ? true : (P.VelHyperDiffTendencyEnable != 0);
+      const bool WindOn = Fast ? false : (P.WindForcingTendencyEnable != 0);
+      const bool DragOn = Fast ? false : (P.BottomDragTendencyEnable != 0);
+      const unsigned OffC0 = rowOff<T>(L.C0[Le], K, Kv), OffC1 = rowOff<T>(L.C1[Le], K, Kv);
+      const unsigned OffV0 = rowOff<T>(L.V0[Le], K, Kv), OffV1 = rowOff<T>(L.V1[Le], K, Kv);
+      const unsigned OffE  = rowOff<T>(IEdge, K, Kv);
+      const Real InvDc = L.InvDc[Le], InvDv = L.InvDv[Le];
+      const T H0 = ldo<T>(H, OffC0), H1 = ldo<T>(H, OffC1);
+      T TendV = splat<T>(0.0);
+      if (PVOn)
+         TendV += L.Mask[Le] * ldo<T>(Partial, OffE);
+      if (KEOn)
+         TendV -= L.Mask[Le] * (ldo<T>(KE, OffC1) - ldo<T>(KE, OffC0)) * InvDc;
+      if (SSHOn) {
+         const T Ssh0 = H0 - L.BD0[Le], Ssh1 = H1 - L.BD1[Le];
+         TendV -= L.MaskGrav[Le] * (Ssh1 - Ssh0) * InvDc;
+      }
+      if (D2On) {
+         const T Del2U = ((ldo<T>(Div, OffC1) - ldo<T>(Div, OffC0)) * InvDc -
+                          (ldo<T>(RelVort, OffV1) - ldo<T>(RelVort, OffV0)) * InvDv);
+         TendV += L.C2[Le] * Del2U;
+      }
+      if (D4On) {
+         const T Del2U = (P.DivFactor * (ldo<T>(Del2Div, OffC1) - ldo<T>(Del2Div, OffC0)) * InvDc -
+                          (ldo<T>(Del2RelVort, OffV1) - ldo<T>(Del2RelVort, OffV0)) * InvDv);
+         TendV -= L.C4[Le] * Del2U;
+      }
+      constexpr int W = VecW<T>::W;
+      if (WindOn && Kv == 0) {
+         const Real HMean0       = 0.5 * (getc(H0, 0) + getc(H1, 0));
+         const Real InvThickEdge = 1. / HMean0;
+         setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * NormalStress[IEdge] / P.Density0);
+      }
+      if (DragOn && (Kv + 1) * W >= K) {
+         const int KBot          = K - 1;
+         const int Comp          = KBot - Kv * W;
+         const Real VelNormEdge  = sqrt(KE[(size_t)L.C0[Le] * K + KBot] + KE[(size_t)L.C1[Le] * K + KBot]);
+         const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
+         const Real InvThickEdge = 1. / HMeanB;
+         setc(TendV, Comp,
+              getc(TendV, Comp) - L.Mask[Le] * P.BottomDragCoeff * VelNormEdge * InvThickEdge * U[(size_t)IEdge * K + KBot]);
+      }
+      stnt<T>(Tend, OffE, TendV);
+   }
+};
+
+// ---------------------------------------------------------------------------------------
+// L3 edge pass, LDS-patch form.  Same arithmetic as FusedEdgeChainBody; the data path differs:
+// a workgroup owns a patch of EPSize consecutive edges and a chunk of KC levels, stages every
+// UNIQUE row its PV stencils reference (h on cells, NormRelVort / NormPlanetVort on vertices, u on
+// edges; HorzMesh::buildPatches) into LDS once, and the 46 stencil reads per edge-level then come
+// from LDS (4x the L1 rate) instead of 46 separate gathers.  The ten own-cell / own-vertex
+// values of the other terms are read straight from global memory.
+template <int TME, bool Fast> struct EdgePatchArgs {
+   MeshView M;
+   int K, KC;
+   TendParams P;
+   const Real *H, *U;
+   const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
+   Real *Tend;
+};
+
+template <int TME, bool Fast, class T>
+__global__ void __launch_bounds__(256, 2) edgePatchKernel(EdgePatchArgs<TME, Fast> A) {
+   constexpr int TM1 = TME - 1;
+   constexpr int W   = VecW<T>::W;
+   extern __shared__ __align__(16) unsigned char Lds[];
+   const MeshView &M = A.M;
+   const int K = A.K, KC = A.KC, KCV = KC / W;
+   const int Patch = xcdRemap(blockIdx.x, gridDim.x);
+   const int K0    = blockIdx.y * KC;
+   const int PE = M.EPSize, LS = M.EPLocStride;
+   const int *Off  = M.EPListOff + (size_t)Patch * 4;
+   const int OC = Off[0], OV = Off[1], OE = Off[2], OEnd = Off[3];
+   const int NUC = OV - OC, NUV = OE - OV, NUE = OEnd - OE;
+   // carve LDS: data rows first (16-byte aligned), then weights, then the 16-bit stencil table
+   LdsCarver Cv{Lds};
+   Real *LH  = Cv.take<Real>(M.EPMaxC * KC);
+   Real *LQR = Cv.take<Real>(M.EPMaxV * KC);
+   Real *LQF = Cv.take<Real>(M.EPMaxV * KC);
+   Real *LU  = Cv.take<Real>(M.EPMaxE * KC);
+   Real *LW  = Cv.take<Real>(PE * 2 * TM1);
+   unsigned short *LLoc = Cv.take<unsigned short>(PE * LS);
+   const int Tid = threadIdx.y * blockDim.x + threadIdx.x, NThr = blockDim.x * blockDim.y;
+   const int E0  = Patch * PE;
+   // ---- stage metadata ----
+   for (int I = Tid; I < PE * LS; I += NThr)
+      LLoc[I] = M.EPLocal[(size_t)E0 * LS + I];
+   for (int I = Tid; I < PE * 2 * TM1; I += NThr) {
+      const int E = E0 + I / (2 * TM1);
+      LW[I]       = E < M.NEdgesAll ? M.PVChainWeight[(size_t)E0 * 2 * TM1 + I] : 0.0;
+   }
+   // ---- stage the unique rows of this level chunk: lists -> LDS, then batched row loads so
+   //      that several rows per thread are in flight before the first LDS write ----
+   int *LList = Cv.take<int>(M.EPMaxC + 2 * M.EPMaxV + M.EPMaxE);
+   const int RT = NUC + 2 * NUV + NUE; // local rows: [h | qR | qF | u]
+   for (int I = Tid; I < RT; I += NThr) {
+      int G;
+      if (I < NUC)
+         G = M.EPList[OC + I];
+      else if (I < NUC + NUV)
+         G = M.EPList[OV + (I - NUC)];
+      else if (I < NUC + 2 * NUV)
+         G = M.EPList[OV + (I - NUC - NUV)];
+      else
+         G = M.EPList[OE + (I - NUC - 2 * NUV)];
+      LList[I] = G;
+   }
+   __syncthreads();
+   {
+      // destination of local row r: the four arrays are carved back to back with pitch KC, but the
+      // h / q / u regions are sized by the MAX list lengths, so map r -> region base + index
+      const int RowsPerIter = NThr / KCV;
+      const int MyRow = Tid / KCV, Kv = Tid - MyRow * KCV;
+      const int Kk    = K0 + Kv * W;
+      constexpr int B = 8;
+      for (int R0 = 0; R0 < RT; R0 += RowsPerIter * B) {
+         T Val[B];
+#pragma unroll
+         for (int Bi = 0; Bi < B; ++Bi) {
+            const int R = R0 + Bi * RowsPerIter + MyRow;
+            Val[Bi]     = splat<T>(0.0);
+            if (R < RT && Kk < K) {
+               const Real *Src = R < NUC ? A.H : (R < NUC + NUV ? A.NormRelVortV : (R < NUC + 2 * NUV ? A.NormPlanetVortV : A.U));
+               Val[Bi]         = *reinterpret_cast<const T *>(Src + (size_t)LList[R] * K + Kk);
+            }
+         }
+#pragma unroll
+         for (int Bi = 0; Bi < B; ++Bi) {
+            const int R = R0 + Bi * RowsPerIter + MyRow;
+            if (R < RT) {
+               Real *Dst = R < NUC ? LH + R * KC
+                                   : (R < NUC + NUV ? LQR + (R - NUC) * KC
+                                                    : (R < NUC + 2 * NUV ? LQF + (R - NUC - NUV) * KC
+                                                                         : LU + (R - NUC - 2 * NUV) * KC));
+               *reinterpret_cast<T *>(Dst + Kv * W) = Val[Bi];
+            }
+         }
+      }
+   }
+   __syncthreads();
+
+   const TendParams &P   = A.P;
+   const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
+   const bool PVOn = Fast ? true : (P.PVTendencyEnable != 0), KEOn = Fast ? true : (P.KETendencyEnable != 0);
+   const bool SSHOn = Fast ? true : (P.SSHTendencyEnable != 0), D2On = Fast ? true : (P.VelDiffTendencyEnable != 0);
+   const bool D4On   = Fast ? true : (P.VelHyperDiffTendencyEnable != 0);
+   const bool WindOn = Fast ? false : (P.WindForcingTendencyEnable != 0);
+   const bool DragOn = Fast ? false : (P.BottomDragTendencyEnable != 0);
+   const Real Grav   = 9.80665; // TendencyTerms.h:176
+   const int Kv = threadIdx.x;
+   const int Kk = K0 + Kv * W; // first level of this thread
+   auto LD = [&](const Real *Rows, int LocalRow) { return *reinterpret_cast<const T *>(Rows + LocalRow * KC + Kv * W); };
+   for (int Le = threadIdx.y; Le < PE; Le += blockDim.y) {
+      const int IEdge = E0 + Le;
+      if (IEdge >= M.NEdgesAll || Kk >= K)
+         continue;
+      const unsigned short *Lp = LLoc + Le * LS;
+      const int C0 = M.CellsOnEdge[2 * IEdge], C1 = M.CellsOnEdge[2 * IEdge + 1];
+      const int V0 = M.VerticesOnEdge[2 * IEdge], V1 = M.VerticesOnEdge[2 * IEdge + 1];
+      const unsigned KvG   = (unsigned)(Kk / W); // level-chunk index within the full column
+      const unsigned OffC0 = rowOff<T>(C0, K, KvG), OffC1 = rowOff<T>(C1, K, KvG);
+      const unsigned OffV0 = rowOff<T>(V0, K, KvG), OffV1 = rowOff<T>(V1, K, KvG);
+      const Real Mask = M.EdgeMask1D[IEdge], InvDc = M.InvDcEdge[IEdge], InvDv = M.InvDvEdge[IEdge];
+      const T H0 = LD(LH, Lp[0]), H1 = LD(LH, Lp[1]);
+      T TendV = splat<T>(0.0);
+      if (PVOn) {
+         const T QRe = 0.5 * (LD(LQR, Lp[LS - 2]) + LD(LQR, Lp[LS - 1]));
+         const T QFe = 0.5 * (LD(LQF, Lp[LS - 2]) + LD(LQF, Lp[LS - 1]));
+         T VortTmp   = splat<T>(0.0);
+#pragma unroll
+         for (int Sd = 0; Sd < 2; ++Sd) {
+            const T Hs = Sd == 0 ? H0 : H1;
+            const unsigned short *LV = Lp + 2 + Sd * TME;
+            const unsigned short *LF = Lp + 2 + 2 * TME + Sd * TM1;
+            const unsigned short *LE = Lp + 2 + 2 * TME + 2 * TM1 + Sd * TM1;
+            T QRp = LD(LQR, LV[0]), QFp = LD(LQF, LV[0]);
+#pragma unroll
+            for (int J = 0; J < TM1; ++J) {
+               const T QRn = LD(LQR, LV[J + 1]), QFn = LD(LQF, LV[J + 1]);
+               const unsigned F = LF[J];
+               const T Hf = LD(LH, F & 0x7fff), Uj = LD(LU, LE[J]);
+               T Flux = 0.5 * (Hs + Hf);
+               if (FluxUpwind) {
+                  const bool First = (F & 0x8000) != 0;
+                  Flux             = upwind(Uj, pick(First, Hs, Hf), pick(First, Hf, Hs));
+               }
+               const T QRj = 0.5 * (QRp + QRn);
+               const T QFj = 0.5 * (QFp + QFn);
+               const T NormVort = (QRe + QFe + QRj + QFj) * 0.5;
+               VortTmp += LW[(Le * 2 + Sd) * TM1 + J] * Flux * Uj * NormVort;
+               QRp = QRn;
+               QFp = QFn;
+            }
+         }
+         TendV += Mask * VortTmp;
+      }
+      if (KEOn)
+         TendV -= Mask * (ldo<T>(A.KE, OffC1) - ldo<T>(A.KE, OffC0)) * InvDc;
+      if (SSHOn) {
+         const T Ssh0 = H0 - M.BottomDepth[C0], Ssh1 = H1 - M.BottomDepth[C1];
+         TendV -= (Mask * Grav) * (Ssh1 - Ssh0) * InvDc;
+      }
+      if (D2On) {
+         const T Del2U = ((ldo<T>(A.Div, OffC1) - ldo<T>(A.Div, OffC0)) * InvDc -
+                          (ldo<T>(A.RelVort, OffV1) - ldo<T>(A.RelVort, OffV0)) * InvDv);
+         TendV += (Mask * P.ViscDel2 * M.MeshScalingDel2[IEdge]) * Del2U;
+      }
+      if (D4On) {
+         const T Del2U = (P.DivFactor * (ldo<T>(A.Del2Div, OffC1) - ldo<T>(A.Del2Div, OffC0)) * InvDc -
+                          (ldo<T>(A.Del2RelVort, OffV1) - ldo<T>(A.Del2RelVort, OffV0)) * InvDv);
+         TendV -= (Mask * P.ViscDel4 * M.MeshScalingDel4[IEdge]) * Del2U;
+      }
+      if (WindOn && Kk == 0) {
+         const Real HMean0       = 0.5 * (getc(H0, 0) + getc(H1, 0));
+         const Real InvThickEdge = 1. / HMean0;
+         setc(TendV, 0, getc(TendV, 0) + Mask * InvThickEdge * A.NormalStress[IEdge] / P.Density0);
+      }
+      if (DragOn && Kk + W >= K) {
+         const int KBot          = K - 1;
+         const int Comp          = KBot - Kk;
+         const Real VelNormEdge  = sqrt(A.KE[(size_t)C0 * K + KBot] + A.KE[(size_t)C1 * K + KBot]);
+         const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
+         const Real InvThickEdge = 1. / HMeanB;
+         setc(TendV, Comp,
+              getc(TendV, Comp) - Mask * P.BottomDragCoeff * VelNormEdge * InvThickEdge * A.U[(size_t)IEdge * K + KBot]);
+      }
+      sto<T>(A.Tend, rowOff<T>(IEdge, K, KvG), TendV);
+   }
+}
+
+template <int TME, bool Fast>
+static bool launchEdgePatch(const MeshView &M, int K, const TendParams &P, const AuxPtrs &A, Real *UTend,
+                            const Real *H, const Real *U, hipStream_t S) {
+   if (M.EPCount <= 0 || !M.PVChainOK || (K & 1))
+      return false;
+   static const int KC = getenv("OMEGA_EDGE_KC") ? atoi(getenv("OMEGA_EDGE_KC")) : 16;
+   const int W = 2, KCV = KC / W;
+   const size_t Lds = ldsRound8(sizeof(Real) * M.EPMaxC * KC) + ldsRound8(sizeof(Real) * M.EPMaxV * KC) * 2 +
+                      ldsRound8(sizeof(Real) * M.EPMaxE * KC) + ldsRound8(sizeof(Real) * M.EPSize * 2 * (TME - 1)) +
+                      ldsRound8(sizeof(unsigned short) * M.EPSize * M.EPLocStride) +
+                      ldsRound8(sizeof(int) * (M.EPMaxC + 2 * M.EPMaxV + M.EPMaxE));
+   if (Lds > 150 * 1024)
+      return false;
+   EdgePatchArgs<TME, Fast> Args{M,
+                                 K,
+                                 KC,
+                                 P,
+                                 H,
+                                 U,
+                                 A.RelVortVertex,
+                                 A.NormRelVortVertex,
+                                 A.NormPlanetVortVertex,
+                                 A.KineticEnergyCell,
+                                 A.VelocityDivCell,
+                                 A.Del2DivCell,
+                                 A.Del2RelVortVertex,
+                                 A.NormalStressEdge,
+                                 UTend};
+   auto Kern = edgePatchKernel<TME, Fast, dv2>;
+   static bool AttrSet = false;
+   if (!AttrSet && Lds > 64 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Lds);
+      AttrSet = true;
+   }
+   const dim3 Grid(M.EPCount, (K + KC - 1) / KC, 1), Block(KCV, 256 / KCV, 1);
+   hipLaunchKernelGGL(Kern, Grid, Block, Lds, S, Args);
+   return true;
+}
 
 // ---------------------------------------------------------------------------------------
 // L3 cell pass: tracer tendencies (TendencyTerms.h:349-480) with HTracersEdge
@@ -719,10 +1169,192 @@ template <int TME, bool Fast> struct FusedCell3Body {
             TendV += P.EddyDiff2 * DiffTmp * InvA;
          if (HypOn)
             TendV -= P.EddyDiff4 * HypTmp * InvA;
-         sto<T>(uniformPtr(Tend + Lt * CStride), OffS, TendV);
+         stnt<T>(uniformPtr(Tend + Lt * CStride), OffS, TendV);
       }
    }
 };
+
+// ---------------------------------------------------------------------------------------
+// L3 cell pass, LDS-patch form (Default.yml term set only).  Same arithmetic as
+// FusedCell3Body<TME, true>.  A workgroup owns a patch of CPSize consecutive cells and a chunk of
+// KC levels; per tracer it stages the UNIQUE rows (own cells + ring, HorzMesh::buildPatches) of the
+// tracer and of Del2Tracers into LDS once -- every row then costs one fabric/L2 fetch per patch
+// instead of one per neighbour that misses L1 -- and the 14 stencil reads per (cell, levels,
+// tracer) come from LDS.  h is staged once per workgroup; u stays in registers.
+template <int TME> struct CellPatchArgs {
+   MeshView M;
+   int K, KC, NT;
+   TendParams P;
+   const Real *H, *U, *Tr, *Del2Tr;
+   Real *Tend;
+};
+
+template <int TME, int RMAX, class T>
+__global__ void __launch_bounds__(256, 2) cell3PatchKernel(CellPatchArgs<TME> A) {
+   constexpr int W = VecW<T>::W;
+   extern __shared__ __align__(16) unsigned char Lds[];
+   const MeshView &M = A.M;
+   const int K = A.K, KC = A.KC, KCV = KC / W, NT = A.NT;
+   const int Patch = xcdRemap(blockIdx.x, gridDim.x);
+   const int K0    = blockIdx.y * KC;
+   const int PC    = M.CPSize;
+   const int O0 = M.CPListOff[2 * Patch], NU = M.CPListOff[2 * Patch + 1] - O0;
+   LdsCarver Cv{Lds};
+   Real *LHs  = Cv.take<Real>(M.CPMaxC * KC);
+   Real *LT   = Cv.take<Real>(M.CPMaxC * KC);
+   Real *LD2  = Cv.take<Real>(M.CPMaxC * KC);
+   Real *LMDv = Cv.take<Real>(PC * TME);
+   Real *LDf2 = Cv.take<Real>(PC * TME);
+   Real *LDf4 = Cv.take<Real>(PC * TME);
+   int *LList = Cv.take<int>(M.CPMaxC);
+   unsigned short *LLoc = Cv.take<unsigned short>(PC * TME);
+   const int Tid = threadIdx.y * blockDim.x + threadIdx.x, NThr = blockDim.x * blockDim.y;
+   const int C0  = Patch * PC;
+   for (int I = Tid; I < NU; I += NThr)
+      LList[I] = M.CPList[O0 + I];
+   for (int I = Tid; I < PC * TME; I += NThr) {
+      const int C    = C0 + I / TME;
+      const bool In  = C < M.NCellsAll;
+      const size_t G = (size_t)C0 * TME + I;
+      LLoc[I]        = M.CPLocal[G];
+      LMDv[I]        = In ? M.MaskDvSignOnCell[G] : 0.0;
+      LDf2[I]        = In ? M.Diff2CoefSOnCell[G] : 0.0;
+      LDf4[I]        = In ? M.Diff4CoefSOnCell[G] : 0.0;
+   }
+   __syncthreads();
+   const int RowsPerIter = NThr / KCV;
+   const int MyRow = Tid / KCV, SKv = Tid - MyRow * KCV;
+   const int SKk   = K0 + SKv * W;
+   auto StageRows = [&](Real *Dst, const Real *Src) {
+      constexpr int B = 4;
+      for (int R0 = 0; R0 < NU; R0 += RowsPerIter * B) {
+         T Val[B];
+#pragma unroll
+         for (int Bi = 0; Bi < B; ++Bi) {
+            const int R = R0 + Bi * RowsPerIter + MyRow;
+            Val[Bi]     = splat<T>(0.0);
+            if (R < NU && SKk < K)
+               Val[Bi] = *reinterpret_cast<const T *>(Src + (size_t)LList[R] * K + SKk);
+         }
+#pragma unroll
+         for (int Bi = 0; Bi < B; ++Bi) {
+            const int R = R0 + Bi * RowsPerIter + MyRow;
+            if (R < NU)
+               *reinterpret_cast<T *>(Dst + R * KC + SKv * W) = Val[Bi];
+         }
+      }
+   };
+   StageRows(LHs, A.H);
+   // per-thread items: cells Le = threadIdx.y + s*blockDim.y, levels chunk Kv = threadIdx.x
+   constexpr int MAXIT = 2; // CPSize / blockDim.y
+   const int Kv = threadIdx.x;
+   const int Kk = K0 + Kv * W;
+   const unsigned KvG = (unsigned)(Kk / W);
+   T UJ[MAXIT][TME];
+   Real InvA[MAXIT];
+   bool Active[MAXIT];
+#pragma unroll
+   for (int It = 0; It < MAXIT; ++It) {
+      const int Le = threadIdx.y + It * blockDim.y, ICell = C0 + Le;
+      Active[It]   = Le < PC && ICell < M.NCellsAll && Kk < K;
+      InvA[It]     = Active[It] ? M.InvAreaCell[ICell] : 0.0;
+#pragma unroll
+      for (int J = 0; J < TME; ++J)
+         UJ[It][J] = Active[It] ? ldo<T>(A.U, rowOff<T>(M.EdgesOnCell[(size_t)ICell * TME + J], K, KvG)) : splat<T>(0.0);
+   }
+   auto LD = [&](const Real *Rows, int LocalRow) { return *reinterpret_cast<const T *>(Rows + LocalRow * KC + Kv * W); };
+   const size_t CStride = (size_t)M.NCellsSize * K;
+   const TendParams &P  = A.P;
+   // software pipeline over tracers: the rows of tracer l+1 are in flight (in registers) while
+   // tracer l is computed from LDS
+   // RMAX rows per thread per array: NU <= RMAX * RowsPerIter (checked by the launcher)
+   unsigned RowOffB[RMAX];  // byte offset of this thread's source element inside a plane
+#pragma unroll
+   for (int Bi = 0; Bi < RMAX; ++Bi) {
+      const int R = Bi * RowsPerIter + MyRow;
+      RowOffB[Bi] = (R < NU && SKk < K) ? ((unsigned)LList[R] * (unsigned)K + (unsigned)SKk) * 8u : 0xffffffffu;
+   }
+   T PT[RMAX], PD[RMAX];
+   auto Prefetch = [&](int Lt) {
+      const Real *TrL = uniformPtr(A.Tr + Lt * CStride), *D2L = uniformPtr(A.Del2Tr + Lt * CStride);
+#pragma unroll
+      for (int Bi = 0; Bi < RMAX; ++Bi) {
+         PT[Bi] = splat<T>(0.0);
+         PD[Bi] = splat<T>(0.0);
+         if (RowOffB[Bi] != 0xffffffffu) {
+            PT[Bi] = ldo<T>(TrL, RowOffB[Bi]);
+            PD[Bi] = ldo<T>(D2L, RowOffB[Bi]);
+         }
+      }
+   };
+   if (NT > 0)
+      Prefetch(0);
+#pragma nounroll
+   for (int Lt = 0; Lt < NT; ++Lt) {
+      __syncthreads(); // previous tracer's LDS reads are done (first time: h and the lists are staged)
+#pragma unroll
+      for (int Bi = 0; Bi < RMAX; ++Bi) {
+         const int R = Bi * RowsPerIter + MyRow;
+         if (R < NU) {
+            *reinterpret_cast<T *>(LT + R * KC + SKv * W)  = PT[Bi];
+            *reinterpret_cast<T *>(LD2 + R * KC + SKv * W) = PD[Bi];
+         }
+      }
+      __syncthreads();
+      if (Lt + 1 < NT)
+         Prefetch(Lt + 1);
+#pragma unroll
+      for (int It = 0; It < MAXIT; ++It) {
+         if (!Active[It])
+            continue;
+         const int Le = threadIdx.y + It * blockDim.y, ICell = C0 + Le;
+         const T Hs = LD(LHs, Le), Ts = LD(LT, Le), Ds = LD(LD2, Le); // own cells come first in the list
+         const T HsTs = Hs * Ts;
+         T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            const int I  = Le * TME + J;
+            const int Ln = LLoc[I];
+            const T Hn = LD(LHs, Ln), Tn = LD(LT, Ln), Dn = LD(LD2, Ln);
+            const T HTr = 0.5 * (HsTs + Hn * Tn);
+            HAdvTmp -= LMDv[I] * HTr * UJ[It][J] * InvA[It];
+            const T Mean = 0.5 * (Hs + Hn);
+            DiffTmp -= LDf2[I] * Mean * (Tn - Ts);
+            HypTmp -= LDf4[I] * (Dn - Ds);
+         }
+         T TendV = splat<T>(0.0);
+         TendV -= HAdvTmp;
+         TendV += P.EddyDiff2 * DiffTmp * InvA[It];
+         TendV -= P.EddyDiff4 * HypTmp * InvA[It];
+         sto<T>(uniformPtr(A.Tend + Lt * CStride), rowOff<T>(ICell, K, KvG), TendV);
+      }
+   }
+}
+
+template <int TME>
+static bool launchCell3Patch(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *TrTend,
+                             const Real *H, const Real *U, const Real *Tr, hipStream_t S) {
+   if (M.CPCount <= 0 || (K & 1) || M.CPSize != 64)
+      return false;
+   static const int KC = getenv("OMEGA_CELL_KC") ? atoi(getenv("OMEGA_CELL_KC")) : 16;
+   const int W = 2, KCV = KC / W;
+   if (KCV < 1 || 256 % KCV != 0 || 256 / KCV * 2 < M.CPSize || M.CPMaxC > 8 * (256 / KCV))
+      return false;
+   const size_t Lds = ldsRound8(sizeof(Real) * M.CPMaxC * KC) * 3 + ldsRound8(sizeof(Real) * M.CPSize * TME) * 3 +
+                      ldsRound8(sizeof(int) * M.CPMaxC) + ldsRound8(sizeof(unsigned short) * M.CPSize * TME);
+   if (Lds > 150 * 1024)
+      return false;
+   CellPatchArgs<TME> Args{M, K, KC, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
+   const int RowsPerIter = 256 / KCV;
+   const bool Small = M.CPMaxC <= 4 * RowsPerIter;
+   auto Kern = Small ? cell3PatchKernel<TME, 4, dv2> : cell3PatchKernel<TME, 8, dv2>;
+   if (Lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Lds);
+   const dim3 Grid(M.CPCount, (K + KC - 1) / KC, 1), Block(KCV, 256 / KCV, 1);
+   hipLaunchKernelGGL(Kern, Grid, Block, Lds, S, Args);
+   return true;
+}
 
 const char *const FusedKernelNames[FusedNumKernels] = {"VortVertexBody(L1 vertex)", "FusedCell1Body(L1 cell)",
                                                        "FusedDel2CellBody(L2 cell)", "FusedDel2VertexBody(L2 vertex)",
@@ -745,7 +1377,7 @@ bool fusedRHSSupported(const MeshView &M, int K) {
 template <int TME, bool Fast>
 static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
                          Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                         hipEvent_t *Ev) {
+                         hipEvent_t *Ev, Real *EdgeScratch) {
    auto Mark = [&](int I) {
       if (Ev)
          (void)hipEventRecord(Ev[I], S);
@@ -775,7 +1407,52 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    // L3
    Mark(4);
-   if (M.PVChainOK) {
+   static const int EdgeMode = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
+   // 0: cell-centric PV sums + edge finalize (default), 1: edge-centric chain kernel,
+   // 2: LDS-patch edge kernel (kept for experiments)
+   if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
+      const bool PVOn = P.PVTendencyEnable != 0;
+      if (PVOn) {
+         CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
+         launchTile(B0, M.NCellsAll, K, S);
+         CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
+         launchTile(B1, M.NCellsAll, K, S);
+      }
+      EdgeFinalBody<Fast> BF{M,
+                             K,
+                             P,
+                             H,
+                             U,
+                             EdgeScratch,
+                             A.RelVortVertex,
+                             A.KineticEnergyCell,
+                             A.VelocityDivCell,
+                             A.Del2DivCell,
+                             A.Del2RelVortVertex,
+                             A.NormalStressEdge,
+                             UTend};
+      launchTile(BF, M.NEdgesAll, K, S);
+      if (M.NIrregularEdges > 0) {
+         FusedEdgeChainBody<TME, Fast> B{M,
+                                         K,
+                                         P,
+                                         H,
+                                         U,
+                                         A.RelVortVertex,
+                                         A.NormRelVortVertex,
+                                         A.NormPlanetVortVertex,
+                                         A.KineticEnergyCell,
+                                         A.VelocityDivCell,
+                                         A.Del2DivCell,
+                                         A.Del2RelVortVertex,
+                                         A.NormalStressEdge,
+                                         UTend,
+                                         M.IrregularEdges};
+         launchTile(B, M.NIrregularEdges, K, S);
+      }
+   } else if (EdgeMode == 2 && launchEdgePatch<TME, Fast>(M, K, P, A, UTend, H, U, S)) {
+      // LDS-patch edge kernel launched
+   } else if (M.PVChainOK) {
       FusedEdgeChainBody<TME, Fast> B{M,
                                       K,
                                       P,
@@ -789,7 +1466,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                       A.Del2DivCell,
                                       A.Del2RelVortVertex,
                                       A.NormalStressEdge,
-                                      UTend};
+                                      UTend,
+                                      nullptr};
       launchTile(B, M.NEdgesAll, K, S);
    } else {
       FusedEdgeBody B{M,       K,           P,           H,           U,
@@ -799,21 +1477,26 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    Mark(5);
    if (NT > 0) {
-      FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
-      launchTile(B, M.NCellsAll, K, S);
+      static const int CellMode = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
+      // 0: per-thread gathers (FusedCell3Body); 1: LDS-patch kernel for the default term set
+      if (!(CellMode == 1 && Fast && launchCell3Patch<TME>(M, K, NT, P, A, TrTend, H, U, Tr, S))) {
+         FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
+         launchTile(B, M.NCellsAll, K, S);
+      }
    }
    Mark(6);
 }
 
 void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
-                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S, hipEvent_t *Ev) {
+                    Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S, hipEvent_t *Ev,
+                    Real *EdgeScratch) {
    const bool Fast = isDefaultTermSet(P);
 #define OMEGA_CASE(ME_)                                                                                            \
    case ME_:                                                                                                       \
       if (Fast)                                                                                                    \
-         launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev);                           \
+         launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch);              \
       else                                                                                                         \
-         launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev);                          \
+         launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch);             \
       break;
    switch (M.MaxEdges) {
       OMEGA_CASE(5)

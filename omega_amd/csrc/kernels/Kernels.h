@@ -67,7 +67,8 @@ bool fusedRHSSupported(const MeshView &M, int K);
 extern const char *const FusedKernelNames[FusedNumKernels];
 void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                    hipEvent_t *Ev = nullptr);
+                    hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr);
+/// EdgeScratch: optional [NEdgesSize][K] work array for the cell-centric PV sums (faster path)
 
 // ---- TimeStepper update kernels (TimeStepper.cpp:378-524) ----
 void launchUpdateByTend(int NRows, int K, Real *X1, const Real *X2, const Real *Tend, Real Coeff, hipStream_t S);
