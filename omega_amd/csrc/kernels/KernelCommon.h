@@ -14,6 +14,7 @@
 #ifndef OMEGA_AMD_KERNELCOMMON_H
 #define OMEGA_AMD_KERNELCOMMON_H
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 namespace OMEGA {
@@ -102,12 +103,26 @@ inline Geom makeGeom(int N, int K, int MaxW = 2) {
    Geom G;
    G.W  = (K % 2 == 0 && MaxW >= 2) ? 2 : 1;
    G.KV = K / G.W;
-   int TX = G.KV < 64 ? G.KV : 64;
+   // threadIdx.x spans ONE 128-byte line of a column (8 level-pairs, or 16 single levels) and
+   // threadIdx.y the elements of the tile, so a workgroup issues every gather of its tile for one
+   // line-deep level chunk at the same instant: rows shared between neighbouring elements of
+   // the tile are then served by L1/L2 while still resident (at ~6 TB/s an XCD's 4 MiB L2
+   // turns over in a few microseconds, so reuse separated by a whole sweep is lost).  The
+   // workgroup walks the remaining level chunks with the x-stride loop of tileKernel.
+   const int LineTX = 128 / (8 * G.W);
+   int TX           = G.KV < LineTX ? G.KV : LineTX;
+   static const int EnvTX = getenv("OMEGA_TX") ? atoi(getenv("OMEGA_TX")) : 0;
+   static const int EnvTY = getenv("OMEGA_TY") ? atoi(getenv("OMEGA_TY")) : 0;
+   static const int EnvSW = getenv("OMEGA_SWEEPS") ? atoi(getenv("OMEGA_SWEEPS")) : 1;
+   if (EnvTX > 0)
+      TX = EnvTX < G.KV ? EnvTX : G.KV;
    int TY = 256 / TX;
+   if (EnvTY > 0)
+      TY = EnvTY;
    if (TY < 1)
       TY = 1;
    G.Block = dim3(TX, TY, 1);
-   G.Tile  = TY * 4;
+   G.Tile  = TY * (EnvSW > 0 ? EnvSW : 1);
    if (G.Tile > 256)
       G.Tile = 256;
    int NTiles = (N + G.Tile - 1) / G.Tile;
@@ -131,8 +146,11 @@ template <class B> struct BodyMaxW<B, decltype((void)B::MaxW)> {
    static constexpr int V = B::MaxW;
 };
 
+#ifndef OMEGA_LB
+#define OMEGA_LB 256
+#endif
 template <class Body, class T>
-__global__ void __launch_bounds__(256, BodyMinWaves<Body>::V) tileKernel(Body B, int N, int KV, int Tile) {
+__global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Body B, int N, int KV, int Tile) {
    extern __shared__ __align__(16) unsigned char Lds[];
    const int TileId = xcdRemap(blockIdx.x, gridDim.x);
    const int First  = TileId * Tile;
