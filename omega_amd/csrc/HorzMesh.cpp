@@ -382,6 +382,118 @@ void HorzMesh::buildCoefficientTables() {
    buildPatches();
    HostChW = ChW;
    buildCellPV();
+   buildDel2Tables();
+}
+
+// Ring form of the velocity-del2 stencils (see HorzMesh.h).  Works for any mesh whose
+// EdgesOnCell lists walk around the cell (consecutive slots share a vertex); anything else
+// clears the OK flag and the kernels fall back to the per-edge form.
+void HorzMesh::buildDel2Tables() {
+   const int ME = MaxEdges, VD = VertexDegree;
+   MeshView &W = View;
+   HostArrayI4 Ring(NCellsSize, ME, 1, NVerticesAll);
+   HostArrayReal GradS(NCellsSize, ME, 1, 0.0), IDcC(NCellsSize, ME, 1, 0.0), CurlC(NCellsSize, ME, 1, 0.0);
+   bool RingOK = true;
+   auto InvDv2 = [&](int E) { return 1. / std::max(DvEdgeH(E), 0.25 * DcEdgeH(E)); }; // VelocityDel2AuxVars.h:32-33
+   for (int C = 0; C < NCellsAll && RingOK; ++C) {
+      const int N = NEdgesOnCellH(C);
+      if (N < 3 || N > ME) {
+         RingOK = false;
+         break;
+      }
+      for (int J = 0; J < N; ++J) {
+         const int E = EdgesOnCellH(C, J), En = EdgesOnCellH(C, (J + 1) % N);
+         if (E >= NEdgesAll || En >= NEdgesAll) {
+            RingOK = false;
+            break;
+         }
+         int Shared = -1;
+         for (int A = 0; A < 2; ++A)
+            for (int B = 0; B < 2; ++B)
+               if (VerticesOnEdgeH(E, A) == VerticesOnEdgeH(En, B) && VerticesOnEdgeH(E, A) < NVerticesAll)
+                  Shared = VerticesOnEdgeH(E, A);
+         if (Shared < 0) {
+            RingOK = false;
+            break;
+         }
+         Ring(C, J) = Shared;
+      }
+      if (!RingOK)
+         break;
+      for (int J = N; J < ME; ++J)
+         Ring(C, J) = Ring(C, N - 1); // so that slot 0 finds its first vertex at index ME-1
+      for (int J = 0; J < N; ++J) {
+         const int E  = EdgesOnCellH(C, J);
+         const int Vb = Ring(C, J), Va = Ring(C, (J + N - 1) % N);
+         Real SV;
+         if (VerticesOnEdgeH(E, 1) == Vb && VerticesOnEdgeH(E, 0) == Va)
+            SV = 1.0;
+         else if (VerticesOnEdgeH(E, 0) == Vb && VerticesOnEdgeH(E, 1) == Va)
+            SV = -1.0;
+         else {
+            RingOK = false;
+            break;
+         }
+         const Real SC = CellsOnEdgeH(E, 0) == C ? 1.0 : -1.0;
+         if (CellsOnEdgeH(E, 0) != C && CellsOnEdgeH(E, 1) != C)
+            RingOK = false;
+         GradS(C, J) = EdgeMask1DH(E) * SC;
+         IDcC(C, J)  = 1. / DcEdgeH(E);
+         CurlC(C, J) = -SV * InvDv2(E);
+      }
+   }
+   HostArrayI4 NbrV(NVerticesSize, VD, 1, NVerticesAll), Sel(NVerticesSize, VD, 1, 0);
+   HostArrayReal MaskV(NVerticesSize, VD, 1, 0.0), IDcV(NVerticesSize, VD, 1, 0.0), CurlV(NVerticesSize, VD, 1, 0.0);
+   bool VertOK = VD == 3;
+   for (int V = 0; V < NVerticesAll && VertOK; ++V)
+      for (int J = 0; J < VD; ++J) {
+         const int E = EdgesOnVertexH(V, J);
+         if (E >= NEdgesAll) { // no such edge here: the term must vanish through its coefficient
+            if (EdgeSignOnVertexH(V, J) != 0.0)
+               VertOK = false;
+            NbrV(V, J) = V;
+            continue;
+         }
+         Real SV;
+         if (VerticesOnEdgeH(E, 0) == V)
+            SV = 1.0, NbrV(V, J) = VerticesOnEdgeH(E, 1);
+         else if (VerticesOnEdgeH(E, 1) == V)
+            SV = -1.0, NbrV(V, J) = VerticesOnEdgeH(E, 0);
+         else {
+            VertOK = false;
+            break;
+         }
+         int S0 = -1, S1 = -1;
+         for (int A = 0; A < VD; ++A) {
+            if (S0 < 0 && CellsOnVertexH(V, A) == CellsOnEdgeH(E, 0))
+               S0 = A;
+            if (S1 < 0 && CellsOnVertexH(V, A) == CellsOnEdgeH(E, 1))
+               S1 = A;
+         }
+         if (S0 < 0 || S1 < 0) {
+            VertOK = false;
+            break;
+         }
+         Sel(V, J)   = S0 | (S1 << 2);
+         MaskV(V, J) = EdgeMask1DH(E);
+         IDcV(V, J)  = 1. / DcEdgeH(E);
+         CurlV(V, J) = -SV * InvDv2(E);
+      }
+   VertRingOnCell       = createDeviceMirrorCopy<I4, 2>("VertRingOnCell", Ring);
+   Del2GradMaskSOnCell  = createDeviceMirrorCopy<Real, 2>("Del2GradMaskSOnCell", GradS);
+   InvDcOnCell          = createDeviceMirrorCopy<Real, 2>("InvDcOnCell", IDcC);
+   Del2CurlCoefOnCell   = createDeviceMirrorCopy<Real, 2>("Del2CurlCoefOnCell", CurlC);
+   NbrVertOnVertex      = createDeviceMirrorCopy<I4, 2>("NbrVertOnVertex", NbrV);
+   Del2SelOnVertex      = createDeviceMirrorCopy<I4, 2>("Del2SelOnVertex", Sel);
+   Del2MaskOnVertex     = createDeviceMirrorCopy<Real, 2>("Del2MaskOnVertex", MaskV);
+   InvDcOnVertex        = createDeviceMirrorCopy<Real, 2>("InvDcOnVertex", IDcV);
+   Del2CurlCoefOnVertex = createDeviceMirrorCopy<Real, 2>("Del2CurlCoefOnVertex", CurlV);
+   W.Del2RingOK = RingOK ? 1 : 0, W.Del2VertOK = VertOK ? 1 : 0;
+   W.VertRingOnCell = VertRingOnCell.Ptr, W.Del2GradMaskSOnCell = Del2GradMaskSOnCell.Ptr;
+   W.InvDcOnCell = InvDcOnCell.Ptr, W.Del2CurlCoefOnCell = Del2CurlCoefOnCell.Ptr;
+   W.NbrVertOnVertex = NbrVertOnVertex.Ptr, W.Del2SelOnVertex = Del2SelOnVertex.Ptr;
+   W.Del2MaskOnVertex = Del2MaskOnVertex.Ptr, W.InvDcOnVertex = InvDcOnVertex.Ptr;
+   W.Del2CurlCoefOnVertex = Del2CurlCoefOnVertex.Ptr;
 }
 
 // Cell-centric PV tables (see HorzMesh.h).
@@ -432,6 +544,23 @@ void HorzMesh::buildCellPV() {
          }
       }
    }
+   // orientation of each regular cell's edges against its ring (for the fused side-1 + final pass)
+   HostArrayReal RSign(NCellsSize, ME, 1, 1.0);
+   bool FinalOK = OK;
+   for (int C = 0; C < NCellsAll && FinalOK; ++C)
+      for (int Kk = 0; Kk < ME; ++Kk) {
+         if (Role(C, Kk) == 0)
+            continue;
+         const int E = EdgesOnCellH(C, Kk), Vb = Ring(C, Kk), Va = Ring(C, (Kk + ME - 1) % ME);
+         if (VerticesOnEdgeH(E, 1) == Vb && VerticesOnEdgeH(E, 0) == Va)
+            RSign(C, Kk) = 1.0;
+         else if (VerticesOnEdgeH(E, 0) == Vb && VerticesOnEdgeH(E, 1) == Va)
+            RSign(C, Kk) = -1.0;
+         else
+            FinalOK = false;
+      }
+   RingSignOnCell = createDeviceMirrorCopy<Real, 2>("RingSignOnCell", RSign);
+   W.RingSignOnCell = RingSignOnCell.Ptr, W.CellPVFinalOK = FinalOK ? 1 : 0;
    RingVertOnCell = createDeviceMirrorCopy<I4, 2>("RingVertOnCell", Ring);
    PVRoleOnCell   = createDeviceMirrorCopy<I4, 2>("PVRoleOnCell", Role);
    PVWeightOnCell = createDeviceMirrorCopy<Real, 3>("PVWeightOnCell", Wt);

@@ -48,6 +48,23 @@ struct MeshView {
    const Real *InvDcEdge;          // [E]      1/DcEdge
    const Real *InvDvEdge;          // [E]      1/DvEdge
    const Real *InvDvEdgeDel2;      // [E]      1/max(DvEdge, 0.25*DcEdge)
+   // ---- ring form of the velocity-del2 stencils (HorzMesh::buildDel2Tables) ----
+   // Cell c, edge slot j: the del2 of the edge needs Div at the cell across (and c itself) and
+   // RelVort at the edge's two end vertices, which are ring vertices j-1 and j of the cell, so a
+   // thread gathers ME+1 Div rows and ME RelVort rows instead of 4*ME.  Orientation lives in the
+   // coefficients (x -1 commutes with rounding): Mask*GradDiv == Del2GradMaskSOnCell*((Dn-Ds)*InvDc).
+   I4 Del2RingOK, Del2VertOK;
+   const I4 *VertRingOnCell;          // [C][ME] vertex shared by edge slots j and j+1 (cyclic in NEdgesOnCell)
+   const Real *Del2GradMaskSOnCell;   // [C][ME] EdgeMask * (+1 if c is CellsOnEdge(e,0) else -1)
+   const Real *InvDcOnCell;           // [C][ME] 1/DcEdge
+   const Real *Del2CurlCoefOnCell;    // [C][ME] -(+1 if ring vertex j is VerticesOnEdge(e,1) else -1) * InvDvEdgeDel2
+   // Vertex v, edge slot j (VertexDegree 3): Div at CellsOnVertex(v,0..2), RelVort at v and at the
+   // vertex across each edge: 7 gathers instead of 12.
+   const I4 *NbrVertOnVertex;         // [V][3] other end of edge slot j
+   const I4 *Del2SelOnVertex;         // [V][3] slot in CellsOnVertex of CellsOnEdge(e,0) | slot of CellsOnEdge(e,1) << 2
+   const Real *Del2MaskOnVertex;      // [V][3] EdgeMask
+   const Real *InvDcOnVertex;         // [V][3] 1/DcEdge
+   const Real *Del2CurlCoefOnVertex;  // [V][3] -(+1 if the other end is VerticesOnEdge(e,1) else -1) * InvDvEdgeDel2
    const I4 *PVStencil;            // [E][ME2][4] CellsOnEdge / VerticesOnEdge of EdgesOnEdge(e,j)
    // Chain form of the PotentialVortHAdvOnEdge stencil (valid when PVChainOK): side s = 0,1 is
    // cell CellsOnEdge(e,s); its other edges e'_1..e'_{n-1} in EdgesOnEdge order are
@@ -65,8 +82,9 @@ struct MeshView {
    // neighbour cells and vertices), so one thread per cell can produce the side sums of all its
    // edges from 4*MaxEdges+1 gathers.  Side 0 sums start from zero, side 1 sums continue from the
    // stored side 0 value: the additions happen in the reference's order.
-   I4 CellPVOK, NIrregularEdges;
+   I4 CellPVOK, CellPVFinalOK, NIrregularEdges;
    const I4 *RingVertOnCell;       // [C][ME] vertex shared by edge slots k and k+1 (cyclic)
+   const Real *RingSignOnCell;     // [C][ME] +1 if ring vertex k is VerticesOnEdge(e_k,1) (and k-1 is (e_k,0)), -1 if reversed
    const I4 *PVRoleOnCell;         // [C][ME] 0 none, 1 this cell is cell 0 of a regular edge, 2 cell 1
    const Real *PVWeightOnCell;     // [C][ME][ME-1] WeightsOnEdge of edge slot k, this cell's side, in walk order
    const I4 *EdgeRegular;          // [E] 1 regular, 0 handled by the edge-centric kernel
@@ -143,13 +161,16 @@ class HorzMesh {
    Array2DReal DvSignOnCell, DivCoefOnCell, KECoefOnCell, MaskDvSignOnCell, Del2TrCoefOnCell, Diff2CoefOnCell,
        Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex, Del2TrCoefSOnCell, Diff2CoefSOnCell, Diff4CoefSOnCell;
    DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
-   Array2DI4 NbrFlagOnCell;
+   Array2DReal RingSignOnCell;
+   Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
+   Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;
    DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;
    Array3DReal PVChainWeight;
    Array1DI4 EPListOff, EPList, CPListOff, CPList;
    DeviceArray<unsigned short, 1> EPLocal, CPLocal;
    void buildPatches();
    void buildCellPV();
+   void buildDel2Tables();
    Array2DI4 RingVertOnCell, PVRoleOnCell;
    Array3DReal PVWeightOnCell;
    Array1DI4 EdgeRegular, IrregularEdges;

@@ -314,6 +314,124 @@ struct FusedDel2VertexBody {
    }
 };
 
+// L2 cell pass, ring form (HorzMesh::buildDel2Tables): same arithmetic as FusedDel2CellBody with
+// every row gathered once -- Div at the cell and its TME neighbours, RelVort on its TME ring vertices.
+template <int TME> struct Del2CellRingBody {
+   MeshView M;
+   int K;
+   const Real *Div, *RelVort;
+   Real *Del2Div;
+   struct Lds {
+      Real *DivC, *InvDc, *GradS, *CurlC;
+      int *Nbr, *Ring;
+   };
+   size_t ldsBytes(int Tile) const { return ldsRound8(sizeof(Real) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile * TME) * 2; }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.DivC  = C.take<Real>(Tile * TME);
+      L.InvDc = C.take<Real>(Tile * TME);
+      L.GradS = C.take<Real>(Tile * TME);
+      L.CurlC = C.take<Real>(Tile * TME);
+      L.Nbr   = C.take<int>(Tile * TME);
+      L.Ring  = C.take<int>(Tile * TME);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const size_t G = (size_t)First * TME + I;
+         L.DivC[I]      = M.DivCoefOnCell[G];
+         L.InvDc[I]     = M.InvDcOnCell[G];
+         L.GradS[I]     = M.Del2GradMaskSOnCell[G];
+         L.CurlC[I]     = M.Del2CurlCoefOnCell[G];
+         L.Nbr[I]       = M.NbrFlagOnCell[G] & 0x3fffffff;
+         L.Ring[I]      = M.VertRingOnCell[G];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+      T Dn[TME], Rv[TME];
+#pragma unroll
+      for (int J = 0; J < TME; ++J) {
+         Dn[J] = ldo<T>(Div, rowOff<T>(L.Nbr[Le * TME + J], K, Kv));
+         Rv[J] = ldo<T>(RelVort, rowOff<T>(L.Ring[Le * TME + J], K, Kv));
+      }
+      const unsigned OffS = rowOff<T>(ICell, K, Kv);
+      const T Ds          = ldo<T>(Div, OffS);
+      T Tmp               = splat<T>(0.0);
+#pragma unroll
+      for (int J = 0; J < TME; ++J) {
+         const int I      = Le * TME + J;
+         const int Jm     = (J + TME - 1) % TME;
+         const T GradDiv  = (Dn[J] - Ds) * L.InvDc[I];     // x orientation, folded into GradS
+         const T CurlVort = (Rv[J] - Rv[Jm]) * L.CurlC[I]; // -(RelVort(v1) - RelVort(v0)) * InvDvEdgeDel2
+         const T Del2E    = L.GradS[I] * GradDiv + CurlVort;
+         Tmp -= L.DivC[I] * Del2E;
+      }
+      stnt<T>(Del2Div, OffS, Tmp);
+   }
+};
+
+// L2 vertex pass for VertexDegree 3, each row gathered once (7 instead of 12).
+struct Del2VertexSelBody {
+   MeshView M;
+   int K;
+   const Real *Div, *RelVort;
+   Real *Del2RelVort;
+   struct Lds {
+      Real *VortC, *InvDc, *Mask, *CurlC;
+      int *Cell, *NbrV, *Sel;
+   };
+   size_t ldsBytes(int Tile) const { return ldsRound8(sizeof(Real) * Tile * 3) * 4 + ldsRound8(sizeof(int) * Tile * 3) * 3; }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.VortC = C.take<Real>(Tile * 3);
+      L.InvDc = C.take<Real>(Tile * 3);
+      L.Mask  = C.take<Real>(Tile * 3);
+      L.CurlC = C.take<Real>(Tile * 3);
+      L.Cell  = C.take<int>(Tile * 3);
+      L.NbrV  = C.take<int>(Tile * 3);
+      L.Sel   = C.take<int>(Tile * 3);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      for (int I = Tid; I < Cnt * 3; I += NThr) {
+         const size_t G = (size_t)First * 3 + I;
+         L.VortC[I]     = M.VortCoefOnVertex[G];
+         L.InvDc[I]     = M.InvDcOnVertex[G];
+         L.Mask[I]      = M.Del2MaskOnVertex[G];
+         L.CurlC[I]     = M.Del2CurlCoefOnVertex[G];
+         L.Cell[I]      = M.CellsOnVertex[G];
+         L.NbrV[I]      = M.NbrVertOnVertex[G];
+         L.Sel[I]       = M.Del2SelOnVertex[G];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int IVertex, int Kv) const {
+      T D[3], Rn[3];
+#pragma unroll
+      for (int J = 0; J < 3; ++J) {
+         D[J]  = ldo<T>(Div, rowOff<T>(L.Cell[Le * 3 + J], K, Kv));
+         Rn[J] = ldo<T>(RelVort, rowOff<T>(L.NbrV[Le * 3 + J], K, Kv));
+      }
+      const unsigned OffS = rowOff<T>(IVertex, K, Kv);
+      const T Rs          = ldo<T>(RelVort, OffS);
+      T Tmp               = splat<T>(0.0);
+#pragma unroll
+      for (int J = 0; J < 3; ++J) {
+         const int I  = Le * 3 + J;
+         const int S  = L.Sel[I];
+         const int S0 = S & 3, S1 = S >> 2;
+         const T D0   = pick(S0 == 0, D[0], pick(S0 == 1, D[1], D[2]));
+         const T D1   = pick(S1 == 0, D[0], pick(S1 == 1, D[1], D[2]));
+         const T GradDiv  = (D1 - D0) * L.InvDc[I];
+         const T CurlVort = (Rn[J] - Rs) * L.CurlC[I];
+         const T Del2E    = L.Mask[I] * GradDiv + CurlVort;
+         Tmp += L.VortC[I] * Del2E;
+      }
+      stnt<T>(Del2RelVort, OffS, Tmp);
+   }
+};
+
 // ---------------------------------------------------------------------------------------
 // L3 edge pass: every velocity term (TendencyTerms.h:81-334) in registers.  The edge-located
 // inputs of PotentialVortHAdvOnEdge at each EdgesOnEdge neighbour (FluxLayerThickEdge,
@@ -719,6 +837,146 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
             Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
          }
          sto<T>(Partial, OffE[I], Acc);
+      }
+   }
+};
+
+// Side-1 PV pass fused with the remaining velocity terms (default term set).  The cell-1 thread of
+// a regular edge finishes the PV sum, so it can go on with KE gradient, SSH gradient, del2 and del4
+// (TendencyTerms.h:110-265) in the reference's order and store the finished tendency: the running
+// sum is read once and never written back, and the separate edge pass disappears.  Everything the
+// extra terms need sits on the same ring: h / KE / Div / Del2Div at this cell and the cell across,
+// RelVort / Del2RelVort at ring vertices j-1 and j (orientation folded into InvDvS).
+template <int TME> struct CellPVFinalBody {
+   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int TM1      = TME - 1;
+   MeshView M;
+   int K;
+   TendParams P;
+   const Real *H, *U, *NormRelVortV, *NormPlanetVortV, *Partial;
+   const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort;
+   Real *Tend;
+   struct Lds {
+      Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs;
+      int *Edge, *NbrF, *Ring, *Role;
+   };
+   size_t ldsBytes(int Tile) const {
+      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) * 5 +
+             ldsRound8(sizeof(Real) * Tile) + ldsRound8(sizeof(int) * Tile * TME) * 4;
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.Wt     = C.take<Real>(Tile * TME * TM1);
+      L.InvDc  = C.take<Real>(Tile * TME);
+      L.InvDvS = C.take<Real>(Tile * TME);
+      L.C2     = C.take<Real>(Tile * TME);
+      L.C4     = C.take<Real>(Tile * TME);
+      L.BDn    = C.take<Real>(Tile * TME);
+      L.BDs    = C.take<Real>(Tile);
+      L.Edge   = C.take<int>(Tile * TME);
+      L.NbrF   = C.take<int>(Tile * TME);
+      L.Ring   = C.take<int>(Tile * TME);
+      L.Role   = C.take<int>(Tile * TME);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
+         L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const size_t G = (size_t)First * TME + I;
+         const int E    = M.EdgesOnCell[G];
+         const int F    = M.NbrFlagOnCell[G];
+         const Real Mask = M.EdgeMask1D[E];
+         L.Edge[I]      = E;
+         L.NbrF[I]      = F;
+         L.Ring[I]      = M.RingVertOnCell[G];
+         L.Role[I]      = M.PVRoleOnCell[G];
+         L.InvDc[I]     = M.InvDcEdge[E];
+         L.InvDvS[I]    = M.RingSignOnCell[G] * M.InvDvEdge[E];
+         L.C2[I]        = Mask * P.ViscDel2 * M.MeshScalingDel2[E];
+         L.C4[I]        = Mask * P.ViscDel4 * M.MeshScalingDel4[E];
+         L.BDn[I]       = M.BottomDepth[F & 0x3fffffff];
+      }
+      for (int I = Tid; I < Cnt; I += NThr)
+         L.BDs[I] = M.BottomDepth[First + I];
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+      bool Any = false;
+#pragma unroll
+      for (int J = 0; J < TME; ++J)
+         Any |= L.Role[Le * TME + J] == 2;
+      if (!Any)
+         return;
+      const Real Grav = 9.80665; // TendencyTerms.h:176
+      unsigned OffE[TME], OffN[TME], OffV[TME];
+      T Uj[TME], Flux[TME], QRe[TME], QFe[TME], Hn[TME];
+      const unsigned OffS = rowOff<T>(ICell, K, Kv);
+      const T Hs          = ldo<T>(H, OffS);
+      {
+         T QR[TME], QF[TME];
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            OffE[J] = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
+            OffN[J] = rowOff<T>(L.NbrF[Le * TME + J] & 0x3fffffff, K, Kv);
+            OffV[J] = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
+            Uj[J]   = ldo<T>(U, OffE[J]);
+            Hn[J]   = ldo<T>(H, OffN[J]);
+            QR[J]   = ldo<T>(NormRelVortV, OffV[J]);
+            QF[J]   = ldo<T>(NormPlanetVortV, OffV[J]);
+         }
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            Flux[J]      = 0.5 * (Hs + Hn[J]);
+            const int Jm = (J + TME - 1) % TME;
+            QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
+            QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
+         }
+      }
+      T Acc[TME];
+#pragma unroll
+      for (int I = 0; I < TME; ++I) {
+         Acc[I] = splat<T>(0.0);
+         if (L.Role[Le * TME + I] != 2)
+            continue;
+         Acc[I] = ldo<T>(Partial, OffE[I]);
+#pragma unroll
+         for (int J = 1; J < TME; ++J) {
+            const int Kk     = (I + J) % TME;
+            const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
+            Acc[I] += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
+         }
+      }
+      // ---- remaining terms; this cell is CellsOnEdge(e,1) of every edge it finishes ----
+      T Rv[TME], R2[TME];
+#pragma unroll
+      for (int J = 0; J < TME; ++J) {
+         Rv[J] = ldo<T>(RelVort, OffV[J]);
+         R2[J] = ldo<T>(Del2RelVort, OffV[J]);
+      }
+      const T KEs = ldo<T>(KE, OffS), DivS = ldo<T>(Div, OffS), D2S = ldo<T>(Del2Div, OffS);
+      const T Ssh1 = Hs - L.BDs[Le];
+#pragma unroll
+      for (int I = 0; I < TME; ++I) {
+         const int Li = Le * TME + I;
+         if (L.Role[Li] != 2)
+            continue;
+         const int Im     = (I + TME - 1) % TME;
+         const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
+         T TendV          = splat<T>(0.0);
+         TendV += Acc[I]; // EdgeMask is 1 on a regular edge
+         TendV -= (KEs - ldo<T>(KE, OffN[I])) * InvDc;
+         const T Ssh0 = Hn[I] - L.BDn[Li];
+         TendV -= Grav * (Ssh1 - Ssh0) * InvDc;
+         {
+            const T Del2U = ((DivS - ldo<T>(Div, OffN[I])) * InvDc - (Rv[I] - Rv[Im]) * InvDvS);
+            TendV += L.C2[Li] * Del2U;
+         }
+         {
+            const T Del2U = (P.DivFactor * (D2S - ldo<T>(Del2Div, OffN[I])) * InvDc - (R2[I] - R2[Im]) * InvDvS);
+            TendV -= L.C4[Li] * Del2U;
+         }
+         stnt<T>(Tend, OffE[I], TendV);
       }
    }
 };
@@ -1397,13 +1655,23 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // L2 (only the del4 term consumes it)
    Mark(2);
    if (P.VelHyperDiffTendencyEnable) {
-      FusedDel2CellBody BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
-      launchTile(BC, M.NCellsAll, K, S);
+      if (M.Del2RingOK) {
+         Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+         launchTile(BC, M.NCellsAll, K, S);
+      } else {
+         FusedDel2CellBody BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+         launchTile(BC, M.NCellsAll, K, S);
+      }
    }
    Mark(3);
    if (P.VelHyperDiffTendencyEnable) {
-      FusedDel2VertexBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
-      launchTile(BV, M.NVerticesAll, K, S);
+      if (M.Del2VertOK) {
+         Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
+         launchTile(BV, M.NVerticesAll, K, S);
+      } else {
+         FusedDel2VertexBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
+         launchTile(BV, M.NVerticesAll, K, S);
+      }
    }
    // L3
    Mark(4);
@@ -1412,26 +1680,49 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // 2: LDS-patch edge kernel (kept for experiments)
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
+      bool Finished   = false;
       if (PVOn) {
          CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
          launchTile(B0, M.NCellsAll, K, S);
-         CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
-         launchTile(B1, M.NCellsAll, K, S);
+         static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
+         if (Fast && FuseFinal && M.CellPVFinalOK) {
+            CellPVFinalBody<TME> B1{M,
+                                    K,
+                                    P,
+                                    H,
+                                    U,
+                                    A.NormRelVortVertex,
+                                    A.NormPlanetVortVertex,
+                                    EdgeScratch,
+                                    A.RelVortVertex,
+                                    A.KineticEnergyCell,
+                                    A.VelocityDivCell,
+                                    A.Del2DivCell,
+                                    A.Del2RelVortVertex,
+                                    UTend};
+            launchTile(B1, M.NCellsAll, K, S);
+            Finished = true;
+         } else {
+            CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
+            launchTile(B1, M.NCellsAll, K, S);
+         }
       }
-      EdgeFinalBody<Fast> BF{M,
-                             K,
-                             P,
-                             H,
-                             U,
-                             EdgeScratch,
-                             A.RelVortVertex,
-                             A.KineticEnergyCell,
-                             A.VelocityDivCell,
-                             A.Del2DivCell,
-                             A.Del2RelVortVertex,
-                             A.NormalStressEdge,
-                             UTend};
-      launchTile(BF, M.NEdgesAll, K, S);
+      if (!Finished) {
+         EdgeFinalBody<Fast> BF{M,
+                                K,
+                                P,
+                                H,
+                                U,
+                                EdgeScratch,
+                                A.RelVortVertex,
+                                A.KineticEnergyCell,
+                                A.VelocityDivCell,
+                                A.Del2DivCell,
+                                A.Del2RelVortVertex,
+                                A.NormalStressEdge,
+                                UTend};
+         launchTile(BF, M.NEdgesAll, K, S);
+      }
       if (M.NIrregularEdges > 0) {
          FusedEdgeChainBody<TME, Fast> B{M,
                                          K,

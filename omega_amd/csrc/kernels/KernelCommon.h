@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
+#include "../Base.h"
+
 namespace OMEGA {
 
 typedef double dv2 __attribute__((ext_vector_type(2)));
@@ -101,7 +103,8 @@ struct Geom {
 };
 inline Geom makeGeom(int N, int K, int MaxW = 2) {
    Geom G;
-   G.W  = (K % 2 == 0 && MaxW >= 2) ? 2 : 1;
+   static const int EnvW = getenv("OMEGA_W") ? atoi(getenv("OMEGA_W")) : 2;
+   G.W  = (K % 2 == 0 && MaxW >= 2 && EnvW >= 2) ? 2 : 1;
    G.KV = K / G.W;
    // threadIdx.x spans ONE 128-byte line of a column (8 level-pairs, or 16 single levels) and
    // threadIdx.y the elements of the tile, so a workgroup issues every gather of its tile for one
@@ -176,10 +179,12 @@ template <class Body> void launchTile(const Body &B, int N, int K, hipStream_t S
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
          hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+         HIP_CHECK(hipGetLastError());
          return;
       }
    }
    hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+   HIP_CHECK(hipGetLastError());
 }
 
 } // namespace OMEGA
