@@ -36,6 +36,8 @@ WORKLOADS = {
     "qu30": (680, 680, 30.0e3, 80, 6, "QU30-sized planar periodic hex mesh 680x680 (462400 cells), 80L, 6 tracers"),
     "qu240": (84, 84, 240.0e3, 60, 2, "QU240-sized planar periodic hex mesh 84x84 (7056 cells), 60L, 2 tracers"),
     "ec30to60": (484, 484, 45.0e3, 60, 2, "EC30to60-sized planar mesh 484x484 (234256 cells), 60L, 2 tracers"),
+    "qu30_eighth": (340, 170, 30.0e3, 80, 6, "one eighth of the QU30-sized mesh (340x170 = 57800 cells), 80L, 6 tracers"),
+    "qu30_quarter": (340, 340, 30.0e3, 80, 6, "one quarter of the QU30-sized mesh (340x340 = 115600 cells), 80L, 6 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
 }
 
@@ -44,13 +46,20 @@ def algorithmic_bytes_per_cell_level(nt, kernel=None):
     """SURVEY.md 8(d) B_staged = 8*(39 + 5*NT) B per cell-level for the whole RHS (NE = 3NC,
     NV = 2NC); per kernel: the arrays that kernel must read / write once."""
     per_kernel = {
-        "VortVertexBody(L1 vertex)": 8 * (1 + 3 + 3 * 2),             # h, u -> 3 vertex arrays
-        "FusedCell1Body(L1 cell)": 8 * (3 + 1 + nt + 3 + nt),          # u, h, tr -> KE, Div, hTend, Del2Tr
-        "FusedDel2CellBody(L2 cell)": 8 * (1 + 2 + 1),                 # Div, RelVort -> Del2Div
-        "FusedDel2VertexBody(L2 vertex)": 8 * (1 + 2 + 2),             # Div, RelVort -> Del2RelVort
-        "FusedEdgeBody(L3 edge)": 8 * (3 + 1 + 3 * 2 + 3 + 2 + 3),     # u,h,3V,KE,Div,Del2Div,Del2RV -> uTend
-        "FusedCell3Body(L3 cell)": 8 * (nt + nt + 1 + 3 + nt),         # tr, Del2Tr, h, u -> trTend
+        "VortVertexBody": 8 * (1 + 3 + 3 * 2),                 # h, u -> 3 vertex arrays
+        "FusedCell1Body": 8 * (3 + 1 + nt + 3 + nt),            # u, h, tr -> KE, Div, hTend, Del2Tr
+        "Del2CellRingBody": 8 * (1 + 2 + 1),                    # Div, RelVort -> Del2Div
+        "Del2VertexSelBody": 8 * (1 + 2 + 2),                   # Div, RelVort -> Del2RelVort
+        "CellPVBody<side 0>": 8 * (3 + 1 + 2 * 2 + 3),          # u, h, 2 vertex arrays -> running PV sums
+        "CellPVFinalBody": 8 * (3 + 1 + 3 * 2 + 3 + 3 + 2 + 3),  # + sums, RelVort, KE, Div, Del2Div, Del2RV -> uTend
+        "FusedCell3Body": 8 * (nt + nt + 1 + 3 + nt),           # tr, Del2Tr, h, u -> trTend
     }
+    per_kernel["CellPVBody<side 0>+FusedCell3Body"] = 8 * (nt + nt + 1 + 3 + nt + 2 * 2 + 3)
+    per_kernel["FusedDel2CellBody"] = per_kernel["Del2CellRingBody"]
+    per_kernel["FusedDel2VertexBody"] = per_kernel["Del2VertexSelBody"]
+    per_kernel["CellPVBody<side 1>+EdgeFinalBody"] = per_kernel["CellPVFinalBody"] + 8 * (3 + 3 + 1)
+    for k in ("FusedEdgeChainBody", "FusedEdgeBody", "edgePatchKernel"):
+        per_kernel[k] = 8 * (3 + 1 + 3 * 2 + 3 + 2 + 3)         # u,h,3V,KE,Div,Del2Div,Del2RV -> uTend
     if kernel is None:
         return 8 * (39 + 5 * nt)
     return per_kernel[kernel]

@@ -502,14 +502,15 @@ class Tendencies:
 
     def collect_kernel_times(self):
         """[(kernel name, mean ms)] over the RHS evaluations recorded since kernel_timing(True)."""
-        ms = (C.c_double * 8)()
+        ms = (C.c_double * 16)()
         nk, ns = C.c_int(), C.c_int()
         _chk(lib().omg_tend_collect_kernel_times(self.h, ms, C.byref(nk), C.byref(ns)))
         L = lib()
         L.omg_tend_kernel_name.restype = C.c_char_p
         if ns.value == 0:
             return []
-        return [(L.omg_tend_kernel_name(i).decode(), ms[i] / ns.value) for i in range(nk.value)]
+        out = [(L.omg_tend_kernel_name(i).decode(), ms[i] / ns.value) for i in range(nk.value)]
+        return [(k, v) for k, v in out if k]
 
     def get(self, which: int) -> np.ndarray:
         m = self.mesh

@@ -29,6 +29,12 @@
 #define OMEGA_CELL_MAXW 2
 #endif
 
+#ifndef OMEGA_PVF_MINW
+#define OMEGA_PVF_MINW OMEGA_CELL_MINW
+#endif
+#ifndef OMEGA_C3_MINW
+#define OMEGA_C3_MINW OMEGA_CELL_MINW
+#endif
 #ifndef OMEGA_EDGE_MINW
 #define OMEGA_EDGE_MINW 2
 #endif
@@ -758,7 +764,7 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
       Real *Wt;
       int *Edge, *NbrF, *Ring, *Role;
    };
-   size_t ldsBytes(int Tile) const {
+   __host__ __device__ size_t ldsBytes(int Tile) const {
       return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(int) * Tile * TME) * 4;
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
@@ -841,6 +847,34 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
    }
 };
 
+// Two bodies over the same element range run back to back by the same thread.  Used to put the
+// side-0 PV sums in front of the tracer tendencies: both gather h on the cell's neighbours and u on
+// its edges, and issued from the same workgroup at the same time those rows cross the fabric once.
+template <class BA, class BB> struct SeqBody {
+   static constexpr int MinWaves = 2;
+   BA A;
+   BB B;
+   struct Lds {
+      typename BA::Lds a;
+      typename BB::Lds b;
+   };
+   size_t ldsBytes(int Tile) const { return A.ldsBytes(Tile) + B.ldsBytes(Tile); }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      Lds L;
+      L.a = A.carve(Ptr, Tile);
+      L.b = B.carve(Ptr + A.ldsBytes(Tile), Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      A.stage(L.a, First, Cnt, Tid, NThr);
+      B.stage(L.b, First, Cnt, Tid, NThr);
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int I, int Kv) const {
+      A.template compute<T>(L.a, Le, I, Kv);
+      B.template compute<T>(L.b, Le, I, Kv);
+   }
+};
+
 // Side-1 PV pass fused with the remaining velocity terms (default term set).  The cell-1 thread of
 // a regular edge finishes the PV sum, so it can go on with KE gradient, SSH gradient, del2 and del4
 // (TendencyTerms.h:110-265) in the reference's order and store the finished tendency: the running
@@ -848,7 +882,7 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
 // extra terms need sits on the same ring: h / KE / Div / Del2Div at this cell and the cell across,
 // RelVort / Del2RelVort at ring vertices j-1 and j (orientation folded into InvDvS).
 template <int TME> struct CellPVFinalBody {
-   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int MinWaves = OMEGA_PVF_MINW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
    int K;
@@ -1314,7 +1348,7 @@ static bool launchEdgePatch(const MeshView &M, int K, const TendParams &P, const
 // L3 cell pass: tracer tendencies (TendencyTerms.h:349-480) with HTracersEdge
 // (TracerAuxVars.h:25-59) and MeanLayerThickEdge rebuilt inline; tracer loop inside.
 template <int TME, bool Fast> struct FusedCell3Body {
-   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int MinWaves = OMEGA_C3_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    MeshView M;
    int K, NT;
@@ -1614,9 +1648,7 @@ static bool launchCell3Patch(const MeshView &M, int K, int NT, const TendParams 
    return true;
 }
 
-const char *const FusedKernelNames[FusedNumKernels] = {"VortVertexBody(L1 vertex)", "FusedCell1Body(L1 cell)",
-                                                       "FusedDel2CellBody(L2 cell)", "FusedDel2VertexBody(L2 vertex)",
-                                                       "FusedEdgeBody(L3 edge)", "FusedCell3Body(L3 cell)"};
+const char *FusedKernelNames[FusedNumKernels] = {"VortVertexBody", "FusedCell1Body", "", "", "", "", ""};
 
 /// Default.yml term set: every flag folds at compile time (see `Fast` above)
 static bool isDefaultTermSet(const TendParams &P) {
@@ -1655,6 +1687,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // L2 (only the del4 term consumes it)
    Mark(2);
    if (P.VelHyperDiffTendencyEnable) {
+      FusedKernelNames[2] = M.Del2RingOK ? "Del2CellRingBody" : "FusedDel2CellBody";
       if (M.Del2RingOK) {
          Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
          launchTile(BC, M.NCellsAll, K, S);
@@ -1665,6 +1698,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    Mark(3);
    if (P.VelHyperDiffTendencyEnable) {
+      FusedKernelNames[3] = M.Del2VertOK ? "Del2VertexSelBody" : "FusedDel2VertexBody";
       if (M.Del2VertOK) {
          Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
          launchTile(BV, M.NVerticesAll, K, S);
@@ -1675,15 +1709,31 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    // L3
    Mark(4);
+   bool Marked5 = false, Cell3Done = false;
+   FusedKernelNames[4] = "FusedEdgeChainBody", FusedKernelNames[5] = "";
    static const int EdgeMode = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
    // 0: cell-centric PV sums + edge finalize (default), 1: edge-centric chain kernel,
    // 2: LDS-patch edge kernel (kept for experiments)
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
+      FusedKernelNames[4] = "";
       if (PVOn) {
          CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
-         launchTile(B0, M.NCellsAll, K, S);
+         static const int FuseC3 = getenv("OMEGA_FUSE_PV0_CELL3") ? atoi(getenv("OMEGA_FUSE_PV0_CELL3")) : 0;
+         static const int CellMd = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
+         if (FuseC3 && NT > 0 && CellMd == 0) {
+            SeqBody<CellPVBody<TME, Fast, 0>, FusedCell3Body<TME, Fast>> B01{
+                B0, FusedCell3Body<TME, Fast>{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend}};
+            launchTile(B01, M.NCellsAll, K, S);
+            FusedKernelNames[4] = "CellPVBody<side 0>+FusedCell3Body";
+            Cell3Done           = true;
+         } else {
+            launchTile(B0, M.NCellsAll, K, S);
+            FusedKernelNames[4] = "CellPVBody<side 0>";
+         }
+         Mark(5);
+         Marked5 = true;
          static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
          if (Fast && FuseFinal && M.CellPVFinalOK) {
             CellPVFinalBody<TME> B1{M,
@@ -1701,13 +1751,15 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                     A.Del2RelVortVertex,
                                     UTend};
             launchTile(B1, M.NCellsAll, K, S);
-            Finished = true;
+            Finished            = true;
+            FusedKernelNames[5] = "CellPVFinalBody";
          } else {
             CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
             launchTile(B1, M.NCellsAll, K, S);
          }
       }
       if (!Finished) {
+         FusedKernelNames[5] = "CellPVBody<side 1>+EdgeFinalBody";
          EdgeFinalBody<Fast> BF{M,
                                 K,
                                 P,
@@ -1742,7 +1794,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          launchTile(B, M.NIrregularEdges, K, S);
       }
    } else if (EdgeMode == 2 && launchEdgePatch<TME, Fast>(M, K, P, A, UTend, H, U, S)) {
-      // LDS-patch edge kernel launched
+      FusedKernelNames[4] = "edgePatchKernel";
    } else if (M.PVChainOK) {
       FusedEdgeChainBody<TME, Fast> B{M,
                                       K,
@@ -1761,13 +1813,17 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                       nullptr};
       launchTile(B, M.NEdgesAll, K, S);
    } else {
+      FusedKernelNames[4] = "FusedEdgeBody";
       FusedEdgeBody B{M,       K,           P,           H,           U,
                       A.RelVortVertex, A.NormRelVortVertex, A.NormPlanetVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
                       A.Del2DivCell,   A.Del2RelVortVertex, A.NormalStressEdge,     UTend};
       launchTile(B, M.NEdgesAll, K, S);
    }
-   Mark(5);
-   if (NT > 0) {
+   if (!Marked5)
+      Mark(5);
+   Mark(6);
+   FusedKernelNames[6] = (NT > 0 && !Cell3Done) ? "FusedCell3Body" : "";
+   if (NT > 0 && !Cell3Done) {
       static const int CellMode = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
       // 0: per-thread gathers (FusedCell3Body); 1: LDS-patch kernel for the default term set
       if (!(CellMode == 1 && Fast && launchCell3Patch<TME>(M, K, NT, P, A, TrTend, H, U, Tr, S))) {
@@ -1775,7 +1831,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          launchTile(B, M.NCellsAll, K, S);
       }
    }
-   Mark(6);
+   Mark(7);
 }
 
 void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,

@@ -92,7 +92,7 @@ struct LdsCarver {
       return R;
    }
 };
-inline size_t ldsRound8(size_t B) { return ((B + 7) >> 3) << 3; }
+__host__ __device__ inline size_t ldsRound8(size_t B) { return ((B + 7) >> 3) << 3; }
 
 /// Launch geometry for an N-element, K-level sweep.
 struct Geom {

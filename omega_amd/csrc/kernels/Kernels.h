@@ -60,11 +60,13 @@ void launchTracerTendOnly(const MeshView &M, int K, int NT, const TendParams &P,
 
 // ---- fused RHS (Tendencies::computeAllTendencies): see FusedKernels.hip ----
 /// Kernel order (also the index of the optional timing events, Ev[i] recorded BEFORE kernel i,
-/// Ev[6] after the last): 0 vertex L1, 1 cell L1, 2 cell L2, 3 vertex L2, 4 edge L3, 5 cell L3.
-constexpr int FusedNumKernels = 6;
+/// Ev[7] after the last): 0 vertex L1, 1 cell L1, 2 cell L2, 3 vertex L2, 4 + 5 edge L3 (cell-centric
+/// PV: side-0 sums, then side-1 sums + remaining terms; otherwise one edge kernel in slot 4),
+/// 6 cell L3.  FusedKernelNames[i] is set by the launcher to the kernel actually used ("" = none).
+constexpr int FusedNumKernels = 7;
 /// MaxEdges in [5,8] and every array plane < 4 GiB (32-bit byte offsets inside a plane)
 bool fusedRHSSupported(const MeshView &M, int K);
-extern const char *const FusedKernelNames[FusedNumKernels];
+extern const char *FusedKernelNames[FusedNumKernels];
 void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
                     hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr);
