@@ -207,8 +207,22 @@ def main():
         ach = algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels / (ms * 1e-3) / 1e9
         rhs_ms = sum(m for _, m in ktimes)
         rhs_ach = algorithmic_bytes_per_cell_level(NT) * local_cell_levels / (rhs_ms * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE on this same command, gfx950 correction applied; profiles/): only valid for the
+        # workload and partition they were collected on
+        traffic = traffic_src = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_v4_bench_qu30_pmc.json")
+        if args.workload == "qu30" and N == 1 and not args.unfused and os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                pmc = json.load(fh)
+            for key, rec in pmc.items():
+                if isinstance(rec, dict) and key.split("<")[0] == name.split("<")[0].split("+")[0]:
+                    traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_v4_bench_qu30_pmc.json"
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(ms, 4),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels,
+                    "kernel_ms": round(ms, 4),
                     "kernels_ms": {k: round(v, 4) for k, v in ktimes},
                     "rhs": {"algorithmic_bytes_per_cell_level": algorithmic_bytes_per_cell_level(NT),
                             "ms": round(rhs_ms, 4), "achieved": round(rhs_ach, 1),
