@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--stepper", default="RungeKutta4")
     ap.add_argument("--halo-width", type=int, default=3)
     ap.add_argument("--no-del4", action="store_true", help="disable the two radius-2 (del4) terms")
+    ap.add_argument("--mesh", default="hex", help="hex (planar nx x ny) | icoN (icosahedral level N) | fibN (N cells)")
     a = ap.parse_args()
 
     import torch
@@ -40,11 +41,16 @@ def main():
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
 
     import omega_amd as oa
-    from omega_amd.meshgen import planar_hex, synthetic_state
+    from omega_amd.meshgen import planar_hex, synthetic_state, spherical_voronoi, icosahedral_points
     from oracle import oracle as O
     from tests.problem import Problem
 
-    g = planar_hex(a.nx, a.ny, 30.0e3)
+    if a.mesh == "hex":
+        g = planar_hex(a.nx, a.ny, 30.0e3)
+    elif a.mesh.startswith("ico"):
+        g = spherical_voronoi(points=icosahedral_points(int(a.mesh[3:])), lloyd=2)
+    else:
+        g = spherical_voronoi(int(a.mesh[3:]), lloyd=4)
     K, NT, dt = a.levels, a.tracers, 600.0
     gpu = a.mode == "gpu"
     if gpu:

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import omega_amd as oa
-from omega_amd.meshgen import planar_hex
+from omega_amd.meshgen import planar_hex, spherical_voronoi, icosahedral_points
 from oracle import oracle as O
 from tests.problem import Problem, max_rel_diff
 
@@ -48,12 +48,28 @@ CASES = [
     (16, 16, 30e3, 6, 2, {"VelHyperDiffTendencyEnable": 0, "TracerHyperDiffTendencyEnable": 0, "EddyDiff4": 3.0}),
     (16, 16, 30e3, 6, 2, {"EddyDiff4": 2.5e9, "PVTendencyEnable": 0, "KETendencyEnable": 0}),
     (16, 16, 30e3, 130, 1, {}),                                # KV = 65 > 64: level loop inside the thread
+    # spherical Voronoi meshes (stand-ins for BASELINE configs[1]: QU240 is a download):
+    ("ico3", 0, 0, 12, 2, {}),                                 # icosahedral, 642 cells: 12 pentagons, MaxEdges 6
+    ("fib1500", 0, 0, 10, 2, {}),                              # 1500 cells with pentagons AND heptagons, MaxEdges 7
+    ("ico4", 0, 0, 60, 2, {}),                                 # 2562 cells, 60 levels, T+S
 ]
+
+_SPHERES = {}
+
+
+def sphere(name):
+    """Spherical test meshes, generated once per session."""
+    if name not in _SPHERES:
+        if name.startswith("ico"):
+            _SPHERES[name] = spherical_voronoi(points=icosahedral_points(int(name[3:])), lloyd=2)
+        else:
+            _SPHERES[name] = spherical_voronoi(int(name[3:]), lloyd=4)
+    return _SPHERES[name]
 
 
 def _mk(case):
     nx, ny, dc, K, NT, cfg = case
-    P = Problem(planar_hex(nx, ny, dc), K, NT, config=cfg)
+    P = Problem(sphere(nx) if isinstance(nx, str) else planar_hex(nx, ny, dc), K, NT, config=cfg)
     if cfg.get("WindForcingTendencyEnable"):
         rng = np.random.default_rng(7)
         zs = np.zeros(P.mesh.NCellsSize)
@@ -107,6 +123,18 @@ def test_compute_all_tendencies(case, fused):
     check("TracerTend", P.tend.get(2)[: case[4]], trT[: case[4]], m.NCellsOwned)
 
 
+def test_sphere_meshes_take_the_fast_paths():
+    """Which kernel paths the spherical meshes exercise (HorzMesh table diagnostics): ring-form
+    del2 everywhere; cell-centric PV with the pentagons' edges on the edge-centric list."""
+    P = _mk(("ico3", 0, 0, 4, 1, {}))
+    assert P.mesh.get_int("Del2RingOK") == 1 and P.mesh.get_int("Del2VertOK") == 1
+    assert P.mesh.get_int("CellPVOK") == 1 and P.mesh.get_int("CellPVFinalOK") == 1
+    assert P.mesh.get_int("NIrregularEdges") == 12 * 5
+    P = _mk(("fib1500", 0, 0, 4, 1, {}))
+    assert P.mesh.get_int("MaxEdges") == 7 and P.mesh.get_int("Del2RingOK") == 1
+    assert P.mesh.get_int("CellPVOK") == 1
+
+
 def test_group_tendencies_fb_path():
     """computeThicknessTendencies / computeTracerTendencies / computeVelocityTendencies
     (the ForwardBackward stepper's calls, Tendencies.cpp:488-575)."""
@@ -138,6 +166,25 @@ def test_time_steppers(kind, okind):
         check(f"h step {step}", h, ost["h"][0], m.NCellsOwned)
         check(f"u step {step}", u, ost["u"][0], m.NEdgesOwned)
         check(f"tr step {step}", tr, ost["tr"][0], m.NCellsOwned)
+
+
+def test_rk4_on_the_sphere():
+    """Two RK4 steps on the icosahedral mesh (pentagon edges through the edge-centric list)."""
+    P = _mk(("ico3", 0, 0, 8, 2, {}))
+    dt = 600.0
+    st = oa.TimeStepper("RungeKutta4", dt, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    m = P.mesh
+    for step in range(2):
+        st.do_step(P.state)
+        oa.device_synchronize()
+        P.oracle.step("rk4", ost, dt)
+    h, u = P.state.copy_to_host(0)
+    tr = P.tracers.copy_to_host(0)
+    assert np.isfinite(ost["h"][0]).all() and np.isfinite(ost["u"][0]).all()
+    check("h", h, ost["h"][0], m.NCellsOwned)
+    check("u", u, ost["u"][0], m.NEdgesOwned)
+    check("tr", tr, ost["tr"][0], m.NCellsOwned)
 
 
 def test_known_answer_through_gpu():

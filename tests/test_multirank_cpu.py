@@ -56,6 +56,8 @@ def run_ranks(mode, world, extra=(), timeout=600):
     (2, ["--halo-width", 5, "--nx", 24, "--ny", 24]),
     (4, ["--no-del4", "--nx", 20, "--ny", 20, "--stepper", "RungeKutta2"]),
     (3, ["--no-del4", "--nx", 18, "--ny", 18, "--stepper", "Forward-Backward", "--levels", 3]),
+    (3, ["--no-del4", "--mesh", "ico3", "--levels", 3]),                # sphere, 12 pentagons, RCB in 3-D
+    (2, ["--halo-width", 5, "--mesh", "fib700", "--levels", 3, "--steps", 1]),  # pentagons + heptagons, del4 on
 ])
 def test_partitioned_oracle_matches_single_rank(world, extra):
     outs = run_ranks("cpu", world, extra)
