@@ -504,27 +504,30 @@ void HorzMesh::buildCellPV() {
    HostArrayReal Wt(NCellsSize, ME, MEm1, 0.0);
    bool OK = W.PVChainOK != 0;
    std::vector<I4> Irregular;
+   // valences the ring kernels are instantiated for: MaxEdges, MaxEdges-1 and (MaxEdges >= 6) MaxEdges-2
+   auto ValenceOK = [&](int N) { return N == ME || N == ME - 1 || (ME >= 6 && N == ME - 2); };
    if (OK) {
       for (int E = 0; E < NEdgesAll; ++E) {
          const int C0 = CellsOnEdgeH(E, 0), C1 = CellsOnEdgeH(E, 1);
-         const bool R = EdgeMask1DH(E) != 0.0 && C0 < NCellsAll && C1 < NCellsAll && NEdgesOnCellH(C0) == ME &&
-                        NEdgesOnCellH(C1) == ME;
+         const bool R = EdgeMask1DH(E) != 0.0 && C0 < NCellsAll && C1 < NCellsAll && ValenceOK(NEdgesOnCellH(C0)) &&
+                        ValenceOK(NEdgesOnCellH(C1));
          Reg(E) = R ? 1 : 0;
          if (!R)
             Irregular.push_back(E);
       }
       for (int C = 0; C < NCellsAll && OK; ++C) {
-         if (NEdgesOnCellH(C) != ME)
-            continue; // not an ME-gon: all its edges are irregular
-         for (int Kk = 0; Kk < ME; ++Kk) {
+         const int N = NEdgesOnCellH(C);
+         if (!ValenceOK(N))
+            continue; // all its edges are irregular
+         for (int Kk = 0; Kk < N; ++Kk) {
             const int E = EdgesOnCellH(C, Kk);
             if (E >= NEdgesAll || !Reg(E))
                continue;
             const int Sd = CellsOnEdgeH(E, 0) == C ? 0 : 1;
             Role(C, Kk)  = Sd + 1;
             // the chain of (E, Sd) must be the walk around this cell starting after slot Kk
-            for (int J = 1; J < ME; ++J) {
-               if (HostChE.V[((size_t)E * 2 + Sd) * MEm1 + J - 1] != EdgesOnCellH(C, (Kk + J) % ME))
+            for (int J = 1; J < N; ++J) {
+               if (HostChE.V[((size_t)E * 2 + Sd) * MEm1 + J - 1] != EdgesOnCellH(C, (Kk + J) % N))
                   OK = false;
                Wt.V[((size_t)C * ME + Kk) * MEm1 + J - 1] = HostChW.V[((size_t)E * 2 + Sd) * MEm1 + J - 1];
             }
@@ -534,9 +537,9 @@ void HorzMesh::buildCellPV() {
                OK = false;
             Ring(C, Kk) = V;
             // and the remaining chain vertices are the following ring vertices
-            for (int J = 1; J < ME; ++J) {
+            for (int J = 1; J < N; ++J) {
                const int Vj = HostChV.V[((size_t)E * 2 + Sd) * ME + J];
-               int &Slot    = Ring(C, (Kk + J) % ME);
+               int &Slot    = Ring(C, (Kk + J) % N);
                if (Slot != NVerticesAll && Slot != Vj)
                   OK = false;
                Slot = Vj;
@@ -547,11 +550,12 @@ void HorzMesh::buildCellPV() {
    // orientation of each regular cell's edges against its ring (for the fused side-1 + final pass)
    HostArrayReal RSign(NCellsSize, ME, 1, 1.0);
    bool FinalOK = OK;
-   for (int C = 0; C < NCellsAll && FinalOK; ++C)
-      for (int Kk = 0; Kk < ME; ++Kk) {
+   for (int C = 0; C < NCellsAll && FinalOK; ++C) {
+      const int N = NEdgesOnCellH(C);
+      for (int Kk = 0; Kk < N && Kk < ME; ++Kk) {
          if (Role(C, Kk) == 0)
             continue;
-         const int E = EdgesOnCellH(C, Kk), Vb = Ring(C, Kk), Va = Ring(C, (Kk + ME - 1) % ME);
+         const int E = EdgesOnCellH(C, Kk), Vb = Ring(C, Kk), Va = Ring(C, (Kk + N - 1) % N);
          if (VerticesOnEdgeH(E, 1) == Vb && VerticesOnEdgeH(E, 0) == Va)
             RSign(C, Kk) = 1.0;
          else if (VerticesOnEdgeH(E, 0) == Vb && VerticesOnEdgeH(E, 1) == Va)
@@ -559,6 +563,7 @@ void HorzMesh::buildCellPV() {
          else
             FinalOK = false;
       }
+   }
    RingSignOnCell = createDeviceMirrorCopy<Real, 2>("RingSignOnCell", RSign);
    W.RingSignOnCell = RingSignOnCell.Ptr, W.CellPVFinalOK = FinalOK ? 1 : 0;
    RingVertOnCell = createDeviceMirrorCopy<I4, 2>("RingVertOnCell", Ring);
@@ -568,6 +573,29 @@ void HorzMesh::buildCellPV() {
    IrregularEdges = Array1DI4("IrregularEdges", (int)std::max<size_t>(Irregular.size(), 1));
    if (!Irregular.empty())
       OMEGA::copyToDevice(IrregularEdges.Ptr, Irregular.data(), Irregular.size() * sizeof(I4));
+   std::vector<I4> CellsM1, CellsM2;
+   I4 NM0 = 0;
+   if (OK)
+      for (int C = 0; C < NCellsAll; ++C) {
+         const int N = NEdgesOnCellH(C);
+         bool Any    = false;
+         for (int Kk = 0; Kk < ME; ++Kk)
+            Any |= Role(C, Kk) != 0;
+         if (Any && N == ME)
+            ++NM0;
+         if (Any && N == ME - 1)
+            CellsM1.push_back(C);
+         if (Any && N == ME - 2)
+            CellsM2.push_back(C);
+      }
+   RingCellsM1 = Array1DI4("RingCellsM1", (int)std::max<size_t>(CellsM1.size(), 1));
+   RingCellsM2 = Array1DI4("RingCellsM2", (int)std::max<size_t>(CellsM2.size(), 1));
+   if (!CellsM1.empty())
+      OMEGA::copyToDevice(RingCellsM1.Ptr, CellsM1.data(), CellsM1.size() * sizeof(I4));
+   if (!CellsM2.empty())
+      OMEGA::copyToDevice(RingCellsM2.Ptr, CellsM2.data(), CellsM2.size() * sizeof(I4));
+   W.NRingCellsM0 = NM0, W.NRingCellsM1 = (I4)CellsM1.size(), W.NRingCellsM2 = (I4)CellsM2.size();
+   W.RingCellsM1 = RingCellsM1.Ptr, W.RingCellsM2 = RingCellsM2.Ptr;
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
    W.RingVertOnCell = RingVertOnCell.Ptr, W.PVRoleOnCell = PVRoleOnCell.Ptr, W.PVWeightOnCell = PVWeightOnCell.Ptr;
    W.EdgeRegular = EdgeRegular.Ptr, W.IrregularEdges = IrregularEdges.Ptr;

@@ -77,7 +77,8 @@ struct MeshView {
    const I4 *PVChainEdge;          // [E][2][ME-1]
    const Real *PVChainWeight;      // [E][2][ME-1]
    // ---- cell-centric form of the PV stencil (valid when CellPVOK; HorzMesh::buildCellPV) ----
-   // A "regular" edge has EdgeMask 1 and two MaxEdges-gons as cells.  For such an edge the side-s
+   // A "regular" edge has EdgeMask 1 and two local cells with MaxEdges-2 .. MaxEdges edges (the valences
+   // the ring kernels are instantiated for: mesh files carry maxEdges = 7 with 5-, 6- and 7-gons).  For such an edge the side-s
    // part of the PotentialVortHAdvOnEdge sum only needs data on the ring of cell s (its edges,
    // neighbour cells and vertices), so one thread per cell can produce the side sums of all its
    // edges from 4*MaxEdges+1 gathers.  Side 0 sums start from zero, side 1 sums continue from the
@@ -89,6 +90,9 @@ struct MeshView {
    const Real *PVWeightOnCell;     // [C][ME][ME-1] WeightsOnEdge of edge slot k, this cell's side, in walk order
    const I4 *EdgeRegular;          // [E] 1 regular, 0 handled by the edge-centric kernel
    const I4 *IrregularEdges;       // [NIrregularEdges]
+   // cells of the rarer valences that own regular edges: the ring kernels run once more over each list
+   I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges (no list: full sweep), MaxEdges-1, MaxEdges-2
+   const I4 *RingCellsM1, *RingCellsM2;
    // ---- LDS patches (HorzMesh::buildPatches): consecutive target elements grouped into patches;
    // per patch the UNIQUE rows its stencils reference, and per target element the stencil
    // re-expressed as indices into those lists, so a workgroup stages each row once in LDS ----
@@ -162,6 +166,7 @@ class HorzMesh {
        Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex, Del2TrCoefSOnCell, Diff2CoefSOnCell, Diff4CoefSOnCell;
    DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
    Array2DReal RingSignOnCell;
+   Array1DI4 RingCellsM1, RingCellsM2;
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;
    DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;

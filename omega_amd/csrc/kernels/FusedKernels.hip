@@ -752,7 +752,7 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
 // of ALL its edges (ME*(ME-1) terms), instead of 7..11 gathers per single term in the edge-centric
 // form.  Side = 0 launches first and stores the running sums; Side = 1 continues each sum from the
 // stored value, so the additions happen in exactly the reference's order.
-template <int TME, bool Fast, int Side> struct CellPVBody {
+template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
    static constexpr int MinWaves = OMEGA_CELL_MINW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
@@ -760,12 +760,14 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
    TendParams P;
    const Real *H, *U, *NormRelVortV, *NormPlanetVortV;
    Real *Partial; // [NEdgesSize][K] running PV sums
+   const int *List = nullptr; // optional cell list (the launches for the rarer valences)
    struct Lds {
       Real *Wt;
-      int *Edge, *NbrF, *Ring, *Role;
+      int *Edge, *NbrF, *Ring, *Role, *N;
    };
    __host__ __device__ size_t ldsBytes(int Tile) const {
-      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(int) * Tile * TME) * 4;
+      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(int) * Tile * TME) * 4 +
+             ldsRound8(sizeof(int) * Tile);
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
       LdsCarver C{Ptr};
@@ -775,35 +777,47 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
       L.NbrF = C.take<int>(Tile * TME);
       L.Ring = C.take<int>(Tile * TME);
       L.Role = C.take<int>(Tile * TME);
+      L.N    = C.take<int>(Tile);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
-      for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
-         L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
+         const int Le = I / (TME * TM1);
+         const int C  = List ? List[First + Le] : First + Le;
+         L.Wt[I]      = M.PVWeightOnCell[(size_t)C * TME * TM1 + (I - Le * TME * TM1)];
+      }
       for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
+         const int Le   = I / TME;
+         const int C    = List ? List[First + Le] : First + Le;
+         const size_t G = (size_t)C * TME + (I - Le * TME);
          L.Edge[I]      = M.EdgesOnCell[G];
          L.NbrF[I]      = M.NbrFlagOnCell[G];
          L.Ring[I]      = M.RingVertOnCell[G];
          L.Role[I]      = M.PVRoleOnCell[G];
       }
+      for (int I = Tid; I < Cnt; I += NThr)
+         L.N[I] = M.NEdgesOnCell[List ? List[First + I] : First + I];
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
-      const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
-      // does this cell own any side-`Side` sum?  (wave-uniform per column)
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      if (L.N[Le] != NR)
+         return; // the other valences have their own (list) launches
+      // does this cell own any side-`Side` sum?
       bool Any = false;
 #pragma unroll
-      for (int J = 0; J < TME; ++J)
+      for (int J = 0; J < NR; ++J)
          Any |= L.Role[Le * TME + J] == Side + 1;
       if (!Any)
          return;
-      unsigned OffE[TME];
-      T Uj[TME], Flux[TME], QRe[TME], QFe[TME];
+      constexpr int N = NR; // this launch's valence; table strides stay TME
+      const int ICell = List ? List[IElem] : IElem;
+      const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
+      unsigned OffE[N];
+      T Uj[N], Flux[N], QRe[N], QFe[N];
       {
-         T Hn[TME], QR[TME], QF[TME];
-         bool IsC0[TME];
+         T Hn[N], QR[N], QF[N];
+         bool IsC0[N];
 #pragma unroll
-         for (int J = 0; J < TME; ++J) {
+         for (int J = 0; J < N; ++J) {
             const int F = L.NbrF[Le * TME + J];
             IsC0[J]     = (F >> 30) != 0;
             OffE[J]     = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
@@ -815,31 +829,29 @@ template <int TME, bool Fast, int Side> struct CellPVBody {
          }
          const T Hs = ldo<T>(H, rowOff<T>(ICell, K, Kv));
 #pragma unroll
-         for (int J = 0; J < TME; ++J) {
+         for (int J = 0; J < N; ++J) {
             // FluxLayerThickEdge of edge slot J (LayerThicknessAuxVars.h:25-61)
             Flux[J] = 0.5 * (Hs + Hn[J]);
             if (FluxUpwind)
                Flux[J] = upwind(Uj[J], pick(IsC0[J], Hs, Hn[J]), pick(IsC0[J], Hn[J], Hs));
             // NormRelVortEdge / NormPlanetVortEdge of edge slot J: mean over its two end vertices,
             // ring vertices J-1 and J (VorticityAuxVars.h:61-76)
-            constexpr int Dummy = 0;
-            (void)Dummy;
-            const int Jm = (J + TME - 1) % TME;
+            const int Jm = (J + N - 1) % N;
             QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
             QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
          }
       }
 #pragma unroll
-      for (int I = 0; I < TME; ++I) {
+      for (int I = 0; I < N; ++I) {
          if (L.Role[Le * TME + I] != Side + 1)
             continue;
          T Acc = splat<T>(0.0);
          if (Side == 1)
             Acc = ldo<T>(Partial, OffE[I]);
 #pragma unroll
-         for (int J = 1; J < TME; ++J) {
-            const int Kk       = (I + J) % TME;
-            const T NormVort   = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
+         for (int J = 1; J < N; ++J) {
+            const int Kk     = (I + J) % N;
+            const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
             Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
          }
          sto<T>(Partial, OffE[I], Acc);
@@ -881,7 +893,7 @@ template <class BA, class BB> struct SeqBody {
 // sum is read once and never written back, and the separate edge pass disappears.  Everything the
 // extra terms need sits on the same ring: h / KE / Div / Del2Div at this cell and the cell across,
 // RelVort / Del2RelVort at ring vertices j-1 and j (orientation folded into InvDvS).
-template <int TME> struct CellPVFinalBody {
+template <int TME, int NR = TME> struct CellPVFinalBody {
    static constexpr int MinWaves = OMEGA_PVF_MINW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
@@ -890,13 +902,14 @@ template <int TME> struct CellPVFinalBody {
    const Real *H, *U, *NormRelVortV, *NormPlanetVortV, *Partial;
    const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort;
    Real *Tend;
+   const int *List = nullptr;
    struct Lds {
       Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs;
-      int *Edge, *NbrF, *Ring, *Role;
+      int *Edge, *NbrF, *Ring, *Role, *N;
    };
    size_t ldsBytes(int Tile) const {
       return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) * 5 +
-             ldsRound8(sizeof(Real) * Tile) + ldsRound8(sizeof(int) * Tile * TME) * 4;
+             ldsRound8(sizeof(Real) * Tile) + ldsRound8(sizeof(int) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile);
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
       LdsCarver C{Ptr};
@@ -912,45 +925,58 @@ template <int TME> struct CellPVFinalBody {
       L.NbrF   = C.take<int>(Tile * TME);
       L.Ring   = C.take<int>(Tile * TME);
       L.Role   = C.take<int>(Tile * TME);
+      L.N      = C.take<int>(Tile);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
-      for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
-         L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
-      for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
-         const int E    = M.EdgesOnCell[G];
-         const int F    = M.NbrFlagOnCell[G];
-         const Real Mask = M.EdgeMask1D[E];
-         L.Edge[I]      = E;
-         L.NbrF[I]      = F;
-         L.Ring[I]      = M.RingVertOnCell[G];
-         L.Role[I]      = M.PVRoleOnCell[G];
-         L.InvDc[I]     = M.InvDcEdge[E];
-         L.InvDvS[I]    = M.RingSignOnCell[G] * M.InvDvEdge[E];
-         L.C2[I]        = Mask * P.ViscDel2 * M.MeshScalingDel2[E];
-         L.C4[I]        = Mask * P.ViscDel4 * M.MeshScalingDel4[E];
-         L.BDn[I]       = M.BottomDepth[F & 0x3fffffff];
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
+         const int Le = I / (TME * TM1);
+         const int C  = List ? List[First + Le] : First + Le;
+         L.Wt[I]      = M.PVWeightOnCell[(size_t)C * TME * TM1 + (I - Le * TME * TM1)];
       }
-      for (int I = Tid; I < Cnt; I += NThr)
-         L.BDs[I] = M.BottomDepth[First + I];
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const int Le    = I / TME;
+         const int C     = List ? List[First + Le] : First + Le;
+         const size_t G  = (size_t)C * TME + (I - Le * TME);
+         const int E     = M.EdgesOnCell[G];
+         const int F     = M.NbrFlagOnCell[G];
+         const Real Mask = M.EdgeMask1D[E];
+         L.Edge[I]       = E;
+         L.NbrF[I]       = F;
+         L.Ring[I]       = M.RingVertOnCell[G];
+         L.Role[I]       = M.PVRoleOnCell[G];
+         L.InvDc[I]      = M.InvDcEdge[E];
+         L.InvDvS[I]     = M.RingSignOnCell[G] * M.InvDvEdge[E];
+         L.C2[I]         = Mask * P.ViscDel2 * M.MeshScalingDel2[E];
+         L.C4[I]         = Mask * P.ViscDel4 * M.MeshScalingDel4[E];
+         L.BDn[I]        = M.BottomDepth[F & 0x3fffffff];
+      }
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int C = List ? List[First + I] : First + I;
+         L.BDs[I]    = M.BottomDepth[C];
+         L.N[I]      = M.NEdgesOnCell[C];
+      }
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      if (L.N[Le] != NR)
+         return;
       bool Any = false;
 #pragma unroll
-      for (int J = 0; J < TME; ++J)
+      for (int J = 0; J < NR; ++J)
          Any |= L.Role[Le * TME + J] == 2;
       if (!Any)
          return;
+      constexpr int N = NR; // this launch's valence; table strides stay TME
+      const int ICell = List ? List[IElem] : IElem;
       const Real Grav = 9.80665; // TendencyTerms.h:176
-      unsigned OffE[TME], OffN[TME], OffV[TME];
-      T Uj[TME], Flux[TME], QRe[TME], QFe[TME], Hn[TME];
+      unsigned OffE[N], OffN[N], OffV[N];
+      T Uj[N], Flux[N], QRe[N], QFe[N], Hn[N];
       const unsigned OffS = rowOff<T>(ICell, K, Kv);
       const T Hs          = ldo<T>(H, OffS);
       {
-         T QR[TME], QF[TME];
+         T QR[N], QF[N];
 #pragma unroll
-         for (int J = 0; J < TME; ++J) {
+         for (int J = 0; J < N; ++J) {
             OffE[J] = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
             OffN[J] = rowOff<T>(L.NbrF[Le * TME + J] & 0x3fffffff, K, Kv);
             OffV[J] = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
@@ -960,42 +986,42 @@ template <int TME> struct CellPVFinalBody {
             QF[J]   = ldo<T>(NormPlanetVortV, OffV[J]);
          }
 #pragma unroll
-         for (int J = 0; J < TME; ++J) {
+         for (int J = 0; J < N; ++J) {
             Flux[J]      = 0.5 * (Hs + Hn[J]);
-            const int Jm = (J + TME - 1) % TME;
+            const int Jm = (J + N - 1) % N;
             QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
             QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
          }
       }
-      T Acc[TME];
+      T Acc[N];
 #pragma unroll
-      for (int I = 0; I < TME; ++I) {
+      for (int I = 0; I < N; ++I) {
          Acc[I] = splat<T>(0.0);
          if (L.Role[Le * TME + I] != 2)
             continue;
          Acc[I] = ldo<T>(Partial, OffE[I]);
 #pragma unroll
-         for (int J = 1; J < TME; ++J) {
-            const int Kk     = (I + J) % TME;
+         for (int J = 1; J < N; ++J) {
+            const int Kk     = (I + J) % N;
             const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
             Acc[I] += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
          }
       }
       // ---- remaining terms; this cell is CellsOnEdge(e,1) of every edge it finishes ----
-      T Rv[TME], R2[TME];
+      T Rv[N], R2[N];
 #pragma unroll
-      for (int J = 0; J < TME; ++J) {
+      for (int J = 0; J < N; ++J) {
          Rv[J] = ldo<T>(RelVort, OffV[J]);
          R2[J] = ldo<T>(Del2RelVort, OffV[J]);
       }
       const T KEs = ldo<T>(KE, OffS), DivS = ldo<T>(Div, OffS), D2S = ldo<T>(Del2Div, OffS);
       const T Ssh1 = Hs - L.BDs[Le];
 #pragma unroll
-      for (int I = 0; I < TME; ++I) {
+      for (int I = 0; I < N; ++I) {
          const int Li = Le * TME + I;
          if (L.Role[Li] != 2)
             continue;
-         const int Im     = (I + TME - 1) % TME;
+         const int Im     = (I + N - 1) % N;
          const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
          T TendV          = splat<T>(0.0);
          TendV += Acc[I]; // EdgeMask is 1 on a regular edge
@@ -1719,6 +1745,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       bool Finished   = false;
       FusedKernelNames[4] = "";
       if (PVOn) {
+         // the rarer valences (MaxEdges-1, MaxEdges-2: e.g. the pentagons of a mesh stored with
+         // maxEdges = 6 or 7) run the same ring code, instantiated for their size, over cell lists
+         constexpr int NM1 = TME - 1, NM2 = TME >= 6 ? TME - 2 : TME - 1;
          CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
          static const int FuseC3 = getenv("OMEGA_FUSE_PV0_CELL3") ? atoi(getenv("OMEGA_FUSE_PV0_CELL3")) : 0;
          static const int CellMd = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
@@ -1729,8 +1758,19 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             FusedKernelNames[4] = "CellPVBody<side 0>+FusedCell3Body";
             Cell3Done           = true;
          } else {
-            launchTile(B0, M.NCellsAll, K, S);
+            if (M.NRingCellsM0 > 0)
+               launchTile(B0, M.NCellsAll, K, S);
             FusedKernelNames[4] = "CellPVBody<side 0>";
+         }
+         if (M.NRingCellsM1 > 0) {
+            CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+                                             M.RingCellsM1};
+            launchTile(Bm, M.NRingCellsM1, K, S);
+         }
+         if (TME >= 6 && M.NRingCellsM2 > 0) {
+            CellPVBody<TME, Fast, 0, NM2> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+                                             M.RingCellsM2};
+            launchTile(Bm, M.NRingCellsM2, K, S);
          }
          Mark(5);
          Marked5 = true;
@@ -1750,12 +1790,36 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                     A.Del2DivCell,
                                     A.Del2RelVortVertex,
                                     UTend};
-            launchTile(B1, M.NCellsAll, K, S);
+            if (M.NRingCellsM0 > 0)
+               launchTile(B1, M.NCellsAll, K, S);
+            if (M.NRingCellsM1 > 0) {
+               CellPVFinalBody<TME, NM1> Bm{B1.M,   B1.K,       B1.P,  B1.H,   B1.U,       B1.NormRelVortV, B1.NormPlanetVortV,
+                                            B1.Partial, B1.RelVort, B1.KE, B1.Div, B1.Del2Div, B1.Del2RelVort,  B1.Tend,
+                                            M.RingCellsM1};
+               launchTile(Bm, M.NRingCellsM1, K, S);
+            }
+            if (TME >= 6 && M.NRingCellsM2 > 0) {
+               CellPVFinalBody<TME, NM2> Bm{B1.M,   B1.K,       B1.P,  B1.H,   B1.U,       B1.NormRelVortV, B1.NormPlanetVortV,
+                                            B1.Partial, B1.RelVort, B1.KE, B1.Div, B1.Del2Div, B1.Del2RelVort,  B1.Tend,
+                                            M.RingCellsM2};
+               launchTile(Bm, M.NRingCellsM2, K, S);
+            }
             Finished            = true;
             FusedKernelNames[5] = "CellPVFinalBody";
          } else {
             CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
-            launchTile(B1, M.NCellsAll, K, S);
+            if (M.NRingCellsM0 > 0)
+               launchTile(B1, M.NCellsAll, K, S);
+            if (M.NRingCellsM1 > 0) {
+               CellPVBody<TME, Fast, 1, NM1> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+                                                M.RingCellsM1};
+               launchTile(Bm, M.NRingCellsM1, K, S);
+            }
+            if (TME >= 6 && M.NRingCellsM2 > 0) {
+               CellPVBody<TME, Fast, 1, NM2> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+                                                M.RingCellsM2};
+               launchTile(Bm, M.NRingCellsM2, K, S);
+            }
          }
       }
       if (!Finished) {

@@ -168,7 +168,12 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
    __syncthreads();
    for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
       for (int Kv = threadIdx.x; Kv < KV; Kv += blockDim.x)
-         B.template compute<T>(L, Le, First + Le, Kv);
+{
+#ifdef OMEGA_KV_BARRIER
+            __asm__ volatile("" ::: "memory");
+#endif
+            B.template compute<T>(L, Le, First + Le, Kv);
+         }
 }
 
 template <class Body> void launchTile(const Body &B, int N, int K, hipStream_t S) {

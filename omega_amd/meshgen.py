@@ -478,3 +478,22 @@ def spherical_voronoi(n_cells: int = 0, *, points=None, radius: float = 6371220.
     m["bottomDepth"] = np.full(nC, bottom_depth)
     _trisk_edges_on_edge(m)
     return m
+
+
+def pad_max_edges(mesh: dict, max_edges: int) -> dict:
+    """The same mesh stored with a larger ``maxEdges`` dimension (mesh files often carry maxEdges = 7
+    or more than any cell uses); padding entries are -1 / 0 as in a file."""
+    old = mesh["maxEdges"]
+    assert max_edges >= old
+    out = dict(mesh)
+    out["maxEdges"] = max_edges
+    for name in ("edgesOnCell", "verticesOnCell", "cellsOnCell"):
+        a = np.full((mesh["nCells"], max_edges), -1, dtype=I4)
+        a[:, :old] = mesh[name]
+        out[name] = a
+    e = np.full((mesh["nEdges"], 2 * max_edges), -1, dtype=I4)
+    e[:, : 2 * old] = mesh["edgesOnEdge"]
+    w = np.zeros((mesh["nEdges"], 2 * max_edges))
+    w[:, : 2 * old] = mesh["weightsOnEdge"]
+    out["edgesOnEdge"], out["weightsOnEdge"] = e, w
+    return out

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import omega_amd as oa
-from omega_amd.meshgen import planar_hex, spherical_voronoi, icosahedral_points
+from omega_amd.meshgen import planar_hex, spherical_voronoi, icosahedral_points, pad_max_edges
 from oracle import oracle as O
 from tests.problem import Problem, max_rel_diff
 
@@ -52,6 +52,8 @@ CASES = [
     ("ico3", 0, 0, 12, 2, {}),                                 # icosahedral, 642 cells: 12 pentagons, MaxEdges 6
     ("fib1500", 0, 0, 10, 2, {}),                              # 1500 cells with pentagons AND heptagons, MaxEdges 7
     ("ico4", 0, 0, 60, 2, {}),                                 # 2562 cells, 60 levels, T+S
+    ("ico3pad8", 0, 0, 6, 1, {}),                              # same mesh stored with maxEdges = 8: pentagons
+                                                               # fall outside the ring kernels' valences
 ]
 
 _SPHERES = {}
@@ -60,7 +62,9 @@ _SPHERES = {}
 def sphere(name):
     """Spherical test meshes, generated once per session."""
     if name not in _SPHERES:
-        if name.startswith("ico"):
+        if name == "ico3pad8":
+            _SPHERES[name] = pad_max_edges(sphere("ico3"), 8)
+        elif name.startswith("ico"):
             _SPHERES[name] = spherical_voronoi(points=icosahedral_points(int(name[3:])), lloyd=2)
         else:
             _SPHERES[name] = spherical_voronoi(int(name[3:]), lloyd=4)
@@ -129,10 +133,13 @@ def test_sphere_meshes_take_the_fast_paths():
     P = _mk(("ico3", 0, 0, 4, 1, {}))
     assert P.mesh.get_int("Del2RingOK") == 1 and P.mesh.get_int("Del2VertOK") == 1
     assert P.mesh.get_int("CellPVOK") == 1 and P.mesh.get_int("CellPVFinalOK") == 1
-    assert P.mesh.get_int("NIrregularEdges") == 12 * 5
+    assert P.mesh.get_int("NIrregularEdges") == 0          # pentagons are handled by the 5-ring instantiation
     P = _mk(("fib1500", 0, 0, 4, 1, {}))
     assert P.mesh.get_int("MaxEdges") == 7 and P.mesh.get_int("Del2RingOK") == 1
-    assert P.mesh.get_int("CellPVOK") == 1
+    assert P.mesh.get_int("CellPVOK") == 1 and P.mesh.get_int("NIrregularEdges") == 0
+    P = _mk(("ico3pad8", 0, 0, 4, 1, {}))
+    assert P.mesh.get_int("MaxEdges") == 8 and P.mesh.get_int("CellPVOK") == 1
+    assert P.mesh.get_int("NIrregularEdges") == 12 * 5      # 5 < MaxEdges - 2: edge-centric list
 
 
 def test_group_tendencies_fb_path():
