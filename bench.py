@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--block", type=int, default=16, help="cell-ordering block size of the synthetic mesh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the reference-structured launch sequence instead")
+    ap.add_argument("--no-fuse-stages", action="store_true",
+                    help="RK4 with the separate update kernels instead of stage updates folded into the RHS kernels")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged rehearsal of the N>1 code path")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -188,6 +190,7 @@ def main():
     sypd = t_rk4 = None
     if nrk > 0:
         stepper = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
+        stepper.set_option("FuseStageUpdates", not args.no_fuse_stages)
         stepper.do_step(state, stream=stream)  # warm-up (allocations, RCCL connections)
         barrier()
         t1 = time.perf_counter()
@@ -242,7 +245,8 @@ def main():
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
                           "partition": f"rcb{N}", "halo_width": 3, "mesh_order": f"blocked{args.block}",
                           "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1)},
-               "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4},
+               "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
+                       "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels"},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if N > 1:

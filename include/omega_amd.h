@@ -191,6 +191,10 @@ int omg_stepper_create(const char *type, double time_step_seconds, omg_tend *t, 
                        omg_halo *halo, omg_tracers *tr, omg_stepper **out);
 int omg_stepper_destroy(omg_stepper *st);
 int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream);
+/* RungeKutta4 only: "FuseStageUpdates" (default 1: the stage updates of TimeStepper.cpp:378-524 run in the
+ * epilogue of the RHS kernels, same arithmetic) and "StoreStageTendencies" (default 0: with fused stages the
+ * Tendencies arrays are not written).  0 / 1. */
+int omg_stepper_set_option(omg_stepper *st, const char *name, int value);
 int omg_stepper_coeff_seconds(double mult, double time_step_seconds, double *out);
 
 #ifdef __cplusplus

@@ -538,6 +538,10 @@ class TimeStepper:
     def do_step(self, state: OceanState, stream=None):
         _chk(lib().omg_stepper_do_step(self.h, state.h, _sh(stream)))
 
+    def set_option(self, name: str, value: bool):
+        """RungeKutta4: "FuseStageUpdates" (default on), "StoreStageTendencies" (default off)."""
+        _chk(lib().omg_stepper_set_option(self.h, name.encode(), int(value)))
+
     def __del__(self):
         try:
             lib().omg_stepper_destroy(self.h)

@@ -98,6 +98,21 @@ void Tendencies::computeTracerTendencies(const OceanState *State, const Auxiliar
    computeTracerTendenciesOnly(State, Aux, TracerArray, ThickLvl, VelLvl, S);
 }
 // Tendencies.cpp:579-600
+bool Tendencies::computeAllTendenciesStage(const OceanState *State, const AuxiliaryState *Aux,
+                                           const Array3DReal &TracerArray, int ThickLvl, int VelLvl,
+                                           const StageUpdate &Stage, hipStream_t S) {
+   if (!(UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)))
+      return false;
+   Array2DReal LayerThick, NormVel;
+   OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
+                 "Tendencies: bad time level");
+   if (!EdgeScratch.Ptr)
+      EdgeScratch = Array2DReal("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
+   return launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
+                         NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, nullptr,
+                         EdgeScratch.Ptr, &Stage);
+}
+
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
                                       int ThickLvl, int VelLvl, hipStream_t S) {
    if (UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)) {

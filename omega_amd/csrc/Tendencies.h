@@ -38,6 +38,11 @@ class Tendencies {
                                   int VelTimeLevel, hipStream_t S);
    void computeTracerTendencies(const OceanState *State, const AuxiliaryState *AuxState,
                                 const Array3DReal &TracerArray, int ThickTimeLevel, int VelTimeLevel, hipStream_t S);
+   /// computeAllTendencies with a Runge-Kutta stage update folded into the kernels that produce the
+   /// tendencies (kernels/Kernels.h: StageUpdate).  Returns false -- nothing launched -- when the
+   /// stage-fused kernels do not cover this mesh / option set; the caller then uses the plain sequence.
+   bool computeAllTendenciesStage(const OceanState *State, const AuxiliaryState *AuxState, const Array3DReal &TracerArray,
+                                  int ThickTimeLevel, int VelTimeLevel, const StageUpdate &Stage, hipStream_t S);
    void computeAllTendencies(const OceanState *State, const AuxiliaryState *AuxState, const Array3DReal &TracerArray,
                              int ThickTimeLevel, int VelTimeLevel, hipStream_t S);
 

@@ -245,9 +245,68 @@ void RungeKutta4Stepper::finalizeInit() {
    ProvisTracers = Array3DReal("ProvisTracers", Trc->NTracers > 0 ? Trc->NTracers : 1, Mesh->NCellsSize, K);
 }
 
+// The same scheme with every stage's updates applied in the epilogue of the kernels that produce
+// the tendencies.  Stage s computes R = RHS(q_in) and, element by element,
+//    q^{n+1} (+)= RKB[s]*dt*R          (first stage: = q^n + ..., tracers thickness-weighted)
+//    q_out     = q^n + RKA[s+1]*dt*R   (the next stage's input; tracers divided by the new thickness)
+// which is what weightTracers / updateStateByTend / accumulateTracersUpdate / updateTracersByTend /
+// finalizeTracersUpdate do in separate sweeps.  q_in and q_out alternate between two buffers.
+bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
+   const int CurLevel = 0, NextLevel = 1;
+   const int NT = Trc->NTracers;
+   const int K  = Tend->LayerThicknessTend.Ext[1];
+   if (!ProvisState2) {
+      ProvisState2.reset(new OceanState("Provis2" + Name, Mesh, MeshHalo, K, 1));
+      ProvisTracers2 = Array3DReal("ProvisTracers2", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+   }
+   Array3DReal NextTr, CurTr;
+   Array2DReal CurH, CurU, NextH, NextU;
+   OMEGA_REQUIRE(Trc->getAll(CurTr, CurLevel) == 0 && Trc->getAll(NextTr, NextLevel) == 0,
+                 "RungeKutta4 doStep: error retrieving tracers");
+   State->getLayerThickness(CurH, CurLevel), State->getNormalVelocity(CurU, CurLevel);
+   State->getLayerThickness(NextH, NextLevel), State->getNormalVelocity(NextU, NextLevel);
+   OceanState *Prov[2]   = {ProvisState.get(), ProvisState2.get()};
+   Array3DReal *ProvT[2] = {&ProvisTracers, &ProvisTracers2};
+   for (int Stage = 0; Stage < NStages; ++Stage) {
+      StageUpdate Su;
+      Su.CB        = coeff(RKB[Stage]);
+      Su.CA        = Stage + 1 < NStages ? coeff(RKA[Stage + 1]) : 0.0;
+      Su.First     = Stage == 0;
+      Su.Last      = Stage == NStages - 1;
+      Su.StoreTend = StoreStageTendencies ? 1 : 0;
+      Su.NextH = NextH.Ptr, Su.NextU = NextU.Ptr, Su.NextTr = NextTr.Ptr;
+      Su.CurH = CurH.Ptr, Su.CurU = CurU.Ptr, Su.CurTr = CurTr.Ptr;
+      OceanState *Out = Prov[Stage % 2];
+      Array2DReal OutH, OutU;
+      Out->getLayerThickness(OutH, CurLevel), Out->getNormalVelocity(OutU, CurLevel);
+      Su.ProvH = OutH.Ptr, Su.ProvU = OutU.Ptr, Su.ProvTr = ProvT[Stage % 2]->Ptr;
+      bool Ok;
+      if (Stage == 0) {
+         Ok = Tend->computeAllTendenciesStage(State, AuxState, CurTr, CurLevel, CurLevel, Su, S);
+         if (!Ok)
+            return false; // nothing has been touched: the caller runs the plain sequence
+      } else {
+         OceanState *In = Prov[(Stage - 1) % 2];
+         if (Stage == 2 && MeshHalo && MeshHalo->NNghbr > 0) { // depends on the halo width (:107-113)
+            Array2DReal H, U;
+            In->getLayerThickness(H, CurLevel), In->getNormalVelocity(U, CurLevel);
+            OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? ProvT[(Stage - 1) % 2] : nullptr, NT, S) == 0,
+                          "RungeKutta4: provisional halo exchange failed");
+         }
+         Ok = Tend->computeAllTendenciesStage(In, AuxState, *ProvT[(Stage - 1) % 2], CurLevel, CurLevel, Su, S);
+         OMEGA_REQUIRE(Ok, "RungeKutta4: stage-fused RHS became unavailable mid-step");
+      }
+   }
+   updateTimeLevels(State, S);
+   ++NStepsDone;
+   return true;
+}
+
 void RungeKutta4Stepper::doStep(OceanState *State, hipStream_t S) {
    if (!ProvisState)
       finalizeInit();
+   if (FuseStageUpdates && doStepFused(State, S))
+      return;
    const int CurLevel = 0, NextLevel = 1;
    Array3DReal NextTracerArray, CurTracerArray;
    OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,

@@ -92,6 +92,19 @@ class RungeKutta4Stepper : public TimeStepper {
    R8 RKA[NStages], RKB[NStages], RKC[NStages];
    std::unique_ptr<OceanState> ProvisState;
    Array3DReal ProvisTracers;
+
+ public:
+   /// Fold the stage updates into the RHS kernels (kernels/Kernels.h: StageUpdate) when the fused RHS
+   /// covers the mesh / options: same arithmetic, element by element, without the 19 streaming update
+   /// launches per step.  The tendency arrays are then only stored if StoreStageTendencies is set.
+   bool FuseStageUpdates      = true;
+   bool StoreStageTendencies  = false;
+
+ protected:
+   /// second provisional buffer: a stage reads one and writes the other (neighbours still gather the input)
+   std::unique_ptr<OceanState> ProvisState2;
+   Array3DReal ProvisTracers2;
+   bool doStepFused(OceanState *State, hipStream_t S);
 };
 
 } // namespace OMEGA

@@ -807,6 +807,19 @@ int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream) {
    st->St->doStep(s->S.get(), (hipStream_t)stream);
    OMG_CATCH
 }
+int omg_stepper_set_option(omg_stepper *st, const char *name, int value) {
+   OMG_TRY
+   OMG_ARG(st && name);
+   auto *Rk4 = dynamic_cast<RungeKutta4Stepper *>(st->St.get());
+   const std::string N(name);
+   if (Rk4 && N == "FuseStageUpdates")
+      Rk4->FuseStageUpdates = value != 0;
+   else if (Rk4 && N == "StoreStageTendencies")
+      Rk4->StoreStageTendencies = value != 0;
+   else
+      OMEGA_ABORT("TimeStepper: no option named " + N + " for this scheme");
+   OMG_CATCH
+}
 int omg_stepper_coeff_seconds(double mult, double dt, double *out) {
    OMG_TRY
    OMG_ARG(out);

@@ -20,6 +20,7 @@
 #include "Kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // tuning knobs of the tracer cell kernels (VGPR budget / levels per thread)
 #ifndef OMEGA_CELL_MINW
@@ -65,6 +66,31 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
    __builtin_nontemporal_store(V, reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff));
 #endif
 }
+/// Device-side view of one variable's Runge-Kutta stage update (Kernels.h: StageUpdate)
+struct StageEpi {
+   Real CB = 0, CA = 0;
+   int First = 0, Last = 0, StoreTend = 0;
+   Real *Next      = nullptr;
+   const Real *Cur = nullptr;
+   Real *Prov      = nullptr;
+   const Real *CurH = nullptr, *ProvH = nullptr, *NextH = nullptr; // tracer kernel only
+};
+/// h / u: Next = (First ? Cur : Next) + CB*Tend; Prov = Cur + CA*Tend.  `CurIfFirst` is the RHS input at
+/// this element, which IS the current state in the first stage (HaveReg: the caller holds it in registers).
+template <class T, bool HaveReg>
+__device__ __forceinline__ void stageUpdate(const StageEpi &E, unsigned Off, T Tend, T CurIfFirst) {
+   const bool UseReg = HaveReg && E.First;
+   T Base;
+   if (E.First)
+      Base = UseReg ? CurIfFirst : ldo<T>(E.Cur, Off);
+   else
+      Base = ldo<T>(E.Next, Off);
+   stnt<T>(E.Next, Off, Base + E.CB * Tend);
+   if (!E.Last) {
+      const T Cur = E.First ? Base : ldo<T>(E.Cur, Off);
+      stnt<T>(E.Prov, Off, Cur + E.CA * Tend);
+   }
+}
 template <class T> __device__ __forceinline__ unsigned rowOff(int Row, int K, int Kv) {
    return ((unsigned)Row * (unsigned)K + (unsigned)Kv * (unsigned)VecW<T>::W) * 8u;
 }
@@ -98,7 +124,7 @@ __device__ __forceinline__ dv2 pick(bool C, dv2 A, dv2 B) { return C ? A : B; }
 // LayerThicknessAuxVars::computeVarsOnEdge inline (LayerThicknessAuxVars.h:25-61) feeding
 // ThicknessFluxDivOnCell (TendencyTerms.h:35-58), TracerAuxVars::computeVarsOnCells
 // (TracerAuxVars.h:61-91).
-template <int TME, bool Fast> struct FusedCell1Body {
+template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
    static constexpr int MinWaves = OMEGA_CELL_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    MeshView M;
@@ -107,6 +133,7 @@ template <int TME, bool Fast> struct FusedCell1Body {
    int DoDel2Tr;
    const Real *H, *U, *Tr;
    Real *KE, *Div, *HTend, *Del2Tr;
+   StageEpi E{}; // thickness stage update (EPI)
    struct Lds {
       Real *KEC, *DivC, *DvS, *D2T, *InvA;
       int *Edge, *NbrF;
@@ -175,7 +202,10 @@ template <int TME, bool Fast> struct FusedCell1Body {
       T HT = splat<T>(0.0);
       if (ThickOn)
          HT -= HDivTmp;
-      stnt<T>(HTend, OffS, HT);
+      if (!EPI || E.StoreTend)
+         stnt<T>(HTend, OffS, HT);
+      if (EPI)
+         stageUpdate<T, true>(E, OffS, HT, Hs);
       if (DoDel2Tr) {
          const size_t CStride = (size_t)M.NCellsSize * K;
 #pragma nounroll
@@ -585,7 +615,7 @@ struct FusedEdgeBody {
 // that cell as one of their two cells, so per side only the chain's vertices and the far cells
 // are gathered (a+b == b+a exactly, so which end vertex / cell comes first does not matter for
 // the means; the upwind choice keeps its flag).
-template <int TME, bool Fast> struct FusedEdgeChainBody {
+template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
    static constexpr int MinWaves = OMEGA_EDGE_MINW;
    static constexpr int MaxW     = OMEGA_EDGE_MAXW;
    static constexpr int TM1      = TME - 1;
@@ -596,6 +626,7 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
    const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
    Real *Tend;
    const I4 *EdgeList = nullptr; ///< if set, element i of the sweep is edge EdgeList[i]
+   StageEpi E{};                 ///< velocity stage update (EPI)
    __device__ int edgeOf(int I) const { return EdgeList ? EdgeList[I] : I; }
    struct Lds {
       Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
@@ -739,7 +770,11 @@ template <int TME, bool Fast> struct FusedEdgeChainBody {
          setc(TendV, Comp,
               getc(TendV, Comp) - L.Mask[Le] * P.BottomDragCoeff * VelNormEdge * InvThickEdge * U[(size_t)IEdge * K + KBot]);
       }
-      sto<T>(Tend, rowOff<T>(IEdge, K, Kv), TendV);
+      const unsigned OffT = rowOff<T>(IEdge, K, Kv);
+      if (!EPI || E.StoreTend)
+         sto<T>(Tend, OffT, TendV);
+      if (EPI)
+         stageUpdate<T, false>(E, OffT, TendV, TendV);
    }
 };
 
@@ -893,7 +928,7 @@ template <class BA, class BB> struct SeqBody {
 // sum is read once and never written back, and the separate edge pass disappears.  Everything the
 // extra terms need sits on the same ring: h / KE / Div / Del2Div at this cell and the cell across,
 // RelVort / Del2RelVort at ring vertices j-1 and j (orientation folded into InvDvS).
-template <int TME, int NR = TME> struct CellPVFinalBody {
+template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
    static constexpr int MinWaves = OMEGA_PVF_MINW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
@@ -903,6 +938,7 @@ template <int TME, int NR = TME> struct CellPVFinalBody {
    const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort;
    Real *Tend;
    const int *List = nullptr;
+   StageEpi E{}; // velocity stage update (EPI)
    struct Lds {
       Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs;
       int *Edge, *NbrF, *Ring, *Role, *N;
@@ -1036,7 +1072,10 @@ template <int TME, int NR = TME> struct CellPVFinalBody {
             const T Del2U = (P.DivFactor * (D2S - ldo<T>(Del2Div, OffN[I])) * InvDc - (R2[I] - R2[Im]) * InvDvS);
             TendV -= L.C4[Li] * Del2U;
          }
-         stnt<T>(Tend, OffE[I], TendV);
+         if (!EPI || E.StoreTend)
+            stnt<T>(Tend, OffE[I], TendV);
+         if (EPI)
+            stageUpdate<T, true>(E, OffE[I], TendV, Uj[I]);
       }
    }
 };
@@ -1373,7 +1412,7 @@ static bool launchEdgePatch(const MeshView &M, int K, const TendParams &P, const
 // ---------------------------------------------------------------------------------------
 // L3 cell pass: tracer tendencies (TendencyTerms.h:349-480) with HTracersEdge
 // (TracerAuxVars.h:25-59) and MeanLayerThickEdge rebuilt inline; tracer loop inside.
-template <int TME, bool Fast> struct FusedCell3Body {
+template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
    static constexpr int MinWaves = OMEGA_C3_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    MeshView M;
@@ -1381,6 +1420,7 @@ template <int TME, bool Fast> struct FusedCell3Body {
    TendParams P;
    const Real *H, *U, *Tr, *Del2Tr;
    Real *Tend;
+   StageEpi E{}; // tracer stage update (EPI)
    struct Lds {
       Real *MDvS, *Df2, *Df4, *InvA;
       int *Edge, *NbrF;
@@ -1432,6 +1472,17 @@ template <int TME, bool Fast> struct FusedCell3Body {
       }
       const T Hs = ldo<T>(H, OffS);
       const size_t CStride = (size_t)M.NCellsSize * K;
+      // stage update (EPI): thicknesses this cell's tracer update divides / multiplies by
+      T EpCurH = Hs, EpDivH = Hs;
+      if (EPI) {
+         if (!E.Last) {
+            if (!E.First)
+               EpCurH = ldo<T>(E.CurH, OffS);
+            EpDivH = ldo<T>(E.ProvH, OffS);
+         } else {
+            EpDivH = ldo<T>(E.NextH, OffS);
+         }
+      }
 #pragma nounroll
       for (int Lt = 0; Lt < NT; ++Lt) {
          const Real *TrL = uniformPtr(Tr + Lt * CStride);
@@ -1487,7 +1538,21 @@ template <int TME, bool Fast> struct FusedCell3Body {
             TendV += P.EddyDiff2 * DiffTmp * InvA;
          if (HypOn)
             TendV -= P.EddyDiff4 * HypTmp * InvA;
-         stnt<T>(uniformPtr(Tend + Lt * CStride), OffS, TendV);
+         if (!EPI || E.StoreTend)
+            stnt<T>(uniformPtr(Tend + Lt * CStride), OffS, TendV);
+         if (EPI) {
+            Real *NextL = uniformPtr(E.Next + Lt * CStride);
+            // weightTracers + accumulateTracersUpdate (+ finalizeTracersUpdate in the last stage)
+            T Acc = E.First ? T(Ts * Hs) : ldo<T>(NextL, OffS);
+            Acc   = Acc + E.CB * TendV;
+            if (E.Last)
+               Acc = Acc / EpDivH;
+            stnt<T>(NextL, OffS, Acc);
+            if (!E.Last) { // updateTracersByTend: (CurTr*CurH + CA*Tend) / ProvH
+               const T CurT = E.First ? Ts : ldo<T>(uniformPtr(E.Cur + Lt * CStride), OffS);
+               stnt<T>(uniformPtr(E.Prov + Lt * CStride), OffS, (CurT * EpCurH + E.CA * TendV) / EpDivH);
+            }
+         }
       }
    }
 };
@@ -1693,7 +1758,19 @@ bool fusedRHSSupported(const MeshView &M, int K) {
 template <int TME, bool Fast>
 static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
                          Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                         hipEvent_t *Ev, Real *EdgeScratch) {
+                         hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage) {
+   // Runge-Kutta stage update folded into the tendency-producing kernels (Fast term set only;
+   // launchFusedRHS has checked that this mesh takes the cell-centric PV path)
+   [[maybe_unused]] StageEpi EH, EU, ET;
+   if (Stage) {
+      EH.CB = EU.CB = ET.CB = Stage->CB, EH.CA = EU.CA = ET.CA = Stage->CA;
+      EH.First = EU.First = ET.First = Stage->First, EH.Last = EU.Last = ET.Last = Stage->Last;
+      EH.StoreTend = EU.StoreTend = ET.StoreTend = Stage->StoreTend;
+      EH.Next = Stage->NextH, EH.Cur = Stage->CurH, EH.Prov = Stage->ProvH;
+      EU.Next = Stage->NextU, EU.Cur = Stage->CurU, EU.Prov = Stage->ProvU;
+      ET.Next = Stage->NextTr, ET.Cur = Stage->CurTr, ET.Prov = Stage->ProvTr;
+      ET.CurH = Stage->CurH, ET.ProvH = Stage->ProvH, ET.NextH = Stage->NextH;
+   }
    auto Mark = [&](int I) {
       if (Ev)
          (void)hipEventRecord(Ev[I], S);
@@ -1703,7 +1780,16 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    launchVertexAuxState1(M, K, A, H, U, S);
    Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
-   {
+   bool Cell1Done = false;
+   if constexpr (Fast) {
+      if (Stage) {
+         FusedCell1Body<TME, true, true> B{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell,
+                                           HTend, A.Del2TracersCell, EH};
+         launchTile(B, M.NCellsAll, K, S);
+         Cell1Done = true;
+      }
+   }
+   if (!Cell1Done) {
       FusedCell1Body<TME, Fast> B{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend,
                                   A.Del2TracersCell};
       launchTile(B, M.NCellsAll, K, S);
@@ -1776,34 +1862,43 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          Marked5 = true;
          static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
          if (Fast && FuseFinal && M.CellPVFinalOK) {
-            CellPVFinalBody<TME> B1{M,
-                                    K,
-                                    P,
-                                    H,
-                                    U,
-                                    A.NormRelVortVertex,
-                                    A.NormPlanetVortVertex,
-                                    EdgeScratch,
-                                    A.RelVortVertex,
-                                    A.KineticEnergyCell,
-                                    A.VelocityDivCell,
-                                    A.Del2DivCell,
-                                    A.Del2RelVortVertex,
-                                    UTend};
-            if (M.NRingCellsM0 > 0)
-               launchTile(B1, M.NCellsAll, K, S);
-            if (M.NRingCellsM1 > 0) {
-               CellPVFinalBody<TME, NM1> Bm{B1.M,   B1.K,       B1.P,  B1.H,   B1.U,       B1.NormRelVortV, B1.NormPlanetVortV,
-                                            B1.Partial, B1.RelVort, B1.KE, B1.Div, B1.Del2Div, B1.Del2RelVort,  B1.Tend,
-                                            M.RingCellsM1};
-               launchTile(Bm, M.NRingCellsM1, K, S);
-            }
-            if (TME >= 6 && M.NRingCellsM2 > 0) {
-               CellPVFinalBody<TME, NM2> Bm{B1.M,   B1.K,       B1.P,  B1.H,   B1.U,       B1.NormRelVortV, B1.NormPlanetVortV,
-                                            B1.Partial, B1.RelVort, B1.KE, B1.Div, B1.Del2Div, B1.Del2RelVort,  B1.Tend,
-                                            M.RingCellsM2};
-               launchTile(Bm, M.NRingCellsM2, K, S);
-            }
+            auto LaunchFinal = [&](auto Epi) {
+               constexpr bool EP = decltype(Epi)::value;
+               CellPVFinalBody<TME, TME, EP> B1{M,
+                                                K,
+                                                P,
+                                                H,
+                                                U,
+                                                A.NormRelVortVertex,
+                                                A.NormPlanetVortVertex,
+                                                EdgeScratch,
+                                                A.RelVortVertex,
+                                                A.KineticEnergyCell,
+                                                A.VelocityDivCell,
+                                                A.Del2DivCell,
+                                                A.Del2RelVortVertex,
+                                                UTend,
+                                                nullptr,
+                                                EU};
+               if (M.NRingCellsM0 > 0)
+                  launchTile(B1, M.NCellsAll, K, S);
+               if (M.NRingCellsM1 > 0) {
+                  CellPVFinalBody<TME, NM1, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
+                                                   B1.NormRelVortV, B1.NormPlanetVortV, B1.Partial, B1.RelVort, B1.KE,
+                                                   B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM1, EU};
+                  launchTile(Bm, M.NRingCellsM1, K, S);
+               }
+               if (TME >= 6 && M.NRingCellsM2 > 0) {
+                  CellPVFinalBody<TME, NM2, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
+                                                   B1.NormRelVortV, B1.NormPlanetVortV, B1.Partial, B1.RelVort, B1.KE,
+                                                   B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM2, EU};
+                  launchTile(Bm, M.NRingCellsM2, K, S);
+               }
+            };
+            if (Stage)
+               LaunchFinal(std::true_type{});
+            else
+               LaunchFinal(std::false_type{});
             Finished            = true;
             FusedKernelNames[5] = "CellPVFinalBody";
          } else {
@@ -1840,22 +1935,30 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          launchTile(BF, M.NEdgesAll, K, S);
       }
       if (M.NIrregularEdges > 0) {
-         FusedEdgeChainBody<TME, Fast> B{M,
-                                         K,
-                                         P,
-                                         H,
-                                         U,
-                                         A.RelVortVertex,
-                                         A.NormRelVortVertex,
-                                         A.NormPlanetVortVertex,
-                                         A.KineticEnergyCell,
-                                         A.VelocityDivCell,
-                                         A.Del2DivCell,
-                                         A.Del2RelVortVertex,
-                                         A.NormalStressEdge,
-                                         UTend,
-                                         M.IrregularEdges};
-         launchTile(B, M.NIrregularEdges, K, S);
+         auto LaunchList = [&](auto Epi) {
+            constexpr bool EP = decltype(Epi)::value;
+            FusedEdgeChainBody<TME, Fast, EP> B{M,
+                                                K,
+                                                P,
+                                                H,
+                                                U,
+                                                A.RelVortVertex,
+                                                A.NormRelVortVertex,
+                                                A.NormPlanetVortVertex,
+                                                A.KineticEnergyCell,
+                                                A.VelocityDivCell,
+                                                A.Del2DivCell,
+                                                A.Del2RelVortVertex,
+                                                A.NormalStressEdge,
+                                                UTend,
+                                                M.IrregularEdges,
+                                                EU};
+            launchTile(B, M.NIrregularEdges, K, S);
+         };
+         if (Stage)
+            LaunchList(std::true_type{});
+         else
+            LaunchList(std::false_type{});
       }
    } else if (EdgeMode == 2 && launchEdgePatch<TME, Fast>(M, K, P, A, UTend, H, U, S)) {
       FusedKernelNames[4] = "edgePatchKernel";
@@ -1890,7 +1993,15 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (NT > 0 && !Cell3Done) {
       static const int CellMode = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
       // 0: per-thread gathers (FusedCell3Body); 1: LDS-patch kernel for the default term set
-      if (!(CellMode == 1 && Fast && launchCell3Patch<TME>(M, K, NT, P, A, TrTend, H, U, Tr, S))) {
+      bool Done = false;
+      if constexpr (Fast) {
+         if (Stage) {
+            FusedCell3Body<TME, true, true> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            launchTile(B, M.NCellsAll, K, S);
+            Done = true;
+         }
+      }
+      if (!Done && !(CellMode == 1 && Fast && launchCell3Patch<TME>(M, K, NT, P, A, TrTend, H, U, Tr, S))) {
          FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
          launchTile(B, M.NCellsAll, K, S);
       }
@@ -1898,16 +2009,27 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    Mark(7);
 }
 
-void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
+/// does the stage-fused variant cover this mesh / option set?  (same conditions launchFusedT checks
+/// on its way to CellPVFinalBody)
+static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *EdgeScratch) {
+   static const int EdgeMode  = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
+   static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
+   static const int FuseC3    = getenv("OMEGA_FUSE_PV0_CELL3") ? atoi(getenv("OMEGA_FUSE_PV0_CELL3")) : 0;
+   return isDefaultTermSet(P) && EdgeMode == 0 && FuseFinal && !FuseC3 && M.CellPVOK && M.CellPVFinalOK && EdgeScratch;
+}
+
+bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S, hipEvent_t *Ev,
-                    Real *EdgeScratch) {
+                    Real *EdgeScratch, const StageUpdate *Stage) {
    const bool Fast = isDefaultTermSet(P);
+   if (Stage && !stageFusedSupported(M, P, EdgeScratch))
+      return false;
 #define OMEGA_CASE(ME_)                                                                                            \
    case ME_:                                                                                                       \
       if (Fast)                                                                                                    \
-         launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch);              \
+         launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage);       \
       else                                                                                                         \
-         launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch);             \
+         launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr);    \
       break;
    switch (M.MaxEdges) {
       OMEGA_CASE(5)
@@ -1915,9 +2037,10 @@ void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
       OMEGA_CASE(7)
       OMEGA_CASE(8)
    default:
-      break; // callers check fusedRHSSupported()
+      return false; // callers check fusedRHSSupported()
    }
 #undef OMEGA_CASE
+   return true;
 }
 
 } // namespace OMEGA

@@ -67,9 +67,25 @@ constexpr int FusedNumKernels = 7;
 /// MaxEdges in [5,8] and every array plane < 4 GiB (32-bit byte offsets inside a plane)
 bool fusedRHSSupported(const MeshView &M, int K);
 extern const char *FusedKernelNames[FusedNumKernels];
-void launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
+/// Runge-Kutta stage update folded into the kernels that produce the tendencies (the arithmetic of
+/// TimeStepper::updateStateByTend / updateTracersByTend / weightTracers / accumulateTracersUpdate /
+/// finalizeTracersUpdate, TimeStepper.cpp:378-524, applied element by element in the epilogue):
+///   Next  = (First ? Cur : Next) + CB*Tend          tracers: (First ? CurTr*CurH : NextTr) + CB*Tend,
+///                                                            and / NextH(new) when Last
+///   Prov  = Cur + CA*Tend   (unless Last)           tracers: (CurTr*CurH + CA*Tend) / ProvH(new)
+/// Prov* are OUT buffers distinct from the RHS inputs (neighbours still read the inputs).
+struct StageUpdate {
+   Real CB = 0, CA = 0; ///< seconds
+   int First = 0, Last = 0, StoreTend = 0;
+   Real *NextH = nullptr, *NextU = nullptr, *NextTr = nullptr;
+   const Real *CurH = nullptr, *CurU = nullptr, *CurTr = nullptr;
+   Real *ProvH = nullptr, *ProvU = nullptr, *ProvTr = nullptr;
+};
+/// Returns false (nothing launched) when Stage != nullptr and the stage-fused kernels do not cover
+/// this mesh / option set; the caller then runs the plain RHS followed by the update kernels.
+bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                    hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr);
+                    hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr, const StageUpdate *Stage = nullptr);
 /// EdgeScratch: optional [NEdgesSize][K] work array for the cell-centric PV sums (faster path)
 
 // ---- TimeStepper update kernels (TimeStepper.cpp:378-524) ----

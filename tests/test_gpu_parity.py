@@ -156,12 +156,16 @@ def test_group_tendencies_fb_path():
     check("uTend", P.tend.get(1), P.oracle.compute_velocity_tendencies(P.h, P.u), m.NEdgesOwned)
 
 
-@pytest.mark.parametrize("kind,okind", [("RungeKutta4", "rk4"), ("RungeKutta2", "rk2"), ("Forward-Backward", "fb")])
-def test_time_steppers(kind, okind):
-    """doStep x3 against the oracle's restated steppers (state + tracers, bit-exact)."""
+@pytest.mark.parametrize("kind,okind,fuse", [("RungeKutta4", "rk4", True), ("RungeKutta4", "rk4", False),
+                                             ("RungeKutta2", "rk2", None), ("Forward-Backward", "fb", None)])
+def test_time_steppers(kind, okind, fuse):
+    """doStep x3 against the oracle's restated steppers (state + tracers, bit-exact); RK4 with the
+    stage updates folded into the RHS kernels (default) and with the separate update kernels."""
     P = _mk((16, 16, 30e3, 6, 2, {}))
     dt = 600.0
     st = oa.TimeStepper(kind, dt, P.tend, P.aux, P.mesh, None, P.tracers)
+    if fuse is not None:
+        st.set_option("FuseStageUpdates", fuse)
     ost = P.oracle.make_state(P.h, P.u, P.tr)
     m = P.mesh
     for step in range(3):
@@ -175,10 +179,12 @@ def test_time_steppers(kind, okind):
         check(f"tr step {step}", tr, ost["tr"][0], m.NCellsOwned)
 
 
-def test_rk4_on_the_sphere():
-    """Two RK4 steps on the icosahedral mesh (pentagon edges through the edge-centric list)."""
-    P = _mk(("ico3", 0, 0, 8, 2, {}))
-    dt = 600.0
+@pytest.mark.parametrize("name", ["ico3", "fib1500", "ico3pad8"])
+def test_rk4_on_the_sphere(name):
+    """Two RK4 steps (stage updates fused into the RHS kernels) on the spherical meshes: pentagon /
+    heptagon ring launches, and with maxEdges = 8 the pentagons' edges through the edge-centric list."""
+    P = _mk((name, 0, 0, 8, 2, {}))
+    dt = 600.0 if name != "fib1500" else 5.0   # the Fibonacci mesh has a few very short edges
     st = oa.TimeStepper("RungeKutta4", dt, P.tend, P.aux, P.mesh, None, P.tracers)
     ost = P.oracle.make_state(P.h, P.u, P.tr)
     m = P.mesh
