@@ -38,6 +38,8 @@ WORKLOADS = {
     "ec30to60": (484, 484, 45.0e3, 60, 2, "EC30to60-sized planar mesh 484x484 (234256 cells), 60L, 2 tracers"),
     "qu30_eighth": (340, 170, 30.0e3, 80, 6, "one eighth of the QU30-sized mesh (340x170 = 57800 cells), 80L, 6 tracers"),
     "qu30_quarter": (340, 340, 30.0e3, 80, 6, "one quarter of the QU30-sized mesh (340x340 = 115600 cells), 80L, 6 tracers"),
+    "orrs18to6_eighth": (680, 680, 6.0e3, 80, 37,
+                         "one eighth of an oRRS18to6-sized mesh (680x680 = 462400 of 3.7M cells), 80L, 37 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
 }
 
