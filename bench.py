@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import omega_amd as oa  # noqa: E402
-from omega_amd.meshgen import planar_hex, reorder_cells_blocked, synthetic_state  # noqa: E402
+from omega_amd.meshgen import planar_hex, reorder_cells_blocked, reorder_cells_morton, synthetic_state  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("OMEGA_BENCH_WORKLOAD", "qu30"), choices=sorted(WORKLOADS))
     ap.add_argument("--rk4-steps", type=int, default=-1, help="RK4 steps for SYPD (default: max(2, steps//4))")
     ap.add_argument("--dt", type=float, default=600.0, help="time step [s] (Default.yml TimeStep 10 min)")
-    ap.add_argument("--block", type=int, default=16, help="cell-ordering block size of the synthetic mesh")
+    ap.add_argument("--block", type=int, default=0, help="cell ordering of the synthetic mesh: 0 = Morton curve (default), -1 = Hilbert curve, 1 = row-major, n > 1 = n x n blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the reference-structured launch sequence instead")
     ap.add_argument("--no-fuse-stages", action="store_true",
@@ -110,7 +110,9 @@ def main():
 
     t0 = time.time()
     g = planar_hex(nx, ny, dc)
-    if args.block > 1:
+    if args.block <= 0:
+        g = reorder_cells_morton(g, hilbert=args.block < 0)
+    elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
     gm = oa.GlobalMesh(g)
     decomp = oa.Decomp(gm, N, rank, 3)
@@ -245,7 +247,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
-                          "partition": f"rcb{N}", "halo_width": 3, "mesh_order": f"blocked{args.block}",
+                          "partition": f"rcb{N}", "halo_width": 3, "mesh_order": "hilbert" if args.block < 0 else "morton" if args.block == 0 else f"blocked{args.block}",
                           "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1)},
                "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
                        "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels"},

@@ -212,6 +212,38 @@ def reorder_cells_blocked(mesh: dict, block: int = 16) -> dict:
                         (2 * old_of_new[:, None] + np.arange(2)).ravel())
 
 
+def reorder_cells_morton(mesh: dict, hilbert: bool = False) -> dict:
+    """Renumber a planar_hex mesh along the Z-order (Morton) curve of (col, row) -- any aligned run of
+    2^k consecutive cells is a compact block, at every scale -- or along the Hilbert curve."""
+    nC = mesh["nCells"]
+    nx = int(round(mesh["x_period"] / mesh["dc"]))
+    ny = nC // nx
+    col, row = np.meshgrid(np.arange(nx), np.arange(ny))
+    col, row = col.ravel().astype(np.int64), row.ravel().astype(np.int64)
+    key = np.zeros(nC, dtype=np.int64)
+    if hilbert:
+        x, y = col.copy(), row.copy()
+        n = 1 << 11
+        s = n >> 1
+        while s > 0:
+            rx = ((x & s) > 0).astype(np.int64)
+            ry = ((y & s) > 0).astype(np.int64)
+            key += s * s * ((3 * rx) ^ ry)
+            flip = (ry == 0) & (rx == 1)
+            x = np.where(flip, s - 1 - (x & (s - 1)), x & (s - 1))
+            y = np.where(flip, s - 1 - (y & (s - 1)), y & (s - 1))
+            swap = ry == 0
+            x, y = np.where(swap, y, x), np.where(swap, x, y)
+            s >>= 1
+    for b in range(16 if not hilbert else 0):
+        key |= ((col >> b) & 1) << (2 * b)
+        key |= ((row >> b) & 1) << (2 * b + 1)
+    old_of_new = np.argsort(key, kind="stable")
+    return permute_mesh(mesh, old_of_new,
+                        (3 * old_of_new[:, None] + np.arange(3)).ravel(),
+                        (2 * old_of_new[:, None] + np.arange(2)).ravel())
+
+
 def permute_mesh(mesh: dict, cell_old_of_new, edge_old_of_new, vertex_old_of_new) -> dict:
     """Apply element permutations (new index i holds old element old_of_new[i])."""
     out = dict(mesh)
