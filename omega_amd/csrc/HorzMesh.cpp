@@ -448,8 +448,9 @@ void HorzMesh::buildDel2Tables() {
    for (int V = 0; V < NVerticesAll && VertOK; ++V)
       for (int J = 0; J < VD; ++J) {
          const int E = EdgesOnVertexH(V, J);
-         if (E >= NEdgesAll) { // no such edge here: the term must vanish through its coefficient
-            if (EdgeSignOnVertexH(V, J) != 0.0)
+         if (E >= NEdgesAll) { // no such edge here (outermost halo): the term must vanish through its
+                               // coefficient InvAreaTriangle*DcEdge*EdgeSignOnVertex
+            if (DcEdgeH(E) * EdgeSignOnVertexH(V, J) != 0.0)
                VertOK = false;
             NbrV(V, J) = V;
             continue;
