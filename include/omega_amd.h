@@ -176,6 +176,16 @@ int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, co
                                  int tracer_time_level, int thick_time_level, int vel_time_level, void *stream);
 /* per-kernel timing of the fused RHS with HIP events on the launch stream (Pacer "Tend:*" timers,
  * O/src/ocn/Tendencies.cpp:280-481).  names[i] / ms_sum[i] for i < *n_kernels (<= 8). */
+/* Custom tendencies (O/src/ocn/Tendencies.h:51-53; Tendencies.cpp:41-64 UseCustomTendency +
+ * ManufacturedSolutionTendency): attach the manufactured-solution source terms of
+ * O/src/ocn/CustomTendencyTerms.cpp:18-208 (wavelengths / amplitude = the ManufacturedSolution config group,
+ * Default.yml:143-146; H0 = BottomDepth of the first cell; del2 / del4 switches and viscosities from this
+ * Tendencies' options).  omg_tend_set_time = the TimeInstant argument of the compute* calls, in seconds
+ * since the reference time (the time steppers set it per stage). */
+int omg_tend_use_manufactured_solution(omg_tend *t, const omg_mesh *m, double wavelength_x, double wavelength_y,
+                                       double amplitude);
+int omg_tend_clear_custom_tendencies(omg_tend *t);
+int omg_tend_set_time(omg_tend *t, double seconds);
 int omg_tend_kernel_timing(omg_tend *t, int enable);
 int omg_tend_collect_kernel_times(omg_tend *t, double *ms_sum, int *n_kernels, int *n_samples);
 const char *omg_tend_kernel_name(int i);
@@ -191,6 +201,10 @@ int omg_stepper_create(const char *type, double time_step_seconds, omg_tend *t, 
                        omg_halo *halo, omg_tracers *tr, omg_stepper **out);
 int omg_stepper_destroy(omg_stepper *st);
 int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream);
+/* model time in seconds since the reference time (the reference's SimTime / StepClock); doStep hands the
+ * stage times to the custom tendencies */
+int omg_stepper_set_start_time(omg_stepper *st, double seconds);
+int omg_stepper_get_time(const omg_stepper *st, double *seconds);
 /* RungeKutta4 only: "FuseStageUpdates" (default 1: the stage updates of TimeStepper.cpp:378-524 run in the
  * epilogue of the RHS kernels, same arithmetic) and "StoreStageTendencies" (default 0: with fused stages the
  * Tendencies arrays are not written).  0 / 1. */

@@ -497,6 +497,18 @@ class Tendencies:
         _chk(lib().omg_tend_compute_tracer_only(self.h, state.h, aux.h, tracers.h, tracer_tl, thick_tl, vel_tl,
                                                 _sh(stream)))
 
+    def use_manufactured_solution(self, mesh, wavelength_x: float, wavelength_y: float, amplitude: float):
+        """Tendencies config UseCustomTendency + ManufacturedSolutionTendency (CustomTendencyTerms.cpp)."""
+        _chk(lib().omg_tend_use_manufactured_solution(self.h, mesh.h, C.c_double(wavelength_x), C.c_double(wavelength_y),
+                                                      C.c_double(amplitude)))
+
+    def clear_custom_tendencies(self):
+        _chk(lib().omg_tend_clear_custom_tendencies(self.h))
+
+    def set_time(self, seconds: float):
+        """model time (s since the reference time) the custom tendencies see in direct compute_* calls"""
+        _chk(lib().omg_tend_set_time(self.h, C.c_double(seconds)))
+
     def kernel_timing(self, on: bool):
         _chk(lib().omg_tend_kernel_timing(self.h, int(on)))
 
@@ -537,6 +549,15 @@ class TimeStepper:
 
     def do_step(self, state: OceanState, stream=None):
         _chk(lib().omg_stepper_do_step(self.h, state.h, _sh(stream)))
+
+    def set_start_time(self, seconds: float):
+        _chk(lib().omg_stepper_set_start_time(self.h, C.c_double(seconds)))
+
+    @property
+    def time(self) -> float:
+        v = C.c_double()
+        _chk(lib().omg_stepper_get_time(self.h, C.byref(v)))
+        return v.value
 
     def set_option(self, name: str, value: bool):
         """RungeKutta4: "FuseStageUpdates" (default on), "StoreStageTendencies" (default off)."""

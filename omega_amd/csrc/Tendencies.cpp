@@ -46,20 +46,24 @@ TendParams Tendencies::paramsFor(const AuxiliaryState *Aux) const {
 }
 
 // Tendencies.cpp:257-297
-void Tendencies::computeThicknessTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int, int VelLvl,
+void Tendencies::computeThicknessTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
                                                 hipStream_t S) {
    Array2DReal NormalVelEdge;
    OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
    launchThicknessTendOnly(Mesh->view(), NVertLayers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                            NormalVelEdge.Ptr, S);
+   if (CustomThicknessTend) // Tendencies.cpp:288-291
+      CustomThicknessTend(LayerThicknessTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
 }
 // Tendencies.cpp:301-423
-void Tendencies::computeVelocityTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int, int VelLvl,
+void Tendencies::computeVelocityTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
                                                hipStream_t S) {
    Array2DReal NormalVelEdge;
    OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
    launchVelocityTendOnly(Mesh->view(), NVertLayers, paramsFor(Aux), Aux->ptrs(), NormalVelocityTend.Ptr,
                           NormalVelEdge.Ptr, S);
+   if (CustomVelocityTend) // Tendencies.cpp:416-419
+      CustomVelocityTend(NormalVelocityTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
 }
 // Tendencies.cpp:427-486
 void Tendencies::computeTracerTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux,
@@ -103,6 +107,8 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
                                            const StageUpdate &Stage, hipStream_t S) {
    if (!(UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)))
       return false;
+   if (CustomThicknessTend || CustomVelocityTend)
+      return false; // the custom terms are added to the stored tendencies: needs the plain sequence
    Array2DReal LayerThick, NormVel;
    OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
                  "Tendencies: bad time level");
@@ -132,6 +138,10 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
       launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                      NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
                      EdgeScratch.Ptr);
+      if (CustomThicknessTend)
+         CustomThicknessTend(LayerThicknessTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
+      if (CustomVelocityTend)
+         CustomVelocityTend(NormalVelocityTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
       return;
    }
    Aux->computeAll(State, TracerArray, ThickLvl, VelLvl, S);

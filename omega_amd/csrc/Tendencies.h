@@ -10,6 +10,8 @@
 #include "Base.h"
 #include "kernels/Kernels.h"
 
+#include <functional>
+
 namespace OMEGA {
 
 class Tendencies {
@@ -24,6 +26,16 @@ class Tendencies {
    /// Fused RHS for computeAllTendencies (default on); off = the reference's launch
    /// structure (every AuxiliaryState array materialised).
    bool UseFusedRHS = true;
+
+   /// Custom tendencies (Tendencies.h:51-53, 182-183): called at the end of the thickness / velocity
+   /// group with the tendency array, the state / aux state, the two time levels and the model time
+   /// (here: ModelTime seconds since the reference time instead of a TimeInstant, plus the stream).
+   using CustomTendencyType = std::function<void(const Array2DReal &, const OceanState *, const AuxiliaryState *, int,
+                                                 int, R8 TimeSeconds, hipStream_t)>;
+   CustomTendencyType CustomThicknessTend, CustomVelocityTend;
+   /// model time handed to the custom tendencies; the time steppers set it for every stage
+   /// (RungeKutta4Stepper.cpp:87 StageTime, RungeKutta2Stepper.cpp:44,58, ForwardBackwardStepper.cpp:50,59,67)
+   R8 ModelTime = 0.0;
 
    void computeThicknessTendenciesOnly(const OceanState *State, const AuxiliaryState *AuxState, int ThickTimeLevel,
                                        int VelTimeLevel, hipStream_t S);

@@ -200,13 +200,16 @@ void ForwardBackwardStepper::doStep(OceanState *State, hipStream_t S) {
    OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
                  "ForwardBackward doStep: error retrieving tracers");
    const R8 Dt = coeff(1.0);
+   const R8 T0 = simTime();
    // R_h^{n} = RHS_h(u^{n}, h^{n}, t^{n});  h^{n+1} = h^{n} + R_h^{n}
+   Tend->ModelTime = T0;
    Tend->computeThicknessTendencies(State, AuxState, CurLevel, CurLevel, S);
    updateThicknessByTend(State, NextLevel, State, CurLevel, Dt, S);
    // R_phi^{n};  phi^{n+1} = (phi^{n} * h^{n} + R_phi^{n}) / h^{n+1}
    Tend->computeTracerTendencies(State, AuxState, CurTracerArray, CurLevel, CurLevel, S);
    updateTracersByTend(NextTracerArray, CurTracerArray, State, NextLevel, State, CurLevel, Dt, S);
    // R_u^{n+1} = RHS_u(u^{n}, h^{n+1}, t^{n+1});  u^{n+1} = u^{n} + R_u^{n+1}
+   Tend->ModelTime = T0 + Dt;
    Tend->computeVelocityTendencies(State, AuxState, NextLevel, CurLevel, S);
    updateVelocityByTend(State, NextLevel, State, CurLevel, Dt, S);
    updateTimeLevels(State, S);
@@ -220,9 +223,12 @@ void RungeKutta2Stepper::doStep(OceanState *State, hipStream_t S) {
    OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
                  "RungeKutta2 doStep: error retrieving tracers");
    const R8 Half = coeff(0.5), Full = coeff(1.0);
+   const R8 T0 = simTime();
+   Tend->ModelTime = T0;
    Tend->computeAllTendencies(State, AuxState, CurTracerArray, CurLevel, CurLevel, S);
    updateStateByTend(State, NextLevel, State, CurLevel, Half, S);
    updateTracersByTend(NextTracerArray, CurTracerArray, State, NextLevel, State, CurLevel, Half, S);
+   Tend->ModelTime = T0 + Half;
    Tend->computeAllTendencies(State, AuxState, NextTracerArray, NextLevel, NextLevel, S);
    updateStateByTend(State, NextLevel, State, CurLevel, Full, S);
    updateTracersByTend(NextTracerArray, CurTracerArray, State, NextLevel, State, CurLevel, Full, S);
@@ -312,7 +318,9 @@ void RungeKutta4Stepper::doStep(OceanState *State, hipStream_t S) {
    OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
                  "RungeKutta4 doStep: error retrieving tracers");
    const int NT = Trc->NTracers;
+   const R8 T0  = simTime();
    for (int Stage = 0; Stage < NStages; ++Stage) {
+      Tend->ModelTime = T0 + coeff(RKC[Stage]); // StageTime (:87)
       if (Stage == 0) {
          // R^{(0)} = RHS(q^{n}, t^{n});  q^{n+1} = q^{n} + dt * RKB[0] * R^{(0)}
          weightTracers(NextTracerArray, CurTracerArray, State, CurLevel, S);

@@ -57,6 +57,10 @@ class TimeStepper {
    int NTimeLevels;
    R8 TimeStep;
    I8 NStepsDone = 0;
+   /// model time in seconds since the reference time: StartTime + NStepsDone*TimeStep.  The schemes
+   /// hand the stage times to Tendencies::ModelTime (the reference passes a TimeInstant).
+   R8 StartTime = 0.0;
+   R8 simTime() const { return StartTime + (R8)NStepsDone * TimeStep; }
 
  protected:
    /// end-of-step: halo exchange of the new level, then rotate (State->updateTimeLevels();

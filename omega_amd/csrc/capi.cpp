@@ -7,6 +7,7 @@
 #include "HorzMesh.h"
 #include "OceanState.h"
 #include "Tendencies.h"
+#include "CustomTendencyTerms.h"
 #include "TimeStepper.h"
 
 #include <cstring>
@@ -35,6 +36,7 @@ struct omg_aux {
 };
 struct omg_tend {
    std::unique_ptr<Tendencies> T;
+   std::shared_ptr<ManufacturedSolution> Ms;
 };
 struct omg_stepper {
    std::unique_ptr<TimeStepper> St;
@@ -725,6 +727,35 @@ int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, co
    t->T->computeTracerTendenciesOnly(s->S.get(), a->A.get(), tracerArray(tr, trtl), ttl, vtl, (hipStream_t)stream);
    OMG_CATCH
 }
+int omg_tend_use_manufactured_solution(omg_tend *t, const omg_mesh *m, double wavelength_x, double wavelength_y,
+                                       double amplitude) {
+   OMG_TRY
+   OMG_ARG(t && m);
+   const TendParams &P = t->T->Params;
+   auto Ms = std::make_shared<ManufacturedSolution>(m->M.get(), wavelength_x, wavelength_y, amplitude,
+                                                    P.VelDiffTendencyEnable != 0, P.VelHyperDiffTendencyEnable != 0,
+                                                    P.ViscDel2, P.ViscDel4);
+   t->Ms                     = Ms;
+   t->T->CustomThicknessTend = [Ms](const Array2DReal &Tend, const OceanState *, const AuxiliaryState *, int, int,
+                                    R8 Time, hipStream_t S) { Ms->thicknessTendency(Tend, Time, S); };
+   t->T->CustomVelocityTend  = [Ms](const Array2DReal &Tend, const OceanState *, const AuxiliaryState *, int, int,
+                                    R8 Time, hipStream_t S) { Ms->velocityTendency(Tend, Time, S); };
+   OMG_CATCH
+}
+int omg_tend_clear_custom_tendencies(omg_tend *t) {
+   OMG_TRY
+   OMG_ARG(t);
+   t->T->CustomThicknessTend = nullptr;
+   t->T->CustomVelocityTend  = nullptr;
+   t->Ms.reset();
+   OMG_CATCH
+}
+int omg_tend_set_time(omg_tend *t, double seconds) {
+   OMG_TRY
+   OMG_ARG(t);
+   t->T->ModelTime = seconds;
+   OMG_CATCH
+}
 int omg_tend_kernel_timing(omg_tend *t, int enable) {
    OMG_TRY
    OMG_ARG(t);
@@ -805,6 +836,18 @@ int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream) {
    OMG_TRY
    OMG_ARG(st && s);
    st->St->doStep(s->S.get(), (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_stepper_set_start_time(omg_stepper *st, double seconds) {
+   OMG_TRY
+   OMG_ARG(st);
+   st->St->StartTime = seconds - (double)st->St->NStepsDone * st->St->TimeStep;
+   OMG_CATCH
+}
+int omg_stepper_get_time(const omg_stepper *st, double *seconds) {
+   OMG_TRY
+   OMG_ARG(st && seconds);
+   *seconds = st->St->simTime();
    OMG_CATCH
 }
 int omg_stepper_set_option(omg_stepper *st, const char *name, int value) {

@@ -88,6 +88,16 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
                     hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr, const StageUpdate *Stage = nullptr);
 /// EdgeScratch: optional [NEdgesSize][K] work array for the cell-centric PV sums (faster path)
 
+// ---- ManufacturedSolution custom tendencies (CustomTendencyTerms.cpp:112-208) ----
+struct ManufacturedParams {
+   Real H0, Eta0, Kx, Ky, AngFreq, Grav, ViscDel2, ViscDel4;
+   int VelDiffTendencyEnable, VelHyperDiffTendencyEnable;
+};
+void launchManufacturedThickness(int NCells, int K, Real *Tend, const Real *XCell, const Real *YCell,
+                                 const ManufacturedParams &P, Real ElapsedSec, hipStream_t S);
+void launchManufacturedVelocity(int NEdges, int K, Real *Tend, const Real *XEdge, const Real *YEdge, const Real *FEdge,
+                                const Real *AngleEdge, const ManufacturedParams &P, Real ElapsedSec, hipStream_t S);
+
 // ---- TimeStepper update kernels (TimeStepper.cpp:378-524) ----
 void launchUpdateByTend(int NRows, int K, Real *X1, const Real *X2, const Real *Tend, Real Coeff, hipStream_t S);
 void launchUpdateTracersByTend(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *CurTr, const Real *H1,

@@ -462,4 +462,64 @@ void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int N
    launchHaloCopy<false>(const_cast<Real *>(Buf), A, List, NList, NT, RowsSize, K, S);
 }
 
+// ---------------------------------------------------------------------------------------
+// ManufacturedSolution (CustomTendencyTerms.cpp): one thread per (element, level); the source term
+// is level independent, so it is evaluated once per element row and added to every level.
+__global__ void manufacturedThicknessKernel(int N, int K, Real *Tend, const Real *XCell, const Real *YCell,
+                                            ManufacturedParams P, Real T) {
+   const int I = blockIdx.x * blockDim.y + threadIdx.y;
+   if (I >= N)
+      return;
+   const Real Phase = P.Kx * XCell[I] + P.Ky * YCell[I] - P.AngFreq * T;
+   const Real Src   = P.Eta0 * (-P.H0 * (P.Kx + P.Ky) * sin(Phase) - P.AngFreq * cos(Phase) +
+                              P.Eta0 * (P.Kx + P.Ky) * cos(2.0 * Phase)); // :139-142
+   for (int Kl = threadIdx.x; Kl < K; Kl += blockDim.x)
+      Tend[(size_t)I * K + Kl] += Src;
+}
+__global__ void manufacturedVelocityKernel(int N, int K, Real *Tend, const Real *XEdge, const Real *YEdge,
+                                           const Real *FEdge, const Real *AngleEdge, ManufacturedParams P, Real T) {
+   const int I = blockIdx.x * blockDim.y + threadIdx.y;
+   if (I >= N)
+      return;
+   const Real Kx2 = P.Kx * P.Kx, Ky2 = P.Ky * P.Ky, Kx4 = Kx2 * Kx2, Ky4 = Ky2 * Ky2;
+   const Real Phase       = P.Kx * XEdge[I] + P.Ky * YEdge[I] - P.AngFreq * T;
+   const Real SourceTerm0 = P.AngFreq * sin(Phase) - 0.5 * P.Eta0 * (P.Kx + P.Ky) * sin(2.0 * Phase);
+   Real U = P.Eta0 * ((-FEdge[I] + P.Grav * P.Kx) * cos(Phase) + SourceTerm0);
+   Real V = P.Eta0 * ((FEdge[I] + P.Grav * P.Ky) * cos(Phase) + SourceTerm0);
+   if (P.VelDiffTendencyEnable) { // :188-191
+      U += P.ViscDel2 * P.Eta0 * (Kx2 + Ky2) * cos(Phase);
+      V += P.ViscDel2 * P.Eta0 * (Kx2 + Ky2) * cos(Phase);
+   }
+   if (P.VelHyperDiffTendencyEnable) { // :192-197
+      U -= P.ViscDel4 * P.Eta0 * ((Kx4 + Ky4 + Kx2 * Ky2) * cos(Phase));
+      V -= P.ViscDel4 * P.Eta0 * ((Kx4 + Ky4 + Kx2 * Ky2) * cos(Phase));
+   }
+   const Real Src = cos(AngleEdge[I]) * U + sin(AngleEdge[I]) * V;
+   for (int Kl = threadIdx.x; Kl < K; Kl += blockDim.x)
+      Tend[(size_t)I * K + Kl] += Src;
+}
+static dim3 rowBlock(int K) {
+   int TX = 1;
+   while (TX < K && TX < 64)
+      TX <<= 1;
+   return dim3(TX, 256 / TX, 1);
+}
+void launchManufacturedThickness(int N, int K, Real *Tend, const Real *XCell, const Real *YCell,
+                                 const ManufacturedParams &P, Real T, hipStream_t S) {
+   if (N <= 0)
+      return;
+   const dim3 B = rowBlock(K);
+   hipLaunchKernelGGL(manufacturedThicknessKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, Tend, XCell, YCell, P, T);
+   HIP_CHECK(hipGetLastError());
+}
+void launchManufacturedVelocity(int N, int K, Real *Tend, const Real *XEdge, const Real *YEdge, const Real *FEdge,
+                                const Real *AngleEdge, const ManufacturedParams &P, Real T, hipStream_t S) {
+   if (N <= 0)
+      return;
+   const dim3 B = rowBlock(K);
+   hipLaunchKernelGGL(manufacturedVelocityKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, Tend, XEdge, YEdge, FEdge,
+                      AngleEdge, P, T);
+   HIP_CHECK(hipGetLastError());
+}
+
 } // namespace OMEGA

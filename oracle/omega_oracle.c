@@ -579,11 +579,70 @@ void orc_tracer_hyperdiff_on_cell(const orc_mesh *m, int NT, int N, double *Tend
 
 static void fill0(double *a, size_t n) { memset(a, 0, n * sizeof(double)); }
 
+/* ---- ManufacturedSolution, O/src/ocn/CustomTendencyTerms.cpp ---- */
+static const orc_manufactured *g_custom = NULL;
+static double g_time = 0.0, g_sim_time = 0.0;
+void orc_set_custom_tendency(const orc_manufactured *ms) { g_custom = ms; }
+void orc_set_time(double t) { g_time = t; }
+void orc_set_sim_time(double t) { g_sim_time = t, g_time = t; }
+
+/* ManufacturedSolution::init, CustomTendencyTerms.cpp:18-107 */
+void orc_manufactured_init(orc_manufactured *ms, const orc_mesh *m, const orc_config *c, double WavelengthX,
+                           double WavelengthY, double Amplitude) {
+   const double H0 = m->BottomDepth[0]; /* :76-77 */
+   const double Grav = 9.80665, Pii = 3.141592653589793;
+   const double Kx = 2.0 * Pii / WavelengthX, Ky = 2.0 * Pii / WavelengthY;
+   ms->H0 = H0, ms->Eta0 = Amplitude, ms->Kx = Kx, ms->Ky = Ky, ms->Grav = Grav;
+   ms->AngFreq = sqrt(H0 * Grav * (Kx * Kx + Ky * Ky)); /* :84 */
+   ms->VelDiffTendencyEnable = c->VelDiffTendencyEnable, ms->VelHyperDiffTendencyEnable = c->VelHyperDiffTendencyEnable;
+   ms->ViscDel2 = c->ViscDel2, ms->ViscDel4 = c->ViscDel4;
+}
+
+/* ManufacturedThicknessTendency::operator(), CustomTendencyTerms.cpp:112-145 */
+void orc_manufactured_thickness_tend(const orc_mesh *m, const orc_manufactured *ms, double *hTend, double T) {
+   const int K = m->NVertLayers;
+#pragma omp parallel for
+   for (int ICell = 0; ICell < m->NCellsAll; ++ICell) {
+      const double X = ms->XCell[ICell], Y = ms->YCell[ICell];
+      const double Phase = ms->Kx * X + ms->Ky * Y - ms->AngFreq * T;
+      for (int k = 0; k < K; ++k)
+         hTend[(size_t)ICell * K + k] += ms->Eta0 * (-ms->H0 * (ms->Kx + ms->Ky) * sin(Phase) - ms->AngFreq * cos(Phase) +
+                                                     ms->Eta0 * (ms->Kx + ms->Ky) * cos(2.0 * Phase));
+   }
+}
+
+/* ManufacturedVelocityTendency::operator(), CustomTendencyTerms.cpp:150-208 */
+void orc_manufactured_velocity_tend(const orc_mesh *m, const orc_manufactured *ms, double *uTend, double T) {
+   const int K = m->NVertLayers;
+   const double Kx2 = ms->Kx * ms->Kx, Ky2 = ms->Ky * ms->Ky, Kx4 = Kx2 * Kx2, Ky4 = Ky2 * Ky2;
+#pragma omp parallel for
+   for (int IEdge = 0; IEdge < m->NEdgesAll; ++IEdge) {
+      const double X = ms->XEdge[IEdge], Y = ms->YEdge[IEdge];
+      const double Phase       = ms->Kx * X + ms->Ky * Y - ms->AngFreq * T;
+      const double SourceTerm0 = ms->AngFreq * sin(Phase) - 0.5 * ms->Eta0 * (ms->Kx + ms->Ky) * sin(2.0 * Phase);
+      double U = ms->Eta0 * ((-ms->FEdge[IEdge] + ms->Grav * ms->Kx) * cos(Phase) + SourceTerm0);
+      double V = ms->Eta0 * ((ms->FEdge[IEdge] + ms->Grav * ms->Ky) * cos(Phase) + SourceTerm0);
+      if (ms->VelDiffTendencyEnable) {
+         U += ms->ViscDel2 * ms->Eta0 * (Kx2 + Ky2) * cos(Phase);
+         V += ms->ViscDel2 * ms->Eta0 * (Kx2 + Ky2) * cos(Phase);
+      }
+      if (ms->VelHyperDiffTendencyEnable) {
+         U -= ms->ViscDel4 * ms->Eta0 * ((Kx4 + Ky4 + Kx2 * Ky2) * cos(Phase));
+         V -= ms->ViscDel4 * ms->Eta0 * ((Kx4 + Ky4 + Kx2 * Ky2) * cos(Phase));
+      }
+      const double Src = cos(m->AngleEdge[IEdge]) * U + sin(m->AngleEdge[IEdge]) * V;
+      for (int k = 0; k < K; ++k)
+         uTend[(size_t)IEdge * K + k] += Src;
+   }
+}
+
 /* Tendencies::computeThicknessTendenciesOnly, O/src/ocn/Tendencies.cpp:257-297 */
 void orc_tend_thickness_only(const orc_mesh *m, const orc_config *c, const orc_aux *a, double *hTend, const double *u) {
    fill0(hTend, (size_t)m->NCellsSize * m->NVertLayers); /* deepCopy(...,0) :272 */
    if (c->ThicknessFluxTendencyEnable)
       orc_thickness_flux_div_on_cell(m, m->NCellsAll, hTend, a->FluxLayerThickEdge, u);
+   if (g_custom) /* CustomThicknessTend :288-291 */
+      orc_manufactured_thickness_tend(m, g_custom, hTend, g_time);
 }
 
 /* Tendencies::computeVelocityTendenciesOnly, O/src/ocn/Tendencies.cpp:301-423 */
@@ -604,6 +663,8 @@ void orc_tend_velocity_only(const orc_mesh *m, const orc_config *c, const orc_au
       orc_wind_forcing_on_edge(m, N, uTend, a->NormalStressEdge, a->MeanLayerThickEdge, c->Density0);
    if (c->BottomDragTendencyEnable)
       orc_bottom_drag_on_edge(m, N, uTend, u, a->KineticEnergyCell, a->MeanLayerThickEdge, c->BottomDragCoeff);
+   if (g_custom) /* CustomVelocityTend :416-419 */
+      orc_manufactured_velocity_tend(m, g_custom, uTend, g_time);
 }
 
 /* Tendencies::computeTracerTendenciesOnly, O/src/ocn/Tendencies.cpp:427-486 */
@@ -804,8 +865,10 @@ double orc_coeff_seconds(double Mult, double TimeStepSeconds) {
 void orc_rk4_step(const orc_mesh *m, const orc_config *c, const orc_aux *a, int NT, orc_state *s, double dt, orc_exchange_fn ex, void *ctx) {
    const double RKA[4] = {0, 1. / 2, 1. / 2, 1};
    const double RKB[4] = {1. / 6, 1. / 3, 1. / 3, 1. / 6};
+   const double RKC[4] = {0, 1. / 2, 1. / 2, 1};
    for (int Stage = 0; Stage < 4; ++Stage) {
       const double CB = orc_coeff_seconds(RKB[Stage], dt);
+      g_time          = g_sim_time + orc_coeff_seconds(RKC[Stage], dt); /* StageTime :87 */
       if (Stage == 0) {
          orc_weight_tracers(m, NT, s->tr[1], s->tr[0], s->h[0]);
          orc_tend_compute_all(m, c, a, NT, s->hTend, s->uTend, s->trTend, s->h[0], s->u[0], s->tr[0]);
@@ -833,10 +896,12 @@ void orc_rk4_step(const orc_mesh *m, const orc_config *c, const orc_aux *a, int 
 /* RungeKutta2Stepper::doStep, O/src/timeStepping/RungeKutta2Stepper.cpp:27-73 */
 void orc_rk2_step(const orc_mesh *m, const orc_config *c, const orc_aux *a, int NT, orc_state *s, double dt, orc_exchange_fn ex, void *ctx) {
    const double CH = orc_coeff_seconds(0.5, dt), C1 = orc_coeff_seconds(1.0, dt);
+   g_time = g_sim_time;
    orc_tend_compute_all(m, c, a, NT, s->hTend, s->uTend, s->trTend, s->h[0], s->u[0], s->tr[0]);
    orc_update_thickness_by_tend(m, s->h[1], s->h[0], s->hTend, CH);
    orc_update_velocity_by_tend(m, s->u[1], s->u[0], s->uTend, CH);
    orc_update_tracers_by_tend(m, NT, s->tr[1], s->tr[0], s->h[1], s->h[0], s->trTend, CH);
+   g_time = g_sim_time + CH; /* SimTime + 0.5*TimeStep :58 */
    orc_tend_compute_all(m, c, a, NT, s->hTend, s->uTend, s->trTend, s->h[1], s->u[1], s->tr[1]);
    orc_update_thickness_by_tend(m, s->h[1], s->h[0], s->hTend, C1);
    orc_update_velocity_by_tend(m, s->u[1], s->u[0], s->uTend, C1);
@@ -848,10 +913,12 @@ void orc_rk2_step(const orc_mesh *m, const orc_config *c, const orc_aux *a, int 
 /* ForwardBackwardStepper::doStep, O/src/timeStepping/ForwardBackwardStepper.cpp:27-82 */
 void orc_fb_step(const orc_mesh *m, const orc_config *c, const orc_aux *a, int NT, orc_state *s, double dt, orc_exchange_fn ex, void *ctx) {
    const double C1 = orc_coeff_seconds(1.0, dt);
+   g_time = g_sim_time;
    orc_tend_compute_thickness(m, c, a, s->hTend, s->h[0], s->u[0]);
    orc_update_thickness_by_tend(m, s->h[1], s->h[0], s->hTend, C1);
    orc_tend_compute_tracer(m, c, a, NT, s->trTend, s->h[0], s->u[0], s->tr[0]);
    orc_update_tracers_by_tend(m, NT, s->tr[1], s->tr[0], s->h[1], s->h[0], s->trTend, C1);
+   g_time = g_sim_time + C1; /* SimTime + TimeStep :67 */
    orc_tend_compute_velocity(m, c, a, s->uTend, s->h[1], s->u[0]);
    orc_update_velocity_by_tend(m, s->u[1], s->u[0], s->uTend, C1);
    if (ex)

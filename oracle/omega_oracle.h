@@ -81,6 +81,26 @@ typedef struct {
    double *NormalStressEdge, *ZonalStressCell, *MeridStressCell; /* E, C, C (1-D) */
 } orc_aux;
 
+/* ManufacturedSolution (O/src/ocn/CustomTendencyTerms.h, CustomTendencyTerms.cpp:18-210): the custom
+ * thickness / velocity tendencies of the manufactured-solution test case (Bishnu et al. 2024) */
+typedef struct {
+   double H0, Eta0, Kx, Ky, AngFreq, Grav, ViscDel2, ViscDel4;
+   int VelDiffTendencyEnable, VelHyperDiffTendencyEnable;
+   const double *XCell, *YCell, *XEdge, *YEdge, *FEdge; /* HorzMesh members the functors read (local order) */
+} orc_manufactured;
+/* fills the constants; the caller sets the five coordinate pointers */
+void orc_manufactured_init(orc_manufactured *ms, const orc_mesh *m, const orc_config *c, double WavelengthX,
+                           double WavelengthY, double Amplitude);
+void orc_manufactured_thickness_tend(const orc_mesh *m, const orc_manufactured *ms, double *hTend, double ElapsedSec);
+void orc_manufactured_velocity_tend(const orc_mesh *m, const orc_manufactured *ms, double *uTend, double ElapsedSec);
+/* Tendencies::CustomThicknessTend / CustomVelocityTend (Tendencies.cpp:288-291, 416-419): when set, the
+ * two group functions add the manufactured terms at the time given by orc_set_time; the steppers set
+ * that time per stage from orc_set_sim_time (RungeKutta4Stepper.cpp:87, RungeKutta2Stepper.cpp:44,58,
+ * ForwardBackwardStepper.cpp:50,59,67). */
+void orc_set_custom_tendency(const orc_manufactured *ms);
+void orc_set_time(double ElapsedSec);
+void orc_set_sim_time(double SimTimeSec);
+
 void orc_set_num_threads(int n);
 int orc_get_max_threads(void);
 

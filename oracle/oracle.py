@@ -41,6 +41,12 @@ CONFIG_REALS = ("ViscDel2", "ViscDel4", "DivFactor", "EddyDiff2", "EddyDiff4", "
                 "BottomDragCoeff")
 
 
+class OrcManufactured(C.Structure):
+    _fields_ = ([(n, C.c_double) for n in ("H0", "Eta0", "Kx", "Ky", "AngFreq", "Grav", "ViscDel2", "ViscDel4")]
+                + [(n, C.c_int) for n in ("VelDiffTendencyEnable", "VelHyperDiffTendencyEnable")]
+                + [(n, PD) for n in ("XCell", "YCell", "XEdge", "YEdge", "FEdge")])
+
+
 class OrcConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in CONFIG_FLAGS] + [(n, C.c_double) for n in CONFIG_REALS]
 
@@ -91,6 +97,14 @@ def lib():
         L.orc_coeff_seconds.restype = C.c_double
         L.orc_coeff_seconds.argtypes = [C.c_double, C.c_double]
         L.orc_get_max_threads.restype = C.c_int
+        # OpenMP team size: a GPU box exposes every hardware thread of the host but gives the job a
+        # 16-core share; a team of hundreds of spinning threads on 16 cores makes each of the many
+        # small parallel regions of a time step take milliseconds
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        L.orc_set_num_threads(max(1, min(avail, int(os.environ.get("OMEGA_ORACLE_THREADS", "8")))))
         _lib = L
     return _lib
 
@@ -144,7 +158,7 @@ def single_rank_local_arrays(g: dict) -> dict:
                          ("KiteAreasOnVertex", "kiteAreasOnVertex", nV), ("DcEdge", "dcEdge", nE),
                          ("DvEdge", "dvEdge", nE), ("AngleEdge", "angleEdge", nE),
                          ("WeightsOnEdge", "weightsOnEdge", nE), ("FVertex", "fVertex", nV),
-                         ("BottomDepth", "bottomDepth", nC)):
+                         ("BottomDepth", "bottomDepth", nC), ("FEdge", "fEdge", nE), ("FCell", "fCell", nC)):
         L[name] = _pad_rows(np.ascontiguousarray(g[src], dtype=np.float64), n + 1, 0.0)
     for el, n in (("Cell", nC), ("Edge", nE), ("Vertex", nV)):
         for pre in ("x", "y", "z", "lon", "lat"):
@@ -263,6 +277,29 @@ class Oracle:
         self.L.orc_tend_compute_tracer(m, c, a, self.NT, _pd(self.trTend), _pd(h), _pd(u), _pd(tr))
         return self.trTend
 
+    def use_manufactured_solution(self, wavelength_x=None, wavelength_y=None, amplitude=None):
+        """Tendencies config UseCustomTendency + ManufacturedSolutionTendency (Tendencies.cpp:41-64):
+        from now on the thickness / velocity group functions of the ORACLE LIBRARY add the manufactured
+        terms (process-wide switch: call with no arguments to turn it off)."""
+        if wavelength_x is None:
+            self.L.orc_set_custom_tendency(None)
+            self.ms = None
+            return None
+        ms = OrcManufactured()
+        m, c, _ = self._r()
+        self.L.orc_manufactured_init(C.byref(ms), m, c, C.c_double(wavelength_x), C.c_double(wavelength_y),
+                                     C.c_double(amplitude))
+        self._ms_keep = [np.ascontiguousarray(getattr(self.m, n), dtype=np.float64)
+                         for n in ("XCell", "YCell", "XEdge", "YEdge", "FEdge")]
+        ms.XCell, ms.YCell, ms.XEdge, ms.YEdge, ms.FEdge = [_pd(a) for a in self._ms_keep]
+        self.ms = ms
+        self.L.orc_set_custom_tendency(C.byref(ms))
+        return ms
+
+    def set_time(self, t: float):
+        """model time (s since the reference time) seen by the custom tendencies in direct tendency calls"""
+        self.L.orc_set_time(C.c_double(t))
+
     def make_state(self, h, u, tr):
         """State with two time levels; level 0 initialised from h,u,tr (copied)."""
         st = {"h": [h.copy(), np.zeros_like(h)], "u": [u.copy(), np.zeros_like(u)],
@@ -270,9 +307,10 @@ class Oracle:
               "hProvis": np.zeros_like(h), "uProvis": np.zeros_like(u), "trProvis": np.zeros_like(tr)}
         return st
 
-    def step(self, kind: str, st: dict, dt: float, exchange=None):
-        """One doStep of 'rk4' | 'rk2' | 'fb'; swaps the time levels afterwards
-        (OceanState::updateTimeLevels)."""
+    def step(self, kind: str, st: dict, dt: float, exchange=None, sim_time: float = 0.0):
+        """One doStep of 'rk4' | 'rk2' | 'fb' starting at model time sim_time; swaps the time levels
+        afterwards (OceanState::updateTimeLevels)."""
+        self.L.orc_set_sim_time(C.c_double(sim_time))
         s = OrcState()
         for i in range(2):
             s.h[i], s.u[i], s.tr[i] = _pd(st["h"][i]), _pd(st["u"][i]), _pd(st["tr"][i])

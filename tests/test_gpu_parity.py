@@ -221,3 +221,68 @@ def test_known_answer_through_gpu():
     ka.check_errors("VelocityDiv", ka.compute_errors(M, P.aux.get("VelocityDivCell"),
                                                      ka.set_scalar(M, K, divergence, "Cell"), "Cell"),
                     (0.00124886886594453264, 0.00124886886590973452), 2e-4)
+
+
+def _ms_problem(nx, K=1, NT=1, fused=True):
+    from tests import manufactured as ms
+    g = ms.mesh(nx)
+    wx, wy = ms.wavelengths(g)
+    P = Problem(g, K, NT)
+    h, u, tr = ms.initial_state(P.omesh, K, NT, wx, wy)
+    P.h, P.u, P.tr = h, u, tr
+    P.state.copy_to_device(h, u, 0)
+    P.tracers.copy_to_device(tr, 0)
+    P.tend.set_fused(fused)
+    P.tend.use_manufactured_solution(P.mesh, wx, wy, ms.ETA0)
+    return P, wx, wy
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+def test_manufactured_tendencies_match_the_oracle(fused):
+    """Custom (manufactured-solution) tendencies through the Tendencies hooks, both RHS structures.
+    sin / cos come from the device libm here and glibc in the oracle: ulp-level differences in the
+    source term, so this path is compared at the contractual 1e-12, not bit for bit."""
+    from tests import manufactured as ms
+    P, wx, wy = _ms_problem(24, K=3, NT=1, fused=fused)
+    P.oracle.use_manufactured_solution(wx, wy, ms.ETA0)
+    try:
+        t = 4321.0
+        P.tend.set_time(t)
+        P.oracle.set_time(t)
+        P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+        oa.device_synchronize()
+        hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    finally:
+        P.oracle.use_manufactured_solution()
+    m = P.mesh
+    assert max_rel_diff(P.tend.get(0)[: m.NCellsOwned], hT[: m.NCellsOwned], scale=np.abs(hT).max()) <= RTOL
+    assert max_rel_diff(P.tend.get(1)[: m.NEdgesOwned], uT[: m.NEdgesOwned], scale=np.abs(uT).max()) <= RTOL
+    # and the source term is really there
+    P.tend.clear_custom_tendencies()
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    assert np.abs(P.tend.get(0)[: m.NCellsOwned] - hT[: m.NCellsOwned]).max() > 1e-6
+
+
+def test_manufactured_solution_converges_through_the_gpu_path():
+    """RK4 on the GPU with the custom tendencies (stage times from the stepper): second-order
+    convergence to the exact solution, and the same numbers as the oracle run to 1e-12."""
+    from tests import manufactured as ms
+    from tests.test_manufactured_solution import run_oracle
+    errs = {}
+    for nx in (16, 32):
+        P, wx, wy = _ms_problem(nx)
+        dt = 600.0 * 16 / nx
+        nsteps = int(round(3.0 * 3600 / dt))
+        st = oa.TimeStepper("RungeKutta4", dt, P.tend, P.aux, P.mesh, None, P.tracers)
+        for _ in range(nsteps):
+            st.do_step(P.state)
+        oa.device_synchronize()
+        assert abs(st.time - nsteps * dt) < 1e-9
+        h, _ = P.state.copy_to_host(0)
+        errs[nx] = ms.l2_error_h(P.omesh, h, nsteps * dt, wx, wy)
+        e_orc, ost = run_oracle(nx, hours=3.0)
+        assert abs(errs[nx] - e_orc) <= 1e-9 * e_orc
+        assert max_rel_diff(h[: P.mesh.NCellsOwned], ost["h"][0][: P.mesh.NCellsOwned]) <= 1e-11
+    rate = np.log2(errs[16] / errs[32])
+    assert 1.8 < rate < 2.3, (errs, rate)
