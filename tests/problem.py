@@ -17,7 +17,8 @@ def to_local(glob, ids_1based, rows_size):
 class Problem:
     """One rank's view of a global mesh: product objects (if a GPU is present) + oracle."""
 
-    def __init__(self, g, K, NT, nparts=1, rank=0, device=True, config=None, seed=20251003, halo_width=3):
+    def __init__(self, g, K, NT, nparts=1, rank=0, device=True, config=None, seed=20251003, halo_width=3,
+                 oracle=True):
         self.g, self.K, self.NT = g, K, NT
         self.gm = oa.GlobalMesh(g)
         self.decomp = oa.Decomp(self.gm, nparts, rank, halo_width)
@@ -30,9 +31,10 @@ class Problem:
         self.u = to_local(ug, self.edge_id, self.mesh.NEdgesSize)
         self.tr = to_local(trg, self.cell_id, self.mesh.NCellsSize)
         self.config_over = dict(config or {})
-        # oracle on the product's own local mesh arrays
-        self.omesh = O.Mesh(self.mesh.local_arrays(), K)
-        self.oracle = O.Oracle(self.omesh, NT, O.default_config(**self.config_over))
+        # oracle on the product's own local mesh arrays (skipped for the full-size property tests)
+        if oracle:
+            self.omesh = O.Mesh(self.mesh.local_arrays(), K)
+            self.oracle = O.Oracle(self.omesh, NT, O.default_config(**self.config_over))
         if device:
             cfg = oa.default_config(**self.config_over)
             self.halo = oa.Halo(self.decomp) if nparts > 1 else None

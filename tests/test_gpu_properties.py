@@ -1,0 +1,89 @@
+"""Size-independent properties of the HIP path at the full BASELINE size (QU30-sized mesh: 462 400
+cells x 80 levels x 6 tracers), where an element-wise oracle comparison would take minutes:
+
+* the thickness tendency and the (thickness-weighted) tracer tendencies are divergences of edge
+  fluxes, so their area-weighted global sums vanish on the periodic mesh (TendencyTerms.h:26-66,
+  343-492) -- to rounding;
+* the tracer tendency is linear in the tracer: scaling the tracers by a power of two scales it
+  exactly (bit for bit);
+* a time step conserves total volume and total tracer content;
+* fused and reference-structured RHS agree bit for bit (both are separately compared with the oracle
+  at small sizes in test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+import omega_amd as oa
+from omega_amd.meshgen import planar_hex, reorder_cells_morton
+from tests.problem import Problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    assert oa.device_count() > 0
+    oa.device_init(0)
+    g = reorder_cells_morton(planar_hex(680, 680, 30.0e3))
+    return Problem(g, 80, 6, oracle=False)
+
+
+def _sums(P, h_like, tr_like):
+    nc = P.mesh.NCellsOwned
+    a = P.mesh.get_array("AreaCell")[:nc, None]
+    return (a * h_like[:nc]).sum(), (a[None] * tr_like[:, :nc]).sum(axis=(1, 2))
+
+
+def test_flux_form_tendencies_sum_to_zero(P):
+    P.tend.set_fused(True)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, trT = P.tend.get(0), P.tend.get(2)
+    sh, st = _sums(P, hT, trT)
+    nh, nt = _sums(P, np.abs(hT), np.abs(trT))
+    assert abs(sh) <= 1e-12 * nh
+    assert np.all(np.abs(st) <= 1e-12 * nt)
+    assert nh > 0 and np.all(nt > 0)
+
+
+def test_fused_equals_reference_structured_at_full_size(P):
+    P.tend.set_fused(True)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    fused = [P.tend.get(i).copy() for i in range(3)]
+    P.tend.set_fused(False)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    m = P.mesh
+    for i, n in ((0, m.NCellsOwned), (1, m.NEdgesOwned), (2, m.NCellsOwned)):
+        assert np.array_equal(P.tend.get(i)[..., :n, :], fused[i][..., :n, :])
+    P.tend.set_fused(True)
+
+
+def test_tracer_tendency_is_linear_in_the_tracer(P):
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    t1 = P.tend.get(2).copy()
+    P.tracers.copy_to_device(4.0 * P.tr, 0)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    t4 = P.tend.get(2)
+    P.tracers.copy_to_device(P.tr, 0)
+    assert np.array_equal(t4[:, : P.mesh.NCellsOwned], 4.0 * t1[:, : P.mesh.NCellsOwned])
+
+
+def test_rk4_step_conserves_volume_and_tracer_content(P):
+    nc = P.mesh.NCellsOwned
+    v0, c0 = _sums(P, P.h, P.tr * P.h[None])
+    st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    st.do_step(P.state)
+    oa.device_synchronize()
+    h, _ = P.state.copy_to_host(0)
+    tr = P.tracers.copy_to_host(0)
+    v1, c1 = _sums(P, h, tr * h[None])
+    assert np.isfinite(h[:nc]).all() and not np.array_equal(h[:nc], P.h[:nc])
+    assert abs(v1 - v0) <= 1e-13 * abs(v0)
+    assert np.all(np.abs(c1 - c0) <= 1e-13 * np.abs(c0))
+    # restore the initial state for any test that follows
+    P.state.copy_to_device(P.h, P.u, 0)
+    P.tracers.copy_to_device(P.tr, 0)
