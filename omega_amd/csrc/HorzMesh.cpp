@@ -1,6 +1,8 @@
 // HorzMesh.cpp -- see HorzMesh.h.
 #include "HorzMesh.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 
@@ -379,7 +381,13 @@ void HorzMesh::buildCoefficientTables() {
    W.PVChainVert = PVChainVert.Ptr, W.PVChainFar = PVChainFar.Ptr, W.PVChainEdge = PVChainEdge.Ptr;
    W.PVChainWeight = PVChainWeight.Ptr;
    HostChV = ChV, HostChF = ChF, HostChE = ChE, HostNbrF = NbrF;
-   buildPatches();
+   // the LDS-patch kernels are experiments behind OMEGA_EDGE_MODE=2 / OMEGA_CELL_MODE=1: their tables
+   // (several hundred bytes per element) are only built when one of them is requested
+   {
+      const char *EM = getenv("OMEGA_EDGE_MODE"), *CM = getenv("OMEGA_CELL_MODE");
+      if ((EM && atoi(EM) == 2) || (CM && atoi(CM) == 1))
+         buildPatches();
+   }
    HostChW = ChW;
    buildCellPV();
    buildDel2Tables();

@@ -159,7 +159,7 @@ class HorzMesh {
    void copyToDevice();      // HorzMesh.cpp:630-...
    void buildCoefficientTables();
 
-   MeshView View;
+   MeshView View{};
    // coefficient tables (device)
    Array1DReal InvAreaCell, InvDcEdge, InvDvEdge, InvDvEdgeDel2;
    Array2DReal DvSignOnCell, DivCoefOnCell, KECoefOnCell, MaskDvSignOnCell, Del2TrCoefOnCell, Diff2CoefOnCell,
