@@ -288,9 +288,23 @@ def cpu_baseline(K, NT, dc):
         if el > 10.0 or n >= 50:
             break
     v = gs["nCells"] * K * n / el
+    # SYPD of the CPU path: RK4 steps of the oracle on the same sample, scaled by the cell ratio
+    st = orc.make_state(hs, us, trs)
+    orc.step("rk4", st, 600.0)  # warm-up
+    nst, t1 = 0, time.perf_counter()
+    while True:
+        orc.step("rk4", st, 600.0, sim_time=600.0 * (nst + 1))
+        nst += 1
+        el2 = time.perf_counter() - t1
+        if el2 > 5.0 or nst >= 10:
+            break
+    ratio = WORKLOADS["qu30"][0] * WORKLOADS["qu30"][1] / gs["nCells"]
+    sypd_cpu = (600.0 / (el2 / nst * ratio)) / 365.0
     return {"value": v, "unit": "cell-level-updates/s", "cores": cores, "kind": "port",
-            "sample": f"{n} RHS evaluations of a {nxs}x{nys}-cell ({gs['nCells']} cells = 1/16 of the workload) x {K}L x "
-                      f"{NT} tracers mesh, reference launch structure (23 passes), OpenMP threads = cores"}
+            "sypd": sypd_cpu, "rk4_steps": nst,
+            "sample": f"{n} RHS evaluations and {nst} RK4 steps of a {nxs}x{nys}-cell ({gs['nCells']} cells = 1/16 of the "
+                      f"workload) x {K}L x {NT} tracers mesh, reference launch structure (23 passes), OpenMP threads = "
+                      f"cores; sypd = dt 600 s / (sample step time x 16)"}
 
 
 if __name__ == "__main__":
