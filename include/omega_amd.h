@@ -68,6 +68,21 @@ typedef struct omg_global_mesh {
    const double *fCell, *fEdge, *fVertex, *bottomDepth;
 } omg_global_mesh;
 
+/* ---- MPAS mesh / initial-state file (O/src/base/Decomp.cpp:108-395 readMesh and O/src/ocn/HorzMesh.cpp:424-523
+ *      read the same variables through SCORPIO): NetCDF classic CDF-1 / CDF-2 / CDF-5, both name conventions
+ *      ("NCells" | "nCells", "CellsOnCell" | "cellsOnCell", ...), indices converted to 0-based / -1.
+ *      omg_mesh_file_global_mesh fills `m` with pointers that stay valid until omg_mesh_file_close.
+ *      omg_mesh_file_read_f64 reads any variable (e.g. layerThickness, normalVelocity, temperature of an initial
+ *      state; record < 0 = all records) converted to double; omg_mesh_file_var_size = its element count
+ *      (-1 if absent); omg_mesh_file_dim = a dimension length (-1 if absent). ---- */
+typedef struct omg_mesh_file omg_mesh_file;
+int omg_mesh_file_open(const char *path, omg_mesh_file **out);
+int omg_mesh_file_close(omg_mesh_file *f);
+int omg_mesh_file_global_mesh(const omg_mesh_file *f, omg_global_mesh *m);
+int omg_mesh_file_dim(const omg_mesh_file *f, const char *name, int64_t *len);
+int omg_mesh_file_var_size(const omg_mesh_file *f, const char *name, int64_t record, int64_t *n);
+int omg_mesh_file_read_f64(const omg_mesh_file *f, const char *name, int64_t record, double *out, size_t n);
+
 /* ---- Decomp (O/src/base/Decomp.cpp:444-745 constructor; Decomp.h:189-260 members).
  *      cell_task: optional [nCells] owner task of each cell (e.g. a METIS part file);
  *      NULL = built-in recursive coordinate bisection.  The global mesh arrays must stay

@@ -176,6 +176,67 @@ class GlobalMesh:
         self.s = s
 
 
+class MeshFile:
+    """An MPAS mesh / initial-state file (NetCDF classic CDF-1/2/5) opened by the library's own reader;
+    `.gm` is the GlobalMesh to build a Decomp from (the arrays live inside the file handle)."""
+
+    def __init__(self, path: str):
+        h = C.c_void_p()
+        _chk(lib().omg_mesh_file_open(os.fsencode(path), C.byref(h)))
+        self.h = h
+        gm = GlobalMesh.__new__(GlobalMesh)
+        gm.s = GlobalMeshC()
+        gm.keep = {"file": self}
+        _chk(lib().omg_mesh_file_global_mesh(self.h, C.byref(gm.s)))
+        self.gm = gm
+
+    def dim(self, name: str) -> int:
+        v = C.c_int64()
+        _chk(lib().omg_mesh_file_dim(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def read(self, name: str, record: int = -1) -> np.ndarray:
+        n = C.c_int64()
+        _chk(lib().omg_mesh_file_var_size(self.h, name.encode(), C.c_int64(record), C.byref(n)))
+        if n.value < 0:
+            raise KeyError(name)
+        out = np.empty(n.value, dtype=np.float64)
+        _chk(lib().omg_mesh_file_read_f64(self.h, name.encode(), C.c_int64(record), _pd(out), C.c_size_t(n.value)))
+        return out
+
+    def arrays(self) -> dict:
+        """The global mesh as numpy copies, keyed like a meshgen mesh (test use)."""
+        s = self.gm.s
+        nC, nE, nV, mE, vD = s.nCells, s.nEdges, s.nVertices, s.maxEdges, s.vertexDegree
+        shp = {"cellsOnCell": (nC, mE), "edgesOnCell": (nC, mE), "verticesOnCell": (nC, mE), "cellsOnEdge": (nE, 2),
+               "verticesOnEdge": (nE, 2), "edgesOnEdge": (nE, 2 * mE), "cellsOnVertex": (nV, vD),
+               "edgesOnVertex": (nV, vD), "kiteAreasOnVertex": (nV, vD), "weightsOnEdge": (nE, 2 * mE)}
+        out = {"nCells": nC, "nEdges": nE, "nVertices": nV, "maxEdges": mE, "vertexDegree": vD}
+        for n in GlobalMeshC._I + GlobalMeshC._R:
+            p = getattr(s, n)
+            el = n[-4:] == "Cell" and nC or n[-4:] == "Edge" and nE or nV
+            if n == "areaTriangle":
+                el = nV
+            if n == "bottomDepth":
+                el = nC
+            shape = shp.get(n, (el,))
+            out[n] = np.ctypeslib.as_array(p, shape=(int(np.prod(shape)),)).reshape(shape).copy()
+        return out
+
+    def __del__(self):
+        try:
+            lib().omg_mesh_file_close(self.h)
+        except Exception:
+            pass
+
+
+def read_partition_file(path: str) -> np.ndarray:
+    """A METIS partition file (`graph.info.part.N`: one owner task per line, cell order) as the
+    cell_task vector of Decomp -- the reference calls METIS itself (Decomp.cpp:868-1000); production
+    runs with pre-computed partitions pass them here."""
+    return np.loadtxt(path, dtype=np.int32, ndmin=1)
+
+
 class Decomp:
     def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None):
         self.gm = gm

@@ -8,6 +8,7 @@
 #include "OceanState.h"
 #include "Tendencies.h"
 #include "CustomTendencyTerms.h"
+#include "MeshIO.h"
 #include "TimeStepper.h"
 
 #include <cstring>
@@ -33,6 +34,9 @@ struct omg_tracers {
 };
 struct omg_aux {
    std::unique_ptr<AuxiliaryState> A;
+};
+struct omg_mesh_file {
+   std::unique_ptr<MeshFile> F;
 };
 struct omg_tend {
    std::unique_ptr<Tendencies> T;
@@ -127,6 +131,75 @@ int omg_event_elapsed_ms(void *start, void *stop, float *ms) {
    OMG_ARG(ms);
    HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
    HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- mesh file
+int omg_mesh_file_open(const char *path, omg_mesh_file **out) {
+   OMG_TRY
+   OMG_ARG(path && out);
+   auto *R = new omg_mesh_file;
+   try {
+      R->F.reset(new MeshFile(path));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_mesh_file_close(omg_mesh_file *f) {
+   delete f;
+   return 0;
+}
+int omg_mesh_file_global_mesh(const omg_mesh_file *f, omg_global_mesh *m) {
+   OMG_TRY
+   OMG_ARG(f && m);
+   const GlobalMeshDesc &G = f->F->desc();
+   m->nCells = G.NCells, m->nEdges = G.NEdges, m->nVertices = G.NVertices, m->maxEdges = G.MaxEdges;
+   m->vertexDegree = G.VertexDegree;
+   m->cellsOnCell = G.CellsOnCell, m->edgesOnCell = G.EdgesOnCell, m->verticesOnCell = G.VerticesOnCell;
+   m->cellsOnEdge = G.CellsOnEdge, m->verticesOnEdge = G.VerticesOnEdge, m->edgesOnEdge = G.EdgesOnEdge;
+   m->cellsOnVertex = G.CellsOnVertex, m->edgesOnVertex = G.EdgesOnVertex;
+   m->xCell = G.XCell, m->yCell = G.YCell, m->zCell = G.ZCell, m->lonCell = G.LonCell, m->latCell = G.LatCell;
+   m->xEdge = G.XEdge, m->yEdge = G.YEdge, m->zEdge = G.ZEdge, m->lonEdge = G.LonEdge, m->latEdge = G.LatEdge;
+   m->xVertex = G.XVertex, m->yVertex = G.YVertex, m->zVertex = G.ZVertex, m->lonVertex = G.LonVertex;
+   m->latVertex = G.LatVertex;
+   m->areaCell = G.AreaCell, m->areaTriangle = G.AreaTriangle, m->kiteAreasOnVertex = G.KiteAreasOnVertex;
+   m->dcEdge = G.DcEdge, m->dvEdge = G.DvEdge, m->angleEdge = G.AngleEdge, m->weightsOnEdge = G.WeightsOnEdge;
+   m->fCell = G.FCell, m->fEdge = G.FEdge, m->fVertex = G.FVertex, m->bottomDepth = G.BottomDepth;
+   OMG_CATCH
+}
+int omg_mesh_file_dim(const omg_mesh_file *f, const char *name, int64_t *len) {
+   OMG_TRY
+   OMG_ARG(f && name && len);
+   *len = f->F->file().hasDim(name) ? f->F->file().dimLen(name) : -1;
+   OMG_CATCH
+}
+int omg_mesh_file_var_size(const omg_mesh_file *f, const char *name, int64_t record, int64_t *n) {
+   OMG_TRY
+   OMG_ARG(f && name && n);
+   if (!f->F->file().hasVar(name)) {
+      *n = -1;
+   } else {
+      const std::vector<I8> S = f->F->file().shape(name);
+      const bool Rec          = f->F->file().var(name).IsRecord;
+      I8 N                    = 1;
+      for (size_t D = (Rec && record >= 0) ? 1 : 0; D < S.size(); ++D)
+         N *= S[D];
+      *n = N;
+   }
+   OMG_CATCH
+}
+int omg_mesh_file_read_f64(const omg_mesh_file *f, const char *name, int64_t record, double *out, size_t n) {
+   OMG_TRY
+   OMG_ARG(f && name && out);
+   std::vector<R8> V;
+   f->F->file().read(name, V, record);
+   if (V.size() != n)
+      OMEGA_ABORT(std::string("omg_mesh_file_read_f64: ") + name + " has " + std::to_string(V.size()) +
+                  " values, buffer holds " + std::to_string(n));
+   std::memcpy(out, V.data(), n * sizeof(double));
    OMG_CATCH
 }
 
