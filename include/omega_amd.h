@@ -68,6 +68,23 @@ typedef struct omg_global_mesh {
    const double *fCell, *fEdge, *fVertex, *bottomDepth;
 } omg_global_mesh;
 
+/* ---- raw device buffers for hosts without their own HIP runtime binding (Kokkos::View allocation / deep_copy) ---- */
+int omg_device_malloc(size_t bytes, void **ptr);
+int omg_device_free(void *ptr);
+int omg_copy_to_device(void *dst, const void *src, size_t bytes);
+int omg_copy_to_host(void *dst, const void *src, size_t bytes);
+
+/* ---- Reductions (O/src/base/Reductions.h:17-88 and the array forms :150-190, :262-310): sums in double-double.
+ *      omg_local_sum_dd: sum a[i] (b == NULL) or sum a[i]*b[i] over n DEVICE values; omg_local_weighted_sum_dd:
+ *      sum_r w[r] * sum_k a[r][k](*b[r][k]) over the first nrows rows of [rows][k] device arrays (w per row, e.g.
+ *      AreaCell x layer thickness x tracer = tracer content).  hi_lo[0] + hi_lo[1] is the sum.
+ *      omg_combine_dd: the reference's MPI_SUMDD operator applied in order to npairs (hi, lo) pairs -- how the
+ *      per-rank partial sums are combined after an all-gather (globalSum). ---- */
+int omg_local_sum_dd(const double *a, const double *b, size_t n, void *stream, double *hi_lo);
+int omg_local_weighted_sum_dd(const double *w, const double *a, const double *b, int nrows, int k, void *stream,
+                              double *hi_lo);
+int omg_combine_dd(const double *pairs, int npairs, double *hi_lo);
+
 /* ---- MPAS mesh / initial-state file (O/src/base/Decomp.cpp:108-395 readMesh and O/src/ocn/HorzMesh.cpp:424-523
  *      read the same variables through SCORPIO): NetCDF classic CDF-1 / CDF-2 / CDF-5, both name conventions
  *      ("NCells" | "nCells", "CellsOnCell" | "cellsOnCell", ...), indices converted to 0-based / -1.

@@ -230,6 +230,64 @@ class MeshFile:
             pass
 
 
+class DeviceBuffer:
+    """A device copy of a host array (omg_device_malloc / omg_copy_to_device)."""
+
+    def __init__(self, host: np.ndarray):
+        self.host = np.ascontiguousarray(host)
+        p = C.c_void_p()
+        _chk(lib().omg_device_malloc(C.c_size_t(self.host.nbytes), C.byref(p)))
+        self.ptr = p.value
+        _chk(lib().omg_copy_to_device(C.c_void_p(self.ptr), self.host.ctypes.data_as(C.c_void_p), C.c_size_t(self.host.nbytes)))
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty_like(self.host)
+        _chk(lib().omg_copy_to_host(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def __del__(self):
+        try:
+            lib().omg_device_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def combine_dd(pairs) -> tuple:
+    """ddSum (Reductions.h:24-35) over an [n][2] array of (hi, lo) partial sums, in order."""
+    p = np.ascontiguousarray(pairs, dtype=np.float64).reshape(-1, 2)
+    out = (C.c_double * 2)()
+    _chk(lib().omg_combine_dd(_pd(p), p.shape[0], out))
+    return out[0], out[1]
+
+
+def local_sum_dd(a_ptr: int, n: int, b_ptr: int = 0, stream=None) -> tuple:
+    """Double-double sum of n device doubles at a_ptr (times those at b_ptr if given)."""
+    out = (C.c_double * 2)()
+    _chk(lib().omg_local_sum_dd(C.c_void_p(a_ptr), C.c_void_p(b_ptr) if b_ptr else None, C.c_size_t(n), _sh(stream), out))
+    return out[0], out[1]
+
+
+def local_weighted_sum_dd(w_ptr: int, a_ptr: int, nrows: int, k: int, b_ptr: int = 0, stream=None) -> tuple:
+    out = (C.c_double * 2)()
+    _chk(lib().omg_local_weighted_sum_dd(C.c_void_p(w_ptr), C.c_void_p(a_ptr), C.c_void_p(b_ptr) if b_ptr else None,
+                                         nrows, k, _sh(stream), out))
+    return out[0], out[1]
+
+
+def global_sum_dd(local_hi_lo, group=None) -> float:
+    """globalSum (Reductions.h:71-84): all-gather the ranks' (hi, lo) partial sums and combine them with the
+    ddSum operator in rank order -- the same value on every rank and for every partition."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return combine_dd([local_hi_lo])[0]
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor(list(local_hi_lo), dtype=torch.float64, device=dev)
+    allp = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(allp, mine, group=group)
+    return combine_dd(torch.stack(allp).cpu().numpy())[0]
+
+
 def read_partition_file(path: str) -> np.ndarray:
     """A METIS partition file (`graph.info.part.N`: one owner task per line, cell order) as the
     cell_task vector of Decomp -- the reference calls METIS itself (Decomp.cpp:868-1000); production

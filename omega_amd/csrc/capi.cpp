@@ -134,6 +134,53 @@ int omg_event_elapsed_ms(void *start, void *stop, float *ms) {
    OMG_CATCH
 }
 
+// ---------------------------------------------------------------- raw device buffers
+int omg_device_malloc(size_t bytes, void **ptr) {
+   OMG_TRY
+   OMG_ARG(ptr);
+   HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 1));
+   OMG_CATCH
+}
+int omg_device_free(void *ptr) {
+   OMG_TRY
+   if (ptr)
+      HIP_CHECK(hipFree(ptr));
+   OMG_CATCH
+}
+int omg_copy_to_device(void *dst, const void *src, size_t bytes) {
+   OMG_TRY
+   OMG_ARG(dst && src);
+   HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+   OMG_CATCH
+}
+int omg_copy_to_host(void *dst, const void *src, size_t bytes) {
+   OMG_TRY
+   OMG_ARG(dst && src);
+   HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+   OMG_CATCH
+}
+
+// ---------------------------------------------------------------- reductions
+int omg_local_sum_dd(const double *a, const double *b, size_t n, void *stream, double *hi_lo) {
+   OMG_TRY
+   OMG_ARG(a && hi_lo);
+   localSumDD(a, b, n, (hipStream_t)stream, hi_lo);
+   OMG_CATCH
+}
+int omg_local_weighted_sum_dd(const double *w, const double *a, const double *b, int nrows, int k, void *stream,
+                              double *hi_lo) {
+   OMG_TRY
+   OMG_ARG(w && a && hi_lo && nrows >= 0 && k > 0);
+   localWeightedSumDD(w, a, b, nrows, k, (hipStream_t)stream, hi_lo);
+   OMG_CATCH
+}
+int omg_combine_dd(const double *pairs, int npairs, double *hi_lo) {
+   OMG_TRY
+   OMG_ARG(pairs && hi_lo && npairs >= 0);
+   combineDD(pairs, npairs, hi_lo);
+   OMG_CATCH
+}
+
 // ---------------------------------------------------------------- mesh file
 int omg_mesh_file_open(const char *path, omg_mesh_file **out) {
    OMG_TRY

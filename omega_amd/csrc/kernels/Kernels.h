@@ -88,6 +88,16 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
                     hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr, const StageUpdate *Stage = nullptr);
 /// EdgeScratch: optional [NEdgesSize][K] work array for the cell-centric PV sums (faster path)
 
+// ---- reductions (base/Reductions.h): double-double local sums on the device ----
+/// sum_i A[i] (B == nullptr) or sum_i A[i]*B[i] over N values, accumulated in double-double (Knuth
+/// two-sum per element, the ddSum combination of Reductions.h:24-35 between threads / workgroups);
+/// HiLo[0] + HiLo[1] is the sum, HiLo[0] its rounded value.  Synchronises the stream.
+void localSumDD(const Real *A, const Real *B, size_t N, hipStream_t S, double HiLo[2]);
+/// element rows [0, NRows) of a [RowsSize][K] array times a per-row weight (e.g. AreaCell): sum_r W[r]*sum_k A[r][k]*B[r][k]
+void localWeightedSumDD(const Real *W, const Real *A, const Real *B, int NRows, int K, hipStream_t S, double HiLo[2]);
+/// ddSum (Reductions.h:24-35) over NPairs (hi, lo) pairs in order: how per-rank partial sums are combined
+void combineDD(const double *Pairs, int NPairs, double HiLo[2]);
+
 // ---- ManufacturedSolution custom tendencies (CustomTendencyTerms.cpp:112-208) ----
 struct ManufacturedParams {
    Real H0, Eta0, Kx, Ky, AngFreq, Grav, ViscDel2, ViscDel4;

@@ -7,6 +7,9 @@
 #include "KernelCommon.h"
 #include "Kernels.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace OMEGA {
 
 // ---------------------------------------------------------------------------------------
@@ -520,6 +523,101 @@ void launchManufacturedVelocity(int N, int K, Real *Tend, const Real *XEdge, con
    hipLaunchKernelGGL(manufacturedVelocityKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, Tend, XEdge, YEdge, FEdge,
                       AngleEdge, P, T);
    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
+// Reproducible sums (reference: components/omega/src/base/Reductions.h).  The reference's host path
+// accumulates in double-double (Knuth) and combines ranks with the ddSum MPI operator; its device path
+// falls back to a plain parallelReduce.  Here the device path keeps the double-double arithmetic:
+// (hi, lo) per thread, combined with the same ddSum expression across the workgroup and across
+// workgroups, so the result does not depend on the launch geometry or the partition to within
+// double-double rounding (~1e-32 relative).
+struct DD {
+   double Hi, Lo;
+};
+__host__ __device__ inline DD ddAdd(DD A, DD B) { // ddSum, Reductions.h:24-35
+   const double T1 = A.Hi + B.Hi;
+   const double E  = T1 - A.Hi;
+   const double T2 = ((B.Hi - E) + (A.Hi - (T1 - E))) + A.Lo + B.Lo;
+   DD R;
+   R.Hi = T1 + T2;
+   R.Lo = T2 - ((T1 + T2) - T1);
+   return R;
+}
+__host__ __device__ inline DD ddAddScalar(DD S, double Ai) { // Knuth accumulation, Reductions.h:171-179
+   const double T1 = Ai + S.Hi;
+   const double E  = T1 - Ai;
+   const double T2 = ((S.Hi - E) + (Ai - (T1 - E))) + S.Lo;
+   DD R;
+   R.Hi = T1 + T2;
+   R.Lo = T2 - ((T1 + T2) - T1);
+   return R;
+}
+__device__ inline DD blockReduceDD(DD V) {
+   __shared__ DD Sh[256];
+   const int T = threadIdx.x;
+   Sh[T]       = V;
+   __syncthreads();
+   for (int Off = 128; Off > 0; Off >>= 1) {
+      if (T < Off)
+         Sh[T] = ddAdd(Sh[T], Sh[T + Off]);
+      __syncthreads();
+   }
+   return Sh[0];
+}
+__global__ void __launch_bounds__(256) sumDDKernel(const Real *A, const Real *B, size_t N, DD *Partial) {
+   DD Acc{0.0, 0.0};
+   for (size_t I = (size_t)blockIdx.x * 256 + threadIdx.x; I < N; I += (size_t)gridDim.x * 256)
+      Acc = ddAddScalar(Acc, B ? A[I] * B[I] : A[I]);
+   const DD R = blockReduceDD(Acc);
+   if (threadIdx.x == 0)
+      Partial[blockIdx.x] = R;
+}
+__global__ void __launch_bounds__(256) weightedSumDDKernel(const Real *W, const Real *A, const Real *B, int NRows, int K,
+                                                           DD *Partial) {
+   DD Acc{0.0, 0.0};
+   const size_t N = (size_t)NRows * K;
+   for (size_t I = (size_t)blockIdx.x * 256 + threadIdx.x; I < N; I += (size_t)gridDim.x * 256) {
+      const double V = B ? A[I] * B[I] : A[I];
+      Acc            = ddAddScalar(Acc, W[I / K] * V);
+   }
+   const DD R = blockReduceDD(Acc);
+   if (threadIdx.x == 0)
+      Partial[blockIdx.x] = R;
+}
+static void finishDD(DD *PartialD, int NB, hipStream_t S, double HiLo[2]) {
+   std::vector<DD> H(NB);
+   HIP_CHECK(hipMemcpyAsync(H.data(), PartialD, NB * sizeof(DD), hipMemcpyDeviceToHost, S));
+   HIP_CHECK(hipStreamSynchronize(S));
+   DD Acc{0.0, 0.0};
+   for (int I = 0; I < NB; ++I)
+      Acc = ddAdd(Acc, H[I]);
+   HiLo[0] = Acc.Hi, HiLo[1] = Acc.Lo;
+   HIP_CHECK(hipFree(PartialD));
+}
+void localSumDD(const Real *A, const Real *B, size_t N, hipStream_t S, double HiLo[2]) {
+   const int NB = (int)std::min<size_t>(1024, (N + 255) / 256 ? (N + 255) / 256 : 1);
+   DD *PartialD = nullptr;
+   HIP_CHECK(hipMalloc(&PartialD, NB * sizeof(DD)));
+   hipLaunchKernelGGL(sumDDKernel, dim3(NB), dim3(256), 0, S, A, B, N, PartialD);
+   HIP_CHECK(hipGetLastError());
+   finishDD(PartialD, NB, S, HiLo);
+}
+void localWeightedSumDD(const Real *W, const Real *A, const Real *B, int NRows, int K, hipStream_t S, double HiLo[2]) {
+   const size_t N = (size_t)NRows * K;
+   const int NB   = (int)std::min<size_t>(1024, (N + 255) / 256 ? (N + 255) / 256 : 1);
+   DD *PartialD   = nullptr;
+   HIP_CHECK(hipMalloc(&PartialD, NB * sizeof(DD)));
+   hipLaunchKernelGGL(weightedSumDDKernel, dim3(NB), dim3(256), 0, S, W, A, B, NRows, K, PartialD);
+   HIP_CHECK(hipGetLastError());
+   finishDD(PartialD, NB, S, HiLo);
+}
+/// host-side ddSum over an array of (hi, lo) pairs, in order (the combination across ranks)
+void combineDD(const double *Pairs, int NPairs, double HiLo[2]) {
+   DD Acc{0.0, 0.0};
+   for (int I = 0; I < NPairs; ++I)
+      Acc = ddAdd(Acc, DD{Pairs[2 * I], Pairs[2 * I + 1]});
+   HiLo[0] = Acc.Hi, HiLo[1] = Acc.Lo;
 }
 
 } // namespace OMEGA
