@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import omega_amd as oa  # noqa: E402
-from omega_amd.meshgen import planar_hex, reorder_cells_blocked, reorder_cells_morton, synthetic_state  # noqa: E402
+from omega_amd.meshgen import (icosahedral_points, planar_hex, reorder_cells_blocked, reorder_cells_morton,  # noqa: E402
+                               spherical_voronoi, synthetic_state)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -40,6 +41,8 @@ WORKLOADS = {
     "qu30_quarter": (340, 340, 30.0e3, 80, 6, "one quarter of the QU30-sized mesh (340x340 = 115600 cells), 80L, 6 tracers"),
     "orrs18to6_eighth": (680, 680, 6.0e3, 80, 37,
                          "one eighth of an oRRS18to6-sized mesh (680x680 = 462400 of 3.7M cells), 80L, 37 tracers"),
+    "ico7": (0, 7, 0.0, 80, 6, "spherical icosahedral Voronoi mesh, 163842 cells (12 pentagons), 80L, 6 tracers"),
+    "ico6": (0, 6, 0.0, 60, 2, "spherical icosahedral Voronoi mesh, 40962 cells (12 pentagons), 60L, 2 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
 }
 
@@ -109,8 +112,13 @@ def main():
     oa.device_init(local_rank)
 
     t0 = time.time()
-    g = planar_hex(nx, ny, dc)
-    if args.block <= 0:
+    if args.workload.startswith("ico"):   # sphere: cells already numbered along a Morton curve in (lon, z)
+        g = spherical_voronoi(points=icosahedral_points(ny), lloyd=0)
+    else:
+        g = planar_hex(nx, ny, dc)
+    if args.workload.startswith("ico"):
+        pass
+    elif args.block <= 0:
         g = reorder_cells_morton(g, hilbert=args.block < 0)
     elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
