@@ -381,13 +381,6 @@ void HorzMesh::buildCoefficientTables() {
    W.PVChainVert = PVChainVert.Ptr, W.PVChainFar = PVChainFar.Ptr, W.PVChainEdge = PVChainEdge.Ptr;
    W.PVChainWeight = PVChainWeight.Ptr;
    HostChV = ChV, HostChF = ChF, HostChE = ChE, HostNbrF = NbrF;
-   // the LDS-patch kernels are experiments behind OMEGA_EDGE_MODE=2 / OMEGA_CELL_MODE=1: their tables
-   // (several hundred bytes per element) are only built when one of them is requested
-   {
-      const char *EM = getenv("OMEGA_EDGE_MODE"), *CM = getenv("OMEGA_CELL_MODE");
-      if ((EM && atoi(EM) == 2) || (CM && atoi(CM) == 1))
-         buildPatches();
-   }
    HostChW = ChW;
    buildCellPV();
    buildDel2Tables();
@@ -608,121 +601,6 @@ void HorzMesh::buildCellPV() {
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
    W.RingVertOnCell = RingVertOnCell.Ptr, W.PVRoleOnCell = PVRoleOnCell.Ptr, W.PVWeightOnCell = PVWeightOnCell.Ptr;
    W.EdgeRegular = EdgeRegular.Ptr, W.IrregularEdges = IrregularEdges.Ptr;
-}
-
-// Patch tables for the LDS-tiled kernels.  Patches are consecutive index ranges, so their
-// shape -- and the ratio of unique rows to own rows -- follows the mesh ordering (meshes sorted
-// for locality give compact patches); any ordering is handled.
-void HorzMesh::buildPatches() {
-   const int ME = MaxEdges, MEm1 = ME - 1;
-   MeshView &W = View;
-   // ---------------- edge patches ----------------
-   {
-      const int PE = 64;
-      const int NP = (NEdgesAll + PE - 1) / PE;
-      const int LS = 4 + 2 * ME + 4 * MEm1; // c0, c1, ChV, ChF, ChE, v0, v1
-      std::vector<I4> Off((size_t)NP * 4, 0), List;
-      std::vector<unsigned short> Loc((size_t)NP * PE * LS, 0);
-      std::vector<I4> StampC(NCellsSize, -1), StampV(NVerticesSize, -1), StampE(NEdgesSize, -1);
-      std::vector<I4> LocC(NCellsSize, 0), LocV(NVerticesSize, 0), LocE(NEdgesSize, 0);
-      int MaxC = 0, MaxV = 0, MaxE = 0;
-      bool Fits = true;
-      for (int P = 0; P < NP; ++P) {
-         std::vector<I4> LC, LV, LE;
-         auto Add = [&](std::vector<I4> &L, std::vector<I4> &Stamp, std::vector<I4> &LocOf, int G) {
-            if (Stamp[G] != P) {
-               Stamp[G] = P;
-               LocOf[G] = (int)L.size();
-               L.push_back(G);
-            }
-            return LocOf[G];
-         };
-         const int E0 = P * PE, E1 = std::min(NEdgesAll, E0 + PE);
-         for (int E = E0; E < E0 + PE; ++E) {
-            unsigned short *Lp = &Loc[((size_t)P * PE + (E - E0)) * LS];
-            const int Es = E < E1 ? E : NEdgesAll; // padding elements use the sentinel edge's (empty) stencil
-            Lp[0] = (unsigned short)Add(LC, StampC, LocC, CellsOnEdgeH(Es, 0));
-            Lp[1] = (unsigned short)Add(LC, StampC, LocC, CellsOnEdgeH(Es, 1));
-            for (int Sd = 0; Sd < 2; ++Sd) {
-               for (int J = 0; J < ME; ++J)
-                  Lp[2 + Sd * ME + J] = (unsigned short)Add(LV, StampV, LocV, HostChV.V[((size_t)Es * 2 + Sd) * ME + J]);
-               for (int J = 0; J < MEm1; ++J) {
-                  const I4 F   = HostChF.V[((size_t)Es * 2 + Sd) * MEm1 + J];
-                  const int Li = Add(LC, StampC, LocC, F & 0x3fffffff);
-                  Lp[2 + 2 * ME + Sd * MEm1 + J] = (unsigned short)(Li | ((F >> 30) ? 0x8000 : 0));
-                  Lp[2 + 2 * ME + 2 * MEm1 + Sd * MEm1 + J] =
-                      (unsigned short)Add(LE, StampE, LocE, HostChE.V[((size_t)Es * 2 + Sd) * MEm1 + J]);
-               }
-            }
-            Lp[LS - 2] = (unsigned short)Add(LV, StampV, LocV, VerticesOnEdgeH(Es, 0));
-            Lp[LS - 1] = (unsigned short)Add(LV, StampV, LocV, VerticesOnEdgeH(Es, 1));
-         }
-         if (LC.size() >= 0x8000 || LV.size() >= 0xffff || LE.size() >= 0xffff)
-            Fits = false;
-         Off[(size_t)P * 4 + 0] = (I4)List.size();
-         List.insert(List.end(), LC.begin(), LC.end());
-         Off[(size_t)P * 4 + 1] = (I4)List.size();
-         List.insert(List.end(), LV.begin(), LV.end());
-         Off[(size_t)P * 4 + 2] = (I4)List.size();
-         List.insert(List.end(), LE.begin(), LE.end());
-         Off[(size_t)P * 4 + 3] = (I4)List.size();
-         MaxC = std::max(MaxC, (int)LC.size());
-         MaxV = std::max(MaxV, (int)LV.size());
-         MaxE = std::max(MaxE, (int)LE.size());
-      }
-      EPListOff = Array1DI4("EPListOff", (int)Off.size());
-      EPList    = Array1DI4("EPList", (int)std::max<size_t>(List.size(), 1));
-      EPLocal   = DeviceArray<unsigned short, 1>("EPLocal", (int)std::max<size_t>(Loc.size(), 1));
-      OMEGA::copyToDevice(EPListOff.Ptr, Off.data(), Off.size() * sizeof(I4));
-      OMEGA::copyToDevice(EPList.Ptr, List.data(), List.size() * sizeof(I4));
-      OMEGA::copyToDevice(EPLocal.Ptr, Loc.data(), Loc.size() * sizeof(unsigned short));
-      W.EPSize = PE, W.EPCount = Fits ? NP : 0, W.EPMaxC = MaxC, W.EPMaxV = MaxV, W.EPMaxE = MaxE, W.EPLocStride = LS;
-      W.EPListOff = EPListOff.Ptr, W.EPList = EPList.Ptr, W.EPLocal = EPLocal.Ptr;
-   }
-   // ---------------- cell patches ----------------
-   {
-      const int PC = 64;
-      const int NP = (NCellsAll + PC - 1) / PC;
-      std::vector<I4> Off((size_t)NP * 2, 0), List;
-      std::vector<unsigned short> Loc((size_t)NP * PC * ME, 0);
-      std::vector<I4> Stamp(NCellsSize, -1), LocOf(NCellsSize, 0);
-      int MaxC = 0;
-      bool Fits = true;
-      for (int P = 0; P < NP; ++P) {
-         std::vector<I4> LC;
-         auto Add = [&](int G) {
-            if (Stamp[G] != P) {
-               Stamp[G] = P;
-               LocOf[G] = (int)LC.size();
-               LC.push_back(G);
-            }
-            return LocOf[G];
-         };
-         const int C0 = P * PC, C1 = std::min(NCellsAll, C0 + PC);
-         for (int C = C0; C < C0 + PC; ++C) // own cells first: local index = C - C0
-            Add(C < C1 ? C : NCellsAll);
-         // (padding cells all map to the sentinel; their "own" slot is wherever it landed)
-         for (int C = C0; C < C0 + PC; ++C) {
-            const int Cs = C < C1 ? C : NCellsAll;
-            for (int J = 0; J < ME; ++J)
-               Loc[((size_t)P * PC + (C - C0)) * ME + J] = (unsigned short)Add(HostNbrF(Cs, J) & 0x3fffffff);
-         }
-         if (LC.size() >= 0xffff)
-            Fits = false;
-         Off[(size_t)P * 2 + 0] = (I4)List.size();
-         List.insert(List.end(), LC.begin(), LC.end());
-         Off[(size_t)P * 2 + 1] = (I4)List.size();
-         MaxC = std::max(MaxC, (int)LC.size());
-      }
-      CPListOff = Array1DI4("CPListOff", (int)Off.size());
-      CPList    = Array1DI4("CPList", (int)std::max<size_t>(List.size(), 1));
-      CPLocal   = DeviceArray<unsigned short, 1>("CPLocal", (int)std::max<size_t>(Loc.size(), 1));
-      OMEGA::copyToDevice(CPListOff.Ptr, Off.data(), Off.size() * sizeof(I4));
-      OMEGA::copyToDevice(CPList.Ptr, List.data(), List.size() * sizeof(I4));
-      OMEGA::copyToDevice(CPLocal.Ptr, Loc.data(), Loc.size() * sizeof(unsigned short));
-      W.CPSize = PC, W.CPCount = Fits ? NP : 0, W.CPMaxC = MaxC;
-      W.CPListOff = CPListOff.Ptr, W.CPList = CPList.Ptr, W.CPLocal = CPLocal.Ptr;
-   }
 }
 
 } // namespace OMEGA

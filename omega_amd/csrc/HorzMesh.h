@@ -93,20 +93,6 @@ struct MeshView {
    // cells of the rarer valences that own regular edges: the ring kernels run once more over each list
    I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges (no list: full sweep), MaxEdges-1, MaxEdges-2
    const I4 *RingCellsM1, *RingCellsM2;
-   // ---- LDS patches (HorzMesh::buildPatches): consecutive target elements grouped into patches;
-   // per patch the UNIQUE rows its stencils reference, and per target element the stencil
-   // re-expressed as indices into those lists, so a workgroup stages each row once in LDS ----
-   // edge patches (PotentialVortHAdvOnEdge stencil): lists of cells, vertices, edges
-   I4 EPSize, EPCount, EPMaxC, EPMaxV, EPMaxE, EPLocStride;
-   const I4 *EPListOff;            // [EPCount][4] start of the cell / vertex / edge list, end
-   const I4 *EPList;               // concatenated lists (local mesh indices)
-   const unsigned short *EPLocal;  // [EPCount*EPSize][EPLocStride]: c0, c1, ChV[2][ME], ChF[2][ME-1]
-                                   //   (bit 15 = side cell is first), ChE[2][ME-1], v0, v1
-   // cell patches (tracer stencils): list of cells (own cells first), neighbour slots
-   I4 CPSize, CPCount, CPMaxC;
-   const I4 *CPListOff;            // [CPCount][2] start, end
-   const I4 *CPList;
-   const unsigned short *CPLocal;  // [CPCount*CPSize][ME] local index of the cell across slot j
 };
 
 class HorzMesh {
@@ -171,9 +157,6 @@ class HorzMesh {
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;
    DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;
    Array3DReal PVChainWeight;
-   Array1DI4 EPListOff, EPList, CPListOff, CPList;
-   DeviceArray<unsigned short, 1> EPLocal, CPLocal;
-   void buildPatches();
    void buildCellPV();
    void buildDel2Tables();
    Array2DI4 RingVertOnCell, PVRoleOnCell;

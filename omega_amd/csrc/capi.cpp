@@ -436,12 +436,12 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                      {"NVertLayers", M.NVertLayers},       {"MaxCellsOnEdge", M.MaxCellsOnEdge}};
    if (!M.HostOnly) { // kernel-side table statistics (diagnostics)
       const MeshView &W = M.view();
-      const std::map<std::string, I4> D{{"PVChainOK", W.PVChainOK}, {"EPSize", W.EPSize},   {"EPCount", W.EPCount},
-                                        {"EPMaxC", W.EPMaxC},       {"EPMaxV", W.EPMaxV},   {"EPMaxE", W.EPMaxE},
-                                        {"CPSize", W.CPSize},       {"CPCount", W.CPCount}, {"CPMaxC", W.CPMaxC},
-                                        {"CellPVOK", W.CellPVOK},   {"CellPVFinalOK", W.CellPVFinalOK},
+      const std::map<std::string, I4> D{{"PVChainOK", W.PVChainOK},
+                                        {"CellPVOK", W.CellPVOK},
+                                        {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
-                                        {"Del2RingOK", W.Del2RingOK}, {"Del2VertOK", W.Del2VertOK}};
+                                        {"Del2RingOK", W.Del2RingOK},
+                                        {"Del2VertOK", W.Del2VertOK}};
       auto Jt = D.find(name);
       if (Jt != D.end()) {
          *out = Jt->second;

@@ -894,34 +894,6 @@ template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
    }
 };
 
-// Two bodies over the same element range run back to back by the same thread.  Used to put the
-// side-0 PV sums in front of the tracer tendencies: both gather h on the cell's neighbours and u on
-// its edges, and issued from the same workgroup at the same time those rows cross the fabric once.
-template <class BA, class BB> struct SeqBody {
-   static constexpr int MinWaves = 2;
-   BA A;
-   BB B;
-   struct Lds {
-      typename BA::Lds a;
-      typename BB::Lds b;
-   };
-   size_t ldsBytes(int Tile) const { return A.ldsBytes(Tile) + B.ldsBytes(Tile); }
-   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
-      Lds L;
-      L.a = A.carve(Ptr, Tile);
-      L.b = B.carve(Ptr + A.ldsBytes(Tile), Tile);
-      return L;
-   }
-   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
-      A.stage(L.a, First, Cnt, Tid, NThr);
-      B.stage(L.b, First, Cnt, Tid, NThr);
-   }
-   template <class T> __device__ void compute(const Lds &L, int Le, int I, int Kv) const {
-      A.template compute<T>(L.a, Le, I, Kv);
-      B.template compute<T>(L.b, Le, I, Kv);
-   }
-};
-
 // Side-1 PV pass fused with the remaining velocity terms (default term set).  The cell-1 thread of
 // a regular edge finishes the PV sum, so it can go on with KE gradient, SSH gradient, del2 and del4
 // (TendencyTerms.h:110-265) in the reference's order and store the finished tendency: the running
@@ -1185,231 +1157,6 @@ template <bool Fast> struct EdgeFinalBody {
 };
 
 // ---------------------------------------------------------------------------------------
-// L3 edge pass, LDS-patch form.  Same arithmetic as FusedEdgeChainBody; the data path differs:
-// a workgroup owns a patch of EPSize consecutive edges and a chunk of KC levels, stages every
-// UNIQUE row its PV stencils reference (h on cells, NormRelVort / NormPlanetVort on vertices, u on
-// edges; HorzMesh::buildPatches) into LDS once, and the 46 stencil reads per edge-level then come
-// from LDS (4x the L1 rate) instead of 46 separate gathers.  The ten own-cell / own-vertex
-// values of the other terms are read straight from global memory.
-template <int TME, bool Fast> struct EdgePatchArgs {
-   MeshView M;
-   int K, KC;
-   TendParams P;
-   const Real *H, *U;
-   const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
-   Real *Tend;
-};
-
-template <int TME, bool Fast, class T>
-__global__ void __launch_bounds__(256, 2) edgePatchKernel(EdgePatchArgs<TME, Fast> A) {
-   constexpr int TM1 = TME - 1;
-   constexpr int W   = VecW<T>::W;
-   extern __shared__ __align__(16) unsigned char Lds[];
-   const MeshView &M = A.M;
-   const int K = A.K, KC = A.KC, KCV = KC / W;
-   const int Patch = xcdRemap(blockIdx.x, gridDim.x);
-   const int K0    = blockIdx.y * KC;
-   const int PE = M.EPSize, LS = M.EPLocStride;
-   const int *Off  = M.EPListOff + (size_t)Patch * 4;
-   const int OC = Off[0], OV = Off[1], OE = Off[2], OEnd = Off[3];
-   const int NUC = OV - OC, NUV = OE - OV, NUE = OEnd - OE;
-   // carve LDS: data rows first (16-byte aligned), then weights, then the 16-bit stencil table
-   LdsCarver Cv{Lds};
-   Real *LH  = Cv.take<Real>(M.EPMaxC * KC);
-   Real *LQR = Cv.take<Real>(M.EPMaxV * KC);
-   Real *LQF = Cv.take<Real>(M.EPMaxV * KC);
-   Real *LU  = Cv.take<Real>(M.EPMaxE * KC);
-   Real *LW  = Cv.take<Real>(PE * 2 * TM1);
-   unsigned short *LLoc = Cv.take<unsigned short>(PE * LS);
-   const int Tid = threadIdx.y * blockDim.x + threadIdx.x, NThr = blockDim.x * blockDim.y;
-   const int E0  = Patch * PE;
-   // ---- stage metadata ----
-   for (int I = Tid; I < PE * LS; I += NThr)
-      LLoc[I] = M.EPLocal[(size_t)E0 * LS + I];
-   for (int I = Tid; I < PE * 2 * TM1; I += NThr) {
-      const int E = E0 + I / (2 * TM1);
-      LW[I]       = E < M.NEdgesAll ? M.PVChainWeight[(size_t)E0 * 2 * TM1 + I] : 0.0;
-   }
-   // ---- stage the unique rows of this level chunk: lists -> LDS, then batched row loads so
-   //      that several rows per thread are in flight before the first LDS write ----
-   int *LList = Cv.take<int>(M.EPMaxC + 2 * M.EPMaxV + M.EPMaxE);
-   const int RT = NUC + 2 * NUV + NUE; // local rows: [h | qR | qF | u]
-   for (int I = Tid; I < RT; I += NThr) {
-      int G;
-      if (I < NUC)
-         G = M.EPList[OC + I];
-      else if (I < NUC + NUV)
-         G = M.EPList[OV + (I - NUC)];
-      else if (I < NUC + 2 * NUV)
-         G = M.EPList[OV + (I - NUC - NUV)];
-      else
-         G = M.EPList[OE + (I - NUC - 2 * NUV)];
-      LList[I] = G;
-   }
-   __syncthreads();
-   {
-      // destination of local row r: the four arrays are carved back to back with pitch KC, but the
-      // h / q / u regions are sized by the MAX list lengths, so map r -> region base + index
-      const int RowsPerIter = NThr / KCV;
-      const int MyRow = Tid / KCV, Kv = Tid - MyRow * KCV;
-      const int Kk    = K0 + Kv * W;
-      constexpr int B = 8;
-      for (int R0 = 0; R0 < RT; R0 += RowsPerIter * B) {
-         T Val[B];
-#pragma unroll
-         for (int Bi = 0; Bi < B; ++Bi) {
-            const int R = R0 + Bi * RowsPerIter + MyRow;
-            Val[Bi]     = splat<T>(0.0);
-            if (R < RT && Kk < K) {
-               const Real *Src = R < NUC ? A.H : (R < NUC + NUV ? A.NormRelVortV : (R < NUC + 2 * NUV ? A.NormPlanetVortV : A.U));
-               Val[Bi]         = *reinterpret_cast<const T *>(Src + (size_t)LList[R] * K + Kk);
-            }
-         }
-#pragma unroll
-         for (int Bi = 0; Bi < B; ++Bi) {
-            const int R = R0 + Bi * RowsPerIter + MyRow;
-            if (R < RT) {
-               Real *Dst = R < NUC ? LH + R * KC
-                                   : (R < NUC + NUV ? LQR + (R - NUC) * KC
-                                                    : (R < NUC + 2 * NUV ? LQF + (R - NUC - NUV) * KC
-                                                                         : LU + (R - NUC - 2 * NUV) * KC));
-               *reinterpret_cast<T *>(Dst + Kv * W) = Val[Bi];
-            }
-         }
-      }
-   }
-   __syncthreads();
-
-   const TendParams &P   = A.P;
-   const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
-   const bool PVOn = Fast ? true : (P.PVTendencyEnable != 0), KEOn = Fast ? true : (P.KETendencyEnable != 0);
-   const bool SSHOn = Fast ? true : (P.SSHTendencyEnable != 0), D2On = Fast ? true : (P.VelDiffTendencyEnable != 0);
-   const bool D4On   = Fast ? true : (P.VelHyperDiffTendencyEnable != 0);
-   const bool WindOn = Fast ? false : (P.WindForcingTendencyEnable != 0);
-   const bool DragOn = Fast ? false : (P.BottomDragTendencyEnable != 0);
-   const Real Grav   = 9.80665; // TendencyTerms.h:176
-   const int Kv = threadIdx.x;
-   const int Kk = K0 + Kv * W; // first level of this thread
-   auto LD = [&](const Real *Rows, int LocalRow) { return *reinterpret_cast<const T *>(Rows + LocalRow * KC + Kv * W); };
-   for (int Le = threadIdx.y; Le < PE; Le += blockDim.y) {
-      const int IEdge = E0 + Le;
-      if (IEdge >= M.NEdgesAll || Kk >= K)
-         continue;
-      const unsigned short *Lp = LLoc + Le * LS;
-      const int C0 = M.CellsOnEdge[2 * IEdge], C1 = M.CellsOnEdge[2 * IEdge + 1];
-      const int V0 = M.VerticesOnEdge[2 * IEdge], V1 = M.VerticesOnEdge[2 * IEdge + 1];
-      const unsigned KvG   = (unsigned)(Kk / W); // level-chunk index within the full column
-      const unsigned OffC0 = rowOff<T>(C0, K, KvG), OffC1 = rowOff<T>(C1, K, KvG);
-      const unsigned OffV0 = rowOff<T>(V0, K, KvG), OffV1 = rowOff<T>(V1, K, KvG);
-      const Real Mask = M.EdgeMask1D[IEdge], InvDc = M.InvDcEdge[IEdge], InvDv = M.InvDvEdge[IEdge];
-      const T H0 = LD(LH, Lp[0]), H1 = LD(LH, Lp[1]);
-      T TendV = splat<T>(0.0);
-      if (PVOn) {
-         const T QRe = 0.5 * (LD(LQR, Lp[LS - 2]) + LD(LQR, Lp[LS - 1]));
-         const T QFe = 0.5 * (LD(LQF, Lp[LS - 2]) + LD(LQF, Lp[LS - 1]));
-         T VortTmp   = splat<T>(0.0);
-#pragma unroll
-         for (int Sd = 0; Sd < 2; ++Sd) {
-            const T Hs = Sd == 0 ? H0 : H1;
-            const unsigned short *LV = Lp + 2 + Sd * TME;
-            const unsigned short *LF = Lp + 2 + 2 * TME + Sd * TM1;
-            const unsigned short *LE = Lp + 2 + 2 * TME + 2 * TM1 + Sd * TM1;
-            T QRp = LD(LQR, LV[0]), QFp = LD(LQF, LV[0]);
-#pragma unroll
-            for (int J = 0; J < TM1; ++J) {
-               const T QRn = LD(LQR, LV[J + 1]), QFn = LD(LQF, LV[J + 1]);
-               const unsigned F = LF[J];
-               const T Hf = LD(LH, F & 0x7fff), Uj = LD(LU, LE[J]);
-               T Flux = 0.5 * (Hs + Hf);
-               if (FluxUpwind) {
-                  const bool First = (F & 0x8000) != 0;
-                  Flux             = upwind(Uj, pick(First, Hs, Hf), pick(First, Hf, Hs));
-               }
-               const T QRj = 0.5 * (QRp + QRn);
-               const T QFj = 0.5 * (QFp + QFn);
-               const T NormVort = (QRe + QFe + QRj + QFj) * 0.5;
-               VortTmp += LW[(Le * 2 + Sd) * TM1 + J] * Flux * Uj * NormVort;
-               QRp = QRn;
-               QFp = QFn;
-            }
-         }
-         TendV += Mask * VortTmp;
-      }
-      if (KEOn)
-         TendV -= Mask * (ldo<T>(A.KE, OffC1) - ldo<T>(A.KE, OffC0)) * InvDc;
-      if (SSHOn) {
-         const T Ssh0 = H0 - M.BottomDepth[C0], Ssh1 = H1 - M.BottomDepth[C1];
-         TendV -= (Mask * Grav) * (Ssh1 - Ssh0) * InvDc;
-      }
-      if (D2On) {
-         const T Del2U = ((ldo<T>(A.Div, OffC1) - ldo<T>(A.Div, OffC0)) * InvDc -
-                          (ldo<T>(A.RelVort, OffV1) - ldo<T>(A.RelVort, OffV0)) * InvDv);
-         TendV += (Mask * P.ViscDel2 * M.MeshScalingDel2[IEdge]) * Del2U;
-      }
-      if (D4On) {
-         const T Del2U = (P.DivFactor * (ldo<T>(A.Del2Div, OffC1) - ldo<T>(A.Del2Div, OffC0)) * InvDc -
-                          (ldo<T>(A.Del2RelVort, OffV1) - ldo<T>(A.Del2RelVort, OffV0)) * InvDv);
-         TendV -= (Mask * P.ViscDel4 * M.MeshScalingDel4[IEdge]) * Del2U;
-      }
-      if (WindOn && Kk == 0) {
-         const Real HMean0       = 0.5 * (getc(H0, 0) + getc(H1, 0));
-         const Real InvThickEdge = 1. / HMean0;
-         setc(TendV, 0, getc(TendV, 0) + Mask * InvThickEdge * A.NormalStress[IEdge] / P.Density0);
-      }
-      if (DragOn && Kk + W >= K) {
-         const int KBot          = K - 1;
-         const int Comp          = KBot - Kk;
-         const Real VelNormEdge  = sqrt(A.KE[(size_t)C0 * K + KBot] + A.KE[(size_t)C1 * K + KBot]);
-         const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
-         const Real InvThickEdge = 1. / HMeanB;
-         setc(TendV, Comp,
-              getc(TendV, Comp) - Mask * P.BottomDragCoeff * VelNormEdge * InvThickEdge * A.U[(size_t)IEdge * K + KBot]);
-      }
-      sto<T>(A.Tend, rowOff<T>(IEdge, K, KvG), TendV);
-   }
-}
-
-template <int TME, bool Fast>
-static bool launchEdgePatch(const MeshView &M, int K, const TendParams &P, const AuxPtrs &A, Real *UTend,
-                            const Real *H, const Real *U, hipStream_t S) {
-   if (M.EPCount <= 0 || !M.PVChainOK || (K & 1))
-      return false;
-   static const int KC = getenv("OMEGA_EDGE_KC") ? atoi(getenv("OMEGA_EDGE_KC")) : 16;
-   const int W = 2, KCV = KC / W;
-   const size_t Lds = ldsRound8(sizeof(Real) * M.EPMaxC * KC) + ldsRound8(sizeof(Real) * M.EPMaxV * KC) * 2 +
-                      ldsRound8(sizeof(Real) * M.EPMaxE * KC) + ldsRound8(sizeof(Real) * M.EPSize * 2 * (TME - 1)) +
-                      ldsRound8(sizeof(unsigned short) * M.EPSize * M.EPLocStride) +
-                      ldsRound8(sizeof(int) * (M.EPMaxC + 2 * M.EPMaxV + M.EPMaxE));
-   if (Lds > 150 * 1024)
-      return false;
-   EdgePatchArgs<TME, Fast> Args{M,
-                                 K,
-                                 KC,
-                                 P,
-                                 H,
-                                 U,
-                                 A.RelVortVertex,
-                                 A.NormRelVortVertex,
-                                 A.NormPlanetVortVertex,
-                                 A.KineticEnergyCell,
-                                 A.VelocityDivCell,
-                                 A.Del2DivCell,
-                                 A.Del2RelVortVertex,
-                                 A.NormalStressEdge,
-                                 UTend};
-   auto Kern = edgePatchKernel<TME, Fast, dv2>;
-   static bool AttrSet = false;
-   if (!AttrSet && Lds > 64 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)Lds);
-      AttrSet = true;
-   }
-   const dim3 Grid(M.EPCount, (K + KC - 1) / KC, 1), Block(KCV, 256 / KCV, 1);
-   hipLaunchKernelGGL(Kern, Grid, Block, Lds, S, Args);
-   return true;
-}
-
-// ---------------------------------------------------------------------------------------
 // L3 cell pass: tracer tendencies (TendencyTerms.h:349-480) with HTracersEdge
 // (TracerAuxVars.h:25-59) and MeanLayerThickEdge rebuilt inline; tracer loop inside.
 template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
@@ -1557,187 +1304,6 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
    }
 };
 
-// ---------------------------------------------------------------------------------------
-// L3 cell pass, LDS-patch form (Default.yml term set only).  Same arithmetic as
-// FusedCell3Body<TME, true>.  A workgroup owns a patch of CPSize consecutive cells and a chunk of
-// KC levels; per tracer it stages the UNIQUE rows (own cells + ring, HorzMesh::buildPatches) of the
-// tracer and of Del2Tracers into LDS once -- every row then costs one fabric/L2 fetch per patch
-// instead of one per neighbour that misses L1 -- and the 14 stencil reads per (cell, levels,
-// tracer) come from LDS.  h is staged once per workgroup; u stays in registers.
-template <int TME> struct CellPatchArgs {
-   MeshView M;
-   int K, KC, NT;
-   TendParams P;
-   const Real *H, *U, *Tr, *Del2Tr;
-   Real *Tend;
-};
-
-template <int TME, int RMAX, class T>
-__global__ void __launch_bounds__(256, 2) cell3PatchKernel(CellPatchArgs<TME> A) {
-   constexpr int W = VecW<T>::W;
-   extern __shared__ __align__(16) unsigned char Lds[];
-   const MeshView &M = A.M;
-   const int K = A.K, KC = A.KC, KCV = KC / W, NT = A.NT;
-   const int Patch = xcdRemap(blockIdx.x, gridDim.x);
-   const int K0    = blockIdx.y * KC;
-   const int PC    = M.CPSize;
-   const int O0 = M.CPListOff[2 * Patch], NU = M.CPListOff[2 * Patch + 1] - O0;
-   LdsCarver Cv{Lds};
-   Real *LHs  = Cv.take<Real>(M.CPMaxC * KC);
-   Real *LT   = Cv.take<Real>(M.CPMaxC * KC);
-   Real *LD2  = Cv.take<Real>(M.CPMaxC * KC);
-   Real *LMDv = Cv.take<Real>(PC * TME);
-   Real *LDf2 = Cv.take<Real>(PC * TME);
-   Real *LDf4 = Cv.take<Real>(PC * TME);
-   int *LList = Cv.take<int>(M.CPMaxC);
-   unsigned short *LLoc = Cv.take<unsigned short>(PC * TME);
-   const int Tid = threadIdx.y * blockDim.x + threadIdx.x, NThr = blockDim.x * blockDim.y;
-   const int C0  = Patch * PC;
-   for (int I = Tid; I < NU; I += NThr)
-      LList[I] = M.CPList[O0 + I];
-   for (int I = Tid; I < PC * TME; I += NThr) {
-      const int C    = C0 + I / TME;
-      const bool In  = C < M.NCellsAll;
-      const size_t G = (size_t)C0 * TME + I;
-      LLoc[I]        = M.CPLocal[G];
-      LMDv[I]        = In ? M.MaskDvSignOnCell[G] : 0.0;
-      LDf2[I]        = In ? M.Diff2CoefSOnCell[G] : 0.0;
-      LDf4[I]        = In ? M.Diff4CoefSOnCell[G] : 0.0;
-   }
-   __syncthreads();
-   const int RowsPerIter = NThr / KCV;
-   const int MyRow = Tid / KCV, SKv = Tid - MyRow * KCV;
-   const int SKk   = K0 + SKv * W;
-   auto StageRows = [&](Real *Dst, const Real *Src) {
-      constexpr int B = 4;
-      for (int R0 = 0; R0 < NU; R0 += RowsPerIter * B) {
-         T Val[B];
-#pragma unroll
-         for (int Bi = 0; Bi < B; ++Bi) {
-            const int R = R0 + Bi * RowsPerIter + MyRow;
-            Val[Bi]     = splat<T>(0.0);
-            if (R < NU && SKk < K)
-               Val[Bi] = *reinterpret_cast<const T *>(Src + (size_t)LList[R] * K + SKk);
-         }
-#pragma unroll
-         for (int Bi = 0; Bi < B; ++Bi) {
-            const int R = R0 + Bi * RowsPerIter + MyRow;
-            if (R < NU)
-               *reinterpret_cast<T *>(Dst + R * KC + SKv * W) = Val[Bi];
-         }
-      }
-   };
-   StageRows(LHs, A.H);
-   // per-thread items: cells Le = threadIdx.y + s*blockDim.y, levels chunk Kv = threadIdx.x
-   constexpr int MAXIT = 2; // CPSize / blockDim.y
-   const int Kv = threadIdx.x;
-   const int Kk = K0 + Kv * W;
-   const unsigned KvG = (unsigned)(Kk / W);
-   T UJ[MAXIT][TME];
-   Real InvA[MAXIT];
-   bool Active[MAXIT];
-#pragma unroll
-   for (int It = 0; It < MAXIT; ++It) {
-      const int Le = threadIdx.y + It * blockDim.y, ICell = C0 + Le;
-      Active[It]   = Le < PC && ICell < M.NCellsAll && Kk < K;
-      InvA[It]     = Active[It] ? M.InvAreaCell[ICell] : 0.0;
-#pragma unroll
-      for (int J = 0; J < TME; ++J)
-         UJ[It][J] = Active[It] ? ldo<T>(A.U, rowOff<T>(M.EdgesOnCell[(size_t)ICell * TME + J], K, KvG)) : splat<T>(0.0);
-   }
-   auto LD = [&](const Real *Rows, int LocalRow) { return *reinterpret_cast<const T *>(Rows + LocalRow * KC + Kv * W); };
-   const size_t CStride = (size_t)M.NCellsSize * K;
-   const TendParams &P  = A.P;
-   // software pipeline over tracers: the rows of tracer l+1 are in flight (in registers) while
-   // tracer l is computed from LDS
-   // RMAX rows per thread per array: NU <= RMAX * RowsPerIter (checked by the launcher)
-   unsigned RowOffB[RMAX];  // byte offset of this thread's source element inside a plane
-#pragma unroll
-   for (int Bi = 0; Bi < RMAX; ++Bi) {
-      const int R = Bi * RowsPerIter + MyRow;
-      RowOffB[Bi] = (R < NU && SKk < K) ? ((unsigned)LList[R] * (unsigned)K + (unsigned)SKk) * 8u : 0xffffffffu;
-   }
-   T PT[RMAX], PD[RMAX];
-   auto Prefetch = [&](int Lt) {
-      const Real *TrL = uniformPtr(A.Tr + Lt * CStride), *D2L = uniformPtr(A.Del2Tr + Lt * CStride);
-#pragma unroll
-      for (int Bi = 0; Bi < RMAX; ++Bi) {
-         PT[Bi] = splat<T>(0.0);
-         PD[Bi] = splat<T>(0.0);
-         if (RowOffB[Bi] != 0xffffffffu) {
-            PT[Bi] = ldo<T>(TrL, RowOffB[Bi]);
-            PD[Bi] = ldo<T>(D2L, RowOffB[Bi]);
-         }
-      }
-   };
-   if (NT > 0)
-      Prefetch(0);
-#pragma nounroll
-   for (int Lt = 0; Lt < NT; ++Lt) {
-      __syncthreads(); // previous tracer's LDS reads are done (first time: h and the lists are staged)
-#pragma unroll
-      for (int Bi = 0; Bi < RMAX; ++Bi) {
-         const int R = Bi * RowsPerIter + MyRow;
-         if (R < NU) {
-            *reinterpret_cast<T *>(LT + R * KC + SKv * W)  = PT[Bi];
-            *reinterpret_cast<T *>(LD2 + R * KC + SKv * W) = PD[Bi];
-         }
-      }
-      __syncthreads();
-      if (Lt + 1 < NT)
-         Prefetch(Lt + 1);
-#pragma unroll
-      for (int It = 0; It < MAXIT; ++It) {
-         if (!Active[It])
-            continue;
-         const int Le = threadIdx.y + It * blockDim.y, ICell = C0 + Le;
-         const T Hs = LD(LHs, Le), Ts = LD(LT, Le), Ds = LD(LD2, Le); // own cells come first in the list
-         const T HsTs = Hs * Ts;
-         T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
-#pragma unroll
-         for (int J = 0; J < TME; ++J) {
-            const int I  = Le * TME + J;
-            const int Ln = LLoc[I];
-            const T Hn = LD(LHs, Ln), Tn = LD(LT, Ln), Dn = LD(LD2, Ln);
-            const T HTr = 0.5 * (HsTs + Hn * Tn);
-            HAdvTmp -= LMDv[I] * HTr * UJ[It][J] * InvA[It];
-            const T Mean = 0.5 * (Hs + Hn);
-            DiffTmp -= LDf2[I] * Mean * (Tn - Ts);
-            HypTmp -= LDf4[I] * (Dn - Ds);
-         }
-         T TendV = splat<T>(0.0);
-         TendV -= HAdvTmp;
-         TendV += P.EddyDiff2 * DiffTmp * InvA[It];
-         TendV -= P.EddyDiff4 * HypTmp * InvA[It];
-         sto<T>(uniformPtr(A.Tend + Lt * CStride), rowOff<T>(ICell, K, KvG), TendV);
-      }
-   }
-}
-
-template <int TME>
-static bool launchCell3Patch(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *TrTend,
-                             const Real *H, const Real *U, const Real *Tr, hipStream_t S) {
-   if (M.CPCount <= 0 || (K & 1) || M.CPSize != 64)
-      return false;
-   static const int KC = getenv("OMEGA_CELL_KC") ? atoi(getenv("OMEGA_CELL_KC")) : 16;
-   const int W = 2, KCV = KC / W;
-   if (KCV < 1 || 256 % KCV != 0 || 256 / KCV * 2 < M.CPSize || M.CPMaxC > 8 * (256 / KCV))
-      return false;
-   const size_t Lds = ldsRound8(sizeof(Real) * M.CPMaxC * KC) * 3 + ldsRound8(sizeof(Real) * M.CPSize * TME) * 3 +
-                      ldsRound8(sizeof(int) * M.CPMaxC) + ldsRound8(sizeof(unsigned short) * M.CPSize * TME);
-   if (Lds > 150 * 1024)
-      return false;
-   CellPatchArgs<TME> Args{M, K, KC, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
-   const int RowsPerIter = 256 / KCV;
-   const bool Small = M.CPMaxC <= 4 * RowsPerIter;
-   auto Kern = Small ? cell3PatchKernel<TME, 4, dv2> : cell3PatchKernel<TME, 8, dv2>;
-   if (Lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)Lds);
-   const dim3 Grid(M.CPCount, (K + KC - 1) / KC, 1), Block(KCV, 256 / KCV, 1);
-   hipLaunchKernelGGL(Kern, Grid, Block, Lds, S, Args);
-   return true;
-}
 
 const char *FusedKernelNames[FusedNumKernels] = {"VortVertexBody", "FusedCell1Body", "", "", "", "", ""};
 
@@ -1821,11 +1387,11 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    // L3
    Mark(4);
-   bool Marked5 = false, Cell3Done = false;
+   bool Marked5        = false;
    FusedKernelNames[4] = "FusedEdgeChainBody", FusedKernelNames[5] = "";
+   // OMEGA_EDGE_MODE=1 forces the edge-centric chain kernel (the fallback of meshes without the
+   // cell-centric PV tables) for A/B measurements
    static const int EdgeMode = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
-   // 0: cell-centric PV sums + edge finalize (default), 1: edge-centric chain kernel,
-   // 2: LDS-patch edge kernel (kept for experiments)
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
@@ -1835,19 +1401,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          // maxEdges = 6 or 7) run the same ring code, instantiated for their size, over cell lists
          constexpr int NM1 = TME - 1, NM2 = TME >= 6 ? TME - 2 : TME - 1;
          CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
-         static const int FuseC3 = getenv("OMEGA_FUSE_PV0_CELL3") ? atoi(getenv("OMEGA_FUSE_PV0_CELL3")) : 0;
-         static const int CellMd = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
-         if (FuseC3 && NT > 0 && CellMd == 0) {
-            SeqBody<CellPVBody<TME, Fast, 0>, FusedCell3Body<TME, Fast>> B01{
-                B0, FusedCell3Body<TME, Fast>{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend}};
-            launchTile(B01, M.NCellsAll, K, S);
-            FusedKernelNames[4] = "CellPVBody<side 0>+FusedCell3Body";
-            Cell3Done           = true;
-         } else {
-            if (M.NRingCellsM0 > 0)
-               launchTile(B0, M.NCellsAll, K, S);
-            FusedKernelNames[4] = "CellPVBody<side 0>";
-         }
+         if (M.NRingCellsM0 > 0)
+            launchTile(B0, M.NCellsAll, K, S);
+         FusedKernelNames[4] = "CellPVBody<side 0>";
          if (M.NRingCellsM1 > 0) {
             CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
                                              M.RingCellsM1};
@@ -1960,8 +1516,6 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          else
             LaunchList(std::false_type{});
       }
-   } else if (EdgeMode == 2 && launchEdgePatch<TME, Fast>(M, K, P, A, UTend, H, U, S)) {
-      FusedKernelNames[4] = "edgePatchKernel";
    } else if (M.PVChainOK) {
       FusedEdgeChainBody<TME, Fast> B{M,
                                       K,
@@ -1989,10 +1543,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (!Marked5)
       Mark(5);
    Mark(6);
-   FusedKernelNames[6] = (NT > 0 && !Cell3Done) ? "FusedCell3Body" : "";
-   if (NT > 0 && !Cell3Done) {
-      static const int CellMode = getenv("OMEGA_CELL_MODE") ? atoi(getenv("OMEGA_CELL_MODE")) : 0;
-      // 0: per-thread gathers (FusedCell3Body); 1: LDS-patch kernel for the default term set
+   FusedKernelNames[6] = NT > 0 ? "FusedCell3Body" : "";
+   if (NT > 0) {
       bool Done = false;
       if constexpr (Fast) {
          if (Stage) {
@@ -2001,7 +1553,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             Done = true;
          }
       }
-      if (!Done && !(CellMode == 1 && Fast && launchCell3Patch<TME>(M, K, NT, P, A, TrTend, H, U, Tr, S))) {
+      if (!Done) {
          FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
          launchTile(B, M.NCellsAll, K, S);
       }
@@ -2014,8 +1566,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
 static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *EdgeScratch) {
    static const int EdgeMode  = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
    static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
-   static const int FuseC3    = getenv("OMEGA_FUSE_PV0_CELL3") ? atoi(getenv("OMEGA_FUSE_PV0_CELL3")) : 0;
-   return isDefaultTermSet(P) && EdgeMode == 0 && FuseFinal && !FuseC3 && M.CellPVOK && M.CellPVFinalOK && EdgeScratch;
+   return isDefaultTermSet(P) && EdgeMode == 0 && FuseFinal && M.CellPVOK && M.CellPVFinalOK && EdgeScratch;
 }
 
 bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
