@@ -384,6 +384,9 @@ void HorzMesh::buildCoefficientTables() {
    HostChW = ChW;
    buildCellPV();
    buildDel2Tables();
+   // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
+   if (const char *Fg = getenv("OMEGA_FORCE_GENERIC"); Fg && atoi(Fg) == 1)
+      W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = 0;
 }
 
 // Ring form of the velocity-del2 stencils (see HorzMesh.h).  Works for any mesh whose

@@ -7,9 +7,13 @@ File name sorts first on purpose: the ranks are child processes, and this pool f
 a new program from a process that has already initialised the GPU -- so it runs before the
 in-process GPU tests touch the device.
 """
+import os
+import subprocess
+import sys
+
 import pytest
 
-from tests.test_multirank_cpu import run_ranks
+from tests.test_multirank_cpu import ROOT, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -22,3 +26,16 @@ pytestmark = pytest.mark.gpu
 def test_two_ranks_one_gpu(extra):
     outs = run_ranks("gpu", 2, extra, timeout=900)
     assert all("OK" in o for o in outs)
+
+
+def test_generic_fallback_kernels_in_a_child_process():
+    """Meshes whose EdgesOnEdge / EdgesOnCell lists are not in MPAS ring order take the generic kernels
+    (FusedEdgeBody, FusedDel2CellBody, FusedDel2VertexBody, separate update sweeps).  No generated mesh
+    is like that, so OMEGA_FORCE_GENERIC=1 clears the ring-table flags and the parity tests run again."""
+    env = dict(os.environ, OMEGA_FORCE_GENERIC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
+                        "(compute_all_tendencies and fused and (K80 or K4_ or K5 or ico3)) or time_steppers or generic_flags"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert " passed" in out and "failed" not in out

@@ -142,6 +142,16 @@ def test_sphere_meshes_take_the_fast_paths():
     assert P.mesh.get_int("NIrregularEdges") == 12 * 5      # 5 < MaxEdges - 2: edge-centric list
 
 
+def test_generic_flags_follow_the_environment():
+    """With OMEGA_FORCE_GENERIC=1 (set by tests/test_00_multirank_gpu.py for a child run) every ring-table
+    flag is off, so the parity tests of that run exercise the generic kernels; otherwise they are on."""
+    import os
+    P = _mk((16, 16, 30e3, 4, 1, {}))
+    want = 0 if os.environ.get("OMEGA_FORCE_GENERIC") == "1" else 1
+    for flag in ("PVChainOK", "CellPVOK", "CellPVFinalOK", "Del2RingOK", "Del2VertOK"):
+        assert P.mesh.get_int(flag) == want, flag
+
+
 def test_group_tendencies_fb_path():
     """computeThicknessTendencies / computeTracerTendencies / computeVelocityTendencies
     (the ForwardBackward stepper's calls, Tendencies.cpp:488-575)."""
