@@ -239,7 +239,9 @@ int omg_stepper_set_start_time(omg_stepper *st, double seconds);
 int omg_stepper_get_time(const omg_stepper *st, double *seconds);
 /* RungeKutta4 only: "FuseStageUpdates" (default 1: the stage updates of TimeStepper.cpp:378-524 run in the
  * epilogue of the RHS kernels, same arithmetic) and "StoreStageTendencies" (default 0: with fused stages the
- * Tendencies arrays are not written).  0 / 1. */
+ * Tendencies arrays are not written), "OverlapHaloExchange" (default 1: with fused stages and neighbours, each
+ * exchange starts when the band of cells whose values travel is final and runs on a communication stream
+ * while the stage's interior cells are computed).  0 / 1. */
 int omg_stepper_set_option(omg_stepper *st, const char *name, int value);
 int omg_stepper_coeff_seconds(double mult, double time_step_seconds, double *out);
 

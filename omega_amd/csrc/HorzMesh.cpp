@@ -384,9 +384,44 @@ void HorzMesh::buildCoefficientTables() {
    HostChW = ChW;
    buildCellPV();
    buildDel2Tables();
+   buildBandLists((I4)NCellsHaloH.size());
    // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
    if (const char *Fg = getenv("OMEGA_FORCE_GENERIC"); Fg && atoi(Fg) == 1)
       W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = 0;
+}
+
+// Band / interior split of the local cells for overlapping a halo exchange with interior work
+// (see HorzMesh.h): breadth-first distance from the halo cells over CellsOnCell.
+void HorzMesh::buildBandLists(I4 HaloWidth) {
+   MeshView &W = View;
+   std::vector<I4> Dist(NCellsAll, -1), Front, Next;
+   for (I4 C = NCellsOwned; C < NCellsAll; ++C) {
+      Dist[C] = 0;
+      Front.push_back(C);
+   }
+   for (I4 D = 1; D <= HaloWidth + 1 && !Front.empty(); ++D) {
+      Next.clear();
+      for (I4 C : Front)
+         for (int J = 0; J < MaxEdges; ++J) {
+            const I4 Nb = CellsOnCellH(C, J);
+            if (Nb >= 0 && Nb < NCellsAll && Dist[Nb] < 0) {
+               Dist[Nb] = D;
+               Next.push_back(Nb);
+            }
+         }
+      Front.swap(Next);
+   }
+   std::vector<I4> Band, Inter;
+   for (I4 C = 0; C < NCellsAll; ++C)
+      (Dist[C] >= 0 ? Band : Inter).push_back(C);
+   BandCells     = Array1DI4("BandCells", (int)std::max<size_t>(Band.size(), 1));
+   InteriorCells = Array1DI4("InteriorCells", (int)std::max<size_t>(Inter.size(), 1));
+   if (!Band.empty())
+      OMEGA::copyToDevice(BandCells.Ptr, Band.data(), Band.size() * sizeof(I4));
+   if (!Inter.empty())
+      OMEGA::copyToDevice(InteriorCells.Ptr, Inter.data(), Inter.size() * sizeof(I4));
+   W.NBandCells = (I4)Band.size(), W.NInteriorCells = (I4)Inter.size();
+   W.BandCells = BandCells.Ptr, W.InteriorCells = InteriorCells.Ptr;
 }
 
 // Ring form of the velocity-del2 stencils (see HorzMesh.h).  Works for any mesh whose

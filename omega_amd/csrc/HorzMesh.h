@@ -93,6 +93,11 @@ struct MeshView {
    // cells of the rarer valences that own regular edges: the ring kernels run once more over each list
    I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges (no list: full sweep), MaxEdges-1, MaxEdges-2
    const I4 *RingCellsM1, *RingCellsM2;
+   // ---- overlap of halo exchanges with interior work (HorzMesh::buildBandLists) ----
+   // BandCells: every halo cell and every owned cell within HaloWidth+1 cells of one (a superset of the cells
+   // that own anything a neighbour receives); InteriorCells: the other owned cells.  Ascending order.
+   I4 NBandCells, NInteriorCells;
+   const I4 *BandCells, *InteriorCells;
 };
 
 class HorzMesh {
@@ -152,7 +157,8 @@ class HorzMesh {
        Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex, Del2TrCoefSOnCell, Diff2CoefSOnCell, Diff4CoefSOnCell;
    DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
    Array2DReal RingSignOnCell;
-   Array1DI4 RingCellsM1, RingCellsM2;
+   Array1DI4 RingCellsM1, RingCellsM2, BandCells, InteriorCells;
+   void buildBandLists(I4 HaloWidth);
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;
    DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;

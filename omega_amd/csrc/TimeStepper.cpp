@@ -257,6 +257,40 @@ void RungeKutta4Stepper::finalizeInit() {
 //    q_out     = q^n + RKA[s+1]*dt*R   (the next stage's input; tracers divided by the new thickness)
 // which is what weightTracers / updateStateByTend / accumulateTracersUpdate / updateTracersByTend /
 // finalizeTracersUpdate do in separate sweeps.  q_in and q_out alternate between two buffers.
+RungeKutta4Stepper::~RungeKutta4Stepper() {
+   if (EvBand)
+      (void)hipEventDestroy(EvBand);
+   if (EvDone)
+      (void)hipEventDestroy(EvDone);
+   if (CommStream)
+      (void)hipStreamDestroy(CommStream);
+}
+
+void RungeKutta4Stepper::startExchangeThunk(void *Job) {
+   auto *J = static_cast<ExchangeJob *>(Job);
+   J->Self->startExchange(*J);
+}
+// Called by the RHS launcher between the band and the interior part of a stage: everything a neighbour
+// receives is final on stream S.  Pack, send / receive and unpack run on the communication stream.
+void RungeKutta4Stepper::startExchange(const ExchangeJob &Job) {
+   if (!CommStream) {
+      HIP_CHECK(hipStreamCreate(&CommStream));
+      HIP_CHECK(hipEventCreateWithFlags(&EvBand, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&EvDone, hipEventDisableTiming));
+   }
+   HIP_CHECK(hipEventRecord(EvBand, Job.S));
+   HIP_CHECK(hipStreamWaitEvent(CommStream, EvBand, 0));
+   OMEGA_REQUIRE(MeshHalo->exchangeState(Job.H, Job.U, Job.NT > 0 ? Job.Tr : nullptr, Job.NT, CommStream) == 0,
+                 "RungeKutta4: overlapped halo exchange failed");
+   HIP_CHECK(hipEventRecord(EvDone, CommStream));
+   ExchangePending = true;
+}
+void RungeKutta4Stepper::joinExchange(hipStream_t S) {
+   if (ExchangePending)
+      HIP_CHECK(hipStreamWaitEvent(S, EvDone, 0));
+   ExchangePending = false;
+}
+
 bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
    const int CurLevel = 0, NextLevel = 1;
    const int NT = Trc->NTracers;
@@ -273,6 +307,9 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
    State->getLayerThickness(NextH, NextLevel), State->getNormalVelocity(NextU, NextLevel);
    OceanState *Prov[2]   = {ProvisState.get(), ProvisState2.get()};
    Array3DReal *ProvT[2] = {&ProvisTracers, &ProvisTracers2};
+   const bool Exchanges  = MeshHalo && MeshHalo->NNghbr > 0;
+   const bool Overlap    = Exchanges && OverlapHaloExchange;
+   ExchangeJob Job{this, S, {}, {}, nullptr, NT};
    for (int Stage = 0; Stage < NStages; ++Stage) {
       StageUpdate Su;
       Su.CB        = coeff(RKB[Stage]);
@@ -286,6 +323,15 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
       Array2DReal OutH, OutU;
       Out->getLayerThickness(OutH, CurLevel), Out->getNormalVelocity(OutU, CurLevel);
       Su.ProvH = OutH.Ptr, Su.ProvU = OutU.Ptr, Su.ProvTr = ProvT[Stage % 2]->Ptr;
+      if (Overlap && (Stage == 1 || Stage == NStages - 1)) {
+         // this stage's output is exchanged next: the provisional state before stage 2 (:107-113), the
+         // new state at the end of the step (:130-131)
+         if (Stage == 1)
+            Job.H = OutH, Job.U = OutU, Job.Tr = ProvT[Stage % 2];
+         else
+            Job.H = NextH, Job.U = NextU, Job.Tr = &NextTr;
+         Su.AfterBand = &RungeKutta4Stepper::startExchangeThunk, Su.AfterBandCtx = &Job;
+      }
       bool Ok;
       if (Stage == 0) {
          Ok = Tend->computeAllTendenciesStage(State, AuxState, CurTr, CurLevel, CurLevel, Su, S);
@@ -293,17 +339,27 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
             return false; // nothing has been touched: the caller runs the plain sequence
       } else {
          OceanState *In = Prov[(Stage - 1) % 2];
-         if (Stage == 2 && MeshHalo && MeshHalo->NNghbr > 0) { // depends on the halo width (:107-113)
-            Array2DReal H, U;
-            In->getLayerThickness(H, CurLevel), In->getNormalVelocity(U, CurLevel);
-            OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? ProvT[(Stage - 1) % 2] : nullptr, NT, S) == 0,
-                          "RungeKutta4: provisional halo exchange failed");
+         if (Stage == 2 && Exchanges) { // depends on the halo width (:107-113)
+            if (Overlap) {
+               joinExchange(S); // started by stage 1 when its band was final
+            } else {
+               Array2DReal H, U;
+               In->getLayerThickness(H, CurLevel), In->getNormalVelocity(U, CurLevel);
+               OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? ProvT[(Stage - 1) % 2] : nullptr, NT, S) == 0,
+                             "RungeKutta4: provisional halo exchange failed");
+            }
          }
          Ok = Tend->computeAllTendenciesStage(In, AuxState, *ProvT[(Stage - 1) % 2], CurLevel, CurLevel, Su, S);
          OMEGA_REQUIRE(Ok, "RungeKutta4: stage-fused RHS became unavailable mid-step");
       }
    }
-   updateTimeLevels(State, S);
+   if (Overlap) { // the end-of-step exchange was started by the last stage: wait for it, then rotate
+      joinExchange(S);
+      State->rotateTimeLevels();
+      Trc->rotateTimeLevels();
+   } else {
+      updateTimeLevels(State, S);
+   }
    ++NStepsDone;
    return true;
 }

@@ -103,12 +103,31 @@ class RungeKutta4Stepper : public TimeStepper {
    /// launches per step.  The tendency arrays are then only stored if StoreStageTendencies is set.
    bool FuseStageUpdates      = true;
    bool StoreStageTendencies  = false;
+   /// With fused stages and neighbours: start each halo exchange as soon as the band of cells whose values
+   /// travel is final and let it run on a communication stream while the stage's interior cells are still
+   /// being computed (kernels/Kernels.h: StageUpdate::AfterBand); the next consumer waits on an event.
+   bool OverlapHaloExchange   = true;
+   ~RungeKutta4Stepper() override;
 
  protected:
    /// second provisional buffer: a stage reads one and writes the other (neighbours still gather the input)
    std::unique_ptr<OceanState> ProvisState2;
    Array3DReal ProvisTracers2;
    bool doStepFused(OceanState *State, hipStream_t S);
+   // overlapped exchange: communication stream, "band is final" and "halo is in place" events
+   hipStream_t CommStream = nullptr;
+   hipEvent_t EvBand = nullptr, EvDone = nullptr;
+   bool ExchangePending = false;
+   struct ExchangeJob {
+      RungeKutta4Stepper *Self;
+      hipStream_t S;
+      Array2DReal H, U;
+      Array3DReal *Tr;
+      int NT;
+   };
+   static void startExchangeThunk(void *Job);
+   void startExchange(const ExchangeJob &Job);
+   void joinExchange(hipStream_t S);
 };
 
 } // namespace OMEGA

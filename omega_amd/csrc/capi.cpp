@@ -441,7 +441,9 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
                                         {"Del2RingOK", W.Del2RingOK},
-                                        {"Del2VertOK", W.Del2VertOK}};
+                                        {"Del2VertOK", W.Del2VertOK},
+                                        {"NBandCells", W.NBandCells},
+                                        {"NInteriorCells", W.NInteriorCells}};
       auto Jt = D.find(name);
       if (Jt != D.end()) {
          *out = Jt->second;
@@ -979,6 +981,8 @@ int omg_stepper_set_option(omg_stepper *st, const char *name, int value) {
       Rk4->FuseStageUpdates = value != 0;
    else if (Rk4 && N == "StoreStageTendencies")
       Rk4->StoreStageTendencies = value != 0;
+   else if (Rk4 && N == "OverlapHaloExchange")
+      Rk4->OverlapHaloExchange = value != 0;
    else
       OMEGA_ABORT("TimeStepper: no option named " + N + " for this scheme");
    OMG_CATCH

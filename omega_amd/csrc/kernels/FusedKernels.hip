@@ -20,6 +20,7 @@
 #include "Kernels.h"
 
 #include <cstdlib>
+#include <functional>
 #include <type_traits>
 
 // tuning knobs of the tracer cell kernels (VGPR budget / levels per thread)
@@ -1167,7 +1168,8 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
    TendParams P;
    const Real *H, *U, *Tr, *Del2Tr;
    Real *Tend;
-   StageEpi E{}; // tracer stage update (EPI)
+   StageEpi E{};              // tracer stage update (EPI)
+   const int *List = nullptr; // EPI only: optional cell list (band / interior launches of an overlapped exchange)
    struct Lds {
       Real *MDvS, *Df2, *Df4, *InvA;
       int *Edge, *NbrF;
@@ -1189,7 +1191,9 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
+         const int Le   = I / TME;
+         const int C    = (EPI && List) ? List[First + Le] : First + Le;
+         const size_t G = (size_t)C * TME + (I - Le * TME);
          L.MDvS[I]      = M.MaskDvSignOnCell[G];
          L.Df2[I]       = Fast ? M.Diff2CoefSOnCell[G] : M.Diff2CoefOnCell[G];
          L.Df4[I]       = Fast ? M.Diff4CoefSOnCell[G] : M.Diff4CoefOnCell[G];
@@ -1197,9 +1201,10 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
          L.NbrF[I]      = M.NbrFlagOnCell[G];
       }
       for (int I = Tid; I < Cnt; I += NThr)
-         L.InvA[I] = M.InvAreaCell[First + I];
+         L.InvA[I] = M.InvAreaCell[(EPI && List) ? List[First + I] : First + I];
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      const int ICell     = (EPI && List) ? List[IElem] : IElem;
       const bool TrUpwind = Fast ? false : (P.FluxTracerUpwind != 0);
       const bool AdvOn = Fast ? true : (P.TracerHorzAdvTendencyEnable != 0);
       const bool DiffOn = Fast ? true : (P.TracerDiffTendencyEnable != 0);
@@ -1388,6 +1393,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // L3
    Mark(4);
    bool Marked5        = false;
+   std::function<void()> LaunchFinalInterior; // set when the side-1 sweep is split for an overlapped exchange
    FusedKernelNames[4] = "FusedEdgeChainBody", FusedKernelNames[5] = "";
    // OMEGA_EDGE_MODE=1 forces the edge-centric chain kernel (the fallback of meshes without the
    // cell-centric PV tables) for A/B measurements
@@ -1418,6 +1424,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          Marked5 = true;
          static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
          if (Fast && FuseFinal && M.CellPVFinalOK) {
+            // Overlap == true: the full sweep is split into the band list now and the interior list after
+            // the exchange has been started (Stage->AfterBand), see Kernels.h: StageUpdate
+            const bool Overlap = Stage && Stage->AfterBand && M.NBandCells > 0;
             auto LaunchFinal = [&](auto Epi) {
                constexpr bool EP = decltype(Epi)::value;
                CellPVFinalBody<TME, TME, EP> B1{M,
@@ -1436,8 +1445,14 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 UTend,
                                                 nullptr,
                                                 EU};
-               if (M.NRingCellsM0 > 0)
-                  launchTile(B1, M.NCellsAll, K, S);
+               if (M.NRingCellsM0 > 0) {
+                  if (Overlap) {
+                     B1.List = M.BandCells;
+                     launchTile(B1, M.NBandCells, K, S);
+                  } else {
+                     launchTile(B1, M.NCellsAll, K, S);
+                  }
+               }
                if (M.NRingCellsM1 > 0) {
                   CellPVFinalBody<TME, NM1, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
                                                    B1.NormRelVortV, B1.NormPlanetVortV, B1.Partial, B1.RelVort, B1.KE,
@@ -1449,6 +1464,31 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                    B1.NormRelVortV, B1.NormPlanetVortV, B1.Partial, B1.RelVort, B1.KE,
                                                    B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM2, EU};
                   launchTile(Bm, M.NRingCellsM2, K, S);
+               }
+            };
+            // the interior part of the split sweep, launched at the end of the L3 phase
+            LaunchFinalInterior = [&, Overlap]() {
+               (void)Overlap;
+               if constexpr (Fast) {
+                  if (Overlap && M.NRingCellsM0 > 0 && M.NInteriorCells > 0) {
+                     CellPVFinalBody<TME, TME, true> B1{M,
+                                                        K,
+                                                        P,
+                                                        H,
+                                                        U,
+                                                        A.NormRelVortVertex,
+                                                        A.NormPlanetVortVertex,
+                                                        EdgeScratch,
+                                                        A.RelVortVertex,
+                                                        A.KineticEnergyCell,
+                                                        A.VelocityDivCell,
+                                                        A.Del2DivCell,
+                                                        A.Del2RelVortVertex,
+                                                        UTend,
+                                                        M.InteriorCells,
+                                                        EU};
+                     launchTile(B1, M.NInteriorCells, K, S);
+                  }
                }
             };
             if (Stage)
@@ -1544,12 +1584,24 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       Mark(5);
    Mark(6);
    FusedKernelNames[6] = NT > 0 ? "FusedCell3Body" : "";
+   bool AfterBandCalled = false;
    if (NT > 0) {
       bool Done = false;
       if constexpr (Fast) {
          if (Stage) {
             FusedCell3Body<TME, true, true> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
-            launchTile(B, M.NCellsAll, K, S);
+            if (Stage->AfterBand && M.NBandCells > 0) {
+               B.List = M.BandCells;
+               launchTile(B, M.NBandCells, K, S);
+               Stage->AfterBand(Stage->AfterBandCtx); // u, h and the tracers of every sent element are final
+               AfterBandCalled = true;
+               if (LaunchFinalInterior)
+                  LaunchFinalInterior();
+               B.List = M.InteriorCells;
+               launchTile(B, M.NInteriorCells, K, S);
+            } else {
+               launchTile(B, M.NCellsAll, K, S);
+            }
             Done = true;
          }
       }
@@ -1557,6 +1609,11 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
          launchTile(B, M.NCellsAll, K, S);
       }
+   }
+   if (Stage && Stage->AfterBand && !AfterBandCalled) { // no tracers (or no band): everything is final here
+      Stage->AfterBand(Stage->AfterBandCtx);
+      if (LaunchFinalInterior)
+         LaunchFinalInterior();
    }
    Mark(7);
 }

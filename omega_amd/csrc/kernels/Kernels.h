@@ -80,6 +80,13 @@ struct StageUpdate {
    Real *NextH = nullptr, *NextU = nullptr, *NextTr = nullptr;
    const Real *CurH = nullptr, *CurU = nullptr, *CurTr = nullptr;
    Real *ProvH = nullptr, *ProvU = nullptr, *ProvTr = nullptr;
+   /// Overlap of the halo exchange that follows this stage with the stage's own interior work: when
+   /// AfterBand is set, the kernels that finish u and the tracers run first over BandCells (halo cells and
+   /// the owned cells whose values any neighbour receives: HorzMesh::BandCells), then AfterBand(Ctx) is
+   /// called -- the stepper starts the exchange on its communication stream there -- and the same
+   /// kernels continue over InteriorCells while the messages travel.
+   void (*AfterBand)(void *) = nullptr;
+   void *AfterBandCtx        = nullptr;
 };
 /// Returns false (nothing launched) when Stage != nullptr and the stage-fused kernels do not cover
 /// this mesh / option set; the caller then runs the plain RHS followed by the update kernels.

@@ -36,7 +36,12 @@ class TorchTransport:
     def _exchange(self, tasks, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream_handle):
         direct = self.backend == "nccl"
         ops, staged = [], []
-        ctx = torch.cuda.stream(self.stream) if (self.stream is not None) else _Null()
+        # the C++ side says which HIP stream the pack / unpack kernels of THIS exchange run on (the stepper's
+        # communication stream when the exchange is overlapped with interior compute): RCCL must order on it
+        if direct and stream_handle:
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream_handle)))
+        else:
+            ctx = torch.cuda.stream(self.stream) if (self.stream is not None) else _Null()
         with ctx:
             for i, t in enumerate(tasks):
                 assert send_ptrs[i] == self.send[i].data_ptr() and recv_ptrs[i] == self.recv[i].data_ptr()

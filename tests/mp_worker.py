@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--stepper", default="RungeKutta4")
     ap.add_argument("--halo-width", type=int, default=3)
     ap.add_argument("--no-del4", action="store_true", help="disable the two radius-2 (del4) terms")
+    ap.add_argument("--no-overlap", action="store_true", help="RK4 (gpu mode): exchange after the stage instead of overlapped")
     ap.add_argument("--mesh", default="hex", help="hex (planar nx x ny) | icoN (icosahedral level N) | fibN (N cells)")
     a = ap.parse_args()
 
@@ -123,6 +124,12 @@ def main():
 
     if gpu:
         st = oa.TimeStepper(a.stepper, dt, P.tend, P.aux, P.mesh, halo, P.tracers)
+        if a.stepper == "RungeKutta4":
+            st.set_option("OverlapHaloExchange", not a.no_overlap)
+            # the overlapped path splits the last kernels of a stage into a band and an interior launch:
+            # make sure this mesh has both, or the test would not exercise it
+            nb, ni = P.mesh.get_int("NBandCells"), P.mesh.get_int("NInteriorCells")
+            assert nb > 0 and (ni > 0 or a.nx * a.ny <= 24 * 24), (nb, ni)
         for _ in range(a.steps):
             st.do_step(P.state)
         oa.device_synchronize()

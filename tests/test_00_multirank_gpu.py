@@ -22,6 +22,9 @@ pytestmark = pytest.mark.gpu
     ["--no-del4"],
     ["--halo-width", 4, "--nx", 24, "--ny", 24, "--levels", 6],
     ["--no-del4", "--stepper", "Forward-Backward", "--levels", 5, "--tracers", 1],
+    ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4],                   # band AND interior launches, overlapped
+    ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4, "--no-overlap"],   # same, exchange after the stage
+    ["--halo-width", 4, "--nx", 72, "--ny", 12, "--levels", 3, "--steps", 3],
 ])
 def test_two_ranks_one_gpu(extra):
     outs = run_ranks("gpu", 2, extra, timeout=900)
