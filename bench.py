@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--block", type=int, default=0, help="cell ordering of the synthetic mesh: 0 = Morton curve (default), -1 = Hilbert curve, 1 = row-major, n > 1 = n x n blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the reference-structured launch sequence instead")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: exchange halos after the producing stage instead of overlapped with its interior part")
     ap.add_argument("--no-fuse-stages", action="store_true",
                     help="RK4 with the separate update kernels instead of stage updates folded into the RHS kernels")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -203,6 +205,7 @@ def main():
     if nrk > 0:
         stepper = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
         stepper.set_option("FuseStageUpdates", not args.no_fuse_stages)
+        stepper.set_option("OverlapHaloExchange", not args.no_overlap)
         stepper.do_step(state, stream=stream)  # warm-up (allocations, RCCL connections)
         barrier()
         t1 = time.perf_counter()
@@ -258,7 +261,10 @@ def main():
                           "partition": f"rcb{N}", "halo_width": 3, "mesh_order": "hilbert" if args.block < 0 else "morton" if args.block == 0 else f"blocked{args.block}",
                           "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1)},
                "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
-                       "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels"},
+                       "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
+                       "halo_exchange": "none (1 rank)" if N == 1 else
+                       ("after the stage" if (args.no_overlap or args.no_fuse_stages or args.unfused)
+                        else "overlapped with the stage's interior cells")},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if N > 1:
