@@ -100,6 +100,24 @@ int omg_mesh_file_dim(const omg_mesh_file *f, const char *name, int64_t *len);
 int omg_mesh_file_var_size(const omg_mesh_file *f, const char *name, int64_t record, int64_t *n);
 int omg_mesh_file_read_f64(const omg_mesh_file *f, const char *name, int64_t record, double *out, size_t n);
 
+/* ---- Restart file (the RestartWrite / InitialState IOStreams of O/configs/Default.yml:91-127 go through SCORPIO;
+ *      here one NetCDF CDF-5 file: layerThickness(nCells,nVertLevels), normalVelocity(nEdges,nVertLevels),
+ *      tracers(nTracers,nCells,nVertLevels), simulationTime, stepsDone).  Rank 0 calls omg_restart_create; then
+ *      every rank opens the file and writes / reads the rows of its own elements by 1-based global id (CellID /
+ *      EdgeID of its Decomp) -- rows are [n][nVertLevels] host doubles; var = "layerThickness" | "normalVelocity" |
+ *      "tracers" (plane = tracer index, else 0).  A restart may use a different partition. ---- */
+typedef struct omg_restart_file omg_restart_file;
+int omg_restart_create(const char *path, int64_t ncells_global, int64_t nedges_global, int nvertlevels, int ntracers,
+                       double simulation_time, int64_t steps_done);
+int omg_restart_open(const char *path, int write, omg_restart_file **out);
+int omg_restart_close(omg_restart_file *f);
+int omg_restart_info(const omg_restart_file *f, int64_t *ncells, int64_t *nedges, int *nvertlevels, int *ntracers,
+                     double *simulation_time, int64_t *steps_done);
+int omg_restart_write_rows(omg_restart_file *f, const char *var, int plane, const int32_t *global_id, int64_t n,
+                           const double *rows);
+int omg_restart_read_rows(const omg_restart_file *f, const char *var, int plane, const int32_t *global_id, int64_t n,
+                          double *rows);
+
 /* ---- Decomp (O/src/base/Decomp.cpp:444-745 constructor; Decomp.h:189-260 members).
  *      cell_task: optional [nCells] owner task of each cell (e.g. a METIS part file);
  *      NULL = built-in recursive coordinate bisection.  The global mesh arrays must stay

@@ -176,6 +176,70 @@ class GlobalMesh:
         self.s = s
 
 
+def write_restart(path, decomp, state, tracers, K, NT, simulation_time, steps_done, rank=0, barrier=None):
+    """Restart dump: rank 0 creates the file, every rank writes the rows of its OWNED cells / edges (time
+    level 0) at their global positions.  `barrier` (callable) separates the two phases when there are
+    several ranks."""
+    if rank == 0:
+        _chk(lib().omg_restart_create(os.fsencode(path), C.c_int64(decomp.get_int("NCellsGlobal")),
+                                      C.c_int64(decomp.get_int("NEdgesGlobal")), K, NT, C.c_double(simulation_time),
+                                      C.c_int64(steps_done)))
+    if barrier is not None:
+        barrier()
+    f = C.c_void_p()
+    _chk(lib().omg_restart_open(os.fsencode(path), 1, C.byref(f)))
+    try:
+        nc, ne = decomp.get_int("NCellsOwned"), decomp.get_int("NEdgesOwned")
+        cid = np.ascontiguousarray(decomp.get_array("CellID")[:nc], dtype=np.int32)
+        eid = np.ascontiguousarray(decomp.get_array("EdgeID")[:ne], dtype=np.int32)
+        h, u = state.copy_to_host(0)
+        _chk(lib().omg_restart_write_rows(f, b"layerThickness", 0, _pi(cid), C.c_int64(nc), _pd(np.ascontiguousarray(h[:nc]))))
+        _chk(lib().omg_restart_write_rows(f, b"normalVelocity", 0, _pi(eid), C.c_int64(ne), _pd(np.ascontiguousarray(u[:ne]))))
+        if NT > 0:
+            tr = tracers.copy_to_host(0)
+            for l in range(NT):
+                _chk(lib().omg_restart_write_rows(f, b"tracers", l, _pi(cid), C.c_int64(nc), _pd(np.ascontiguousarray(tr[l, :nc]))))
+    finally:
+        lib().omg_restart_close(f)
+    if barrier is not None:
+        barrier()
+
+
+def read_restart(path, decomp, mesh, state, tracers, K, NT):
+    """Restart load: every rank reads the rows of ALL its local cells / edges (owned and halo, by global
+    id) into time level 0, so no halo exchange is needed afterwards.  Returns (simulation_time, steps_done)."""
+    f = C.c_void_p()
+    _chk(lib().omg_restart_open(os.fsencode(path), 0, C.byref(f)))
+    try:
+        info = [C.c_int64(), C.c_int64(), C.c_int(), C.c_int(), C.c_double(), C.c_int64()]
+        _chk(lib().omg_restart_info(f, *[C.byref(x) for x in info]))
+        if (info[0].value, info[1].value, info[2].value) != (decomp.get_int("NCellsGlobal"), decomp.get_int("NEdgesGlobal"), K) \
+                or info[3].value < max(NT, 1):
+            raise OmegaAmdError(f"{path}: restart file does not match this mesh / configuration")
+        nc, ne = mesh.NCellsAll, mesh.NEdgesAll
+        cid = np.ascontiguousarray(decomp.get_array("CellID")[:nc], dtype=np.int32)
+        eid = np.ascontiguousarray(decomp.get_array("EdgeID")[:ne], dtype=np.int32)
+        h = np.zeros((mesh.NCellsSize, K))
+        u = np.zeros((mesh.NEdgesSize, K))
+        rows = np.empty((nc, K))
+        _chk(lib().omg_restart_read_rows(f, b"layerThickness", 0, _pi(cid), C.c_int64(nc), _pd(rows)))
+        h[:nc] = rows
+        rows = np.empty((ne, K))
+        _chk(lib().omg_restart_read_rows(f, b"normalVelocity", 0, _pi(eid), C.c_int64(ne), _pd(rows)))
+        u[:ne] = rows
+        state.copy_to_device(h, u, 0)
+        if NT > 0:
+            tr = np.zeros((NT, mesh.NCellsSize, K))
+            rows = np.empty((nc, K))
+            for l in range(NT):
+                _chk(lib().omg_restart_read_rows(f, b"tracers", l, _pi(cid), C.c_int64(nc), _pd(rows)))
+                tr[l, :nc] = rows
+            tracers.copy_to_device(tr, 0)
+        return info[4].value, info[5].value
+    finally:
+        lib().omg_restart_close(f)
+
+
 class MeshFile:
     """An MPAS mesh / initial-state file (NetCDF classic CDF-1/2/5) opened by the library's own reader;
     `.gm` is the GlobalMesh to build a Decomp from (the arrays live inside the file handle)."""

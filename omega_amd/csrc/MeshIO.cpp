@@ -4,6 +4,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace OMEGA {
 
@@ -326,6 +328,139 @@ MeshFile::MeshFile(const std::string &Path) : Nc(Path) {
    D.WeightsOnEdge = real("weightsOnEdge", NE * 2 * ME, true);
    D.FCell = real("fCell", NC, false), D.FEdge = real("fEdge", NE, false), D.FVertex = real("fVertex", NV, false);
    D.BottomDepth = real("bottomDepth", NC, false);
+}
+
+// ---------------------------------------------------------------------------------------
+// RestartFile
+namespace {
+void putBE(std::vector<unsigned char> &B, unsigned long long V, int N) {
+   for (int I = N - 1; I >= 0; --I)
+      B.push_back((unsigned char)((V >> (8 * I)) & 0xff));
+}
+void putName(std::vector<unsigned char> &B, const std::string &S) {
+   putBE(B, S.size(), 8);
+   B.insert(B.end(), S.begin(), S.end());
+   for (size_t I = S.size(); I % 4; ++I)
+      B.push_back(0);
+}
+void swapCopy(unsigned char *Dst, const R8 *Src, I8 N) { // host doubles -> big-endian bytes (and back)
+   for (I8 I = 0; I < N; ++I) {
+      unsigned char T[8];
+      std::memcpy(T, &Src[I], 8);
+      for (int J = 0; J < 8; ++J)
+         Dst[I * 8 + J] = T[7 - J];
+   }
+}
+} // namespace
+
+void RestartFile::create(const std::string &Path, I8 NC, I8 NE, int K, int NT, R8 SimTime, I8 Steps) {
+   struct V {
+      std::string Name;
+      std::vector<int> Dims;
+      int Type;
+      I8 Bytes;
+   };
+   const std::vector<std::pair<std::string, I8>> Dims{{"nCells", NC}, {"nEdges", NE}, {"nVertLevels", K},
+                                                      {"nTracers", NT > 0 ? NT : 1}};
+   const std::vector<V> Vars{{"simulationTime", {}, 6, 8},
+                             {"stepsDone", {}, 10, 8},
+                             {"layerThickness", {0, 2}, 6, NC * K * 8},
+                             {"normalVelocity", {1, 2}, 6, NE * K * 8},
+                             {"tracers", {3, 0, 2}, 6, (I8)(NT > 0 ? NT : 1) * NC * K * 8}};
+   auto Header = [&](const std::vector<I8> &Begins) {
+      std::vector<unsigned char> B{'C', 'D', 'F', 5};
+      putBE(B, 0, 8); // numrecs
+      putBE(B, 0x0A, 4), putBE(B, Dims.size(), 8);
+      for (auto &D : Dims)
+         putName(B, D.first), putBE(B, (unsigned long long)D.second, 8);
+      putBE(B, 0, 4), putBE(B, 0, 8); // no global attributes
+      putBE(B, 0x0B, 4), putBE(B, Vars.size(), 8);
+      for (size_t I = 0; I < Vars.size(); ++I) {
+         putName(B, Vars[I].Name);
+         putBE(B, Vars[I].Dims.size(), 8);
+         for (int D : Vars[I].Dims)
+            putBE(B, (unsigned long long)D, 8);
+         putBE(B, 0, 4), putBE(B, 0, 8); // no attributes
+         putBE(B, (unsigned long long)Vars[I].Type, 4);
+         putBE(B, (unsigned long long)Vars[I].Bytes, 8);
+         putBE(B, (unsigned long long)Begins[I], 8);
+      }
+      return B;
+   };
+   std::vector<I8> Begins(Vars.size(), 0);
+   const I8 HLen = (I8)Header(Begins).size();
+   I8 Off        = HLen;
+   for (size_t I = 0; I < Vars.size(); ++I) {
+      Begins[I] = Off;
+      Off += Vars[I].Bytes;
+   }
+   const std::vector<unsigned char> H = Header(Begins);
+   FILE *F = fopen(Path.c_str(), "wb");
+   if (!F)
+      OMEGA_ABORT("RestartFile: cannot create " + Path);
+   bool Ok = fwrite(H.data(), 1, H.size(), F) == H.size();
+   unsigned char T[16];
+   swapCopy(T, &SimTime, 1);
+   for (int J = 0; J < 8; ++J)
+      T[8 + J] = (unsigned char)(((unsigned long long)Steps >> (8 * (7 - J))) & 0xff);
+   Ok = Ok && fwrite(T, 1, 16, F) == 16;
+   // extend to the full size so that every rank can write its rows at their final positions
+   Ok = Ok && fseeko(F, (off_t)(Off - 1), SEEK_SET) == 0 && fputc(0, F) != EOF;
+   Ok = (fclose(F) == 0) && Ok;
+   if (!Ok)
+      OMEGA_ABORT("RestartFile: error writing the header of " + Path);
+}
+
+RestartFile::RestartFile(const std::string &InPath, bool Write) : Path(InPath) {
+   {
+      NcFile Nc(Path); // header through the reader
+      NCells = Nc.dimLen("nCells"), NEdges = Nc.dimLen("nEdges");
+      NVertLevels = (int)Nc.dimLen("nVertLevels"), NTracers = (int)Nc.dimLen("nTracers");
+      for (const char *N : {"layerThickness", "normalVelocity", "tracers"})
+         Begin[N] = Nc.var(N).Begin;
+      std::vector<R8> T;
+      Nc.read("simulationTime", T);
+      SimulationTime = T[0];
+      Nc.read("stepsDone", T);
+      StepsDone = (I8)T[0];
+   }
+   Fd = open(Path.c_str(), Write ? O_RDWR : O_RDONLY);
+   if (Fd < 0)
+      OMEGA_ABORT("RestartFile: cannot open " + Path);
+}
+RestartFile::~RestartFile() {
+   if (Fd >= 0)
+      close(Fd);
+}
+I8 RestartFile::rowOffset(const std::string &Var, int Plane, I8 Row) const {
+   auto It = Begin.find(Var);
+   if (It == Begin.end())
+      OMEGA_ABORT("RestartFile: no variable " + Var);
+   const I8 Rows = Var == "normalVelocity" ? NEdges : NCells;
+   if (Row < 0 || Row >= Rows || Plane < 0 || (Var == "tracers" ? Plane >= NTracers : Plane != 0))
+      OMEGA_ABORT("RestartFile: row / plane out of range for " + Var);
+   return It->second + ((I8)Plane * Rows + Row) * NVertLevels * 8;
+}
+void RestartFile::writeRows(const std::string &Var, int Plane, const I4 *GlobalID, I8 N, const R8 *Rows) {
+   std::vector<unsigned char> Buf((size_t)NVertLevels * 8);
+   for (I8 I = 0; I < N; ++I) {
+      swapCopy(Buf.data(), Rows + I * NVertLevels, NVertLevels);
+      if (pwrite(Fd, Buf.data(), Buf.size(), (off_t)rowOffset(Var, Plane, GlobalID[I] - 1)) != (ssize_t)Buf.size())
+         OMEGA_ABORT("RestartFile: short write to " + Path);
+   }
+}
+void RestartFile::readRows(const std::string &Var, int Plane, const I4 *GlobalID, I8 N, R8 *Rows) const {
+   std::vector<unsigned char> Buf((size_t)NVertLevels * 8);
+   for (I8 I = 0; I < N; ++I) {
+      if (pread(Fd, Buf.data(), Buf.size(), (off_t)rowOffset(Var, Plane, GlobalID[I] - 1)) != (ssize_t)Buf.size())
+         OMEGA_ABORT("RestartFile: short read from " + Path);
+      for (int K = 0; K < NVertLevels; ++K) {
+         unsigned char T[8];
+         for (int J = 0; J < 8; ++J)
+            T[J] = Buf[(size_t)K * 8 + 7 - J];
+         std::memcpy(&Rows[I * NVertLevels + K], T, 8);
+      }
+   }
 }
 
 } // namespace OMEGA

@@ -73,5 +73,34 @@ class MeshFile {
    const R8 *real(const std::string &MpasName, I8 Expect, bool Required);
 };
 
+/// Restart file (reference: the "RestartWrite" / "InitialState" IOStreams of Default.yml:91-127 write
+/// LayerThickness, NormalVelocity and the tracers through SCORPIO; here: one NetCDF classic CDF-5 file
+/// with fixed-size variables layerThickness(nCells, nVertLevels), normalVelocity(nEdges, nVertLevels),
+/// tracers(nTracers, nCells, nVertLevels), simulationTime, stepsDone).  The classic layout is fixed by the
+/// header, so every rank writes / reads the rows of its own elements at their global positions with
+/// plain positioned IO: no gather, and a restarted run may use a different partition.
+class RestartFile {
+ public:
+   /// rank 0: create the file and write the header (and the two scalars)
+   static void create(const std::string &Path, I8 NCellsGlobal, I8 NEdgesGlobal, int NVertLevels, int NTracers,
+                      R8 SimulationTime, I8 StepsDone);
+   explicit RestartFile(const std::string &Path, bool Write);
+   ~RestartFile();
+   I8 NCells = 0, NEdges = 0;
+   int NVertLevels = 0, NTracers = 0;
+   R8 SimulationTime = 0;
+   I8 StepsDone      = 0;
+   /// rows of `Var` ("layerThickness" | "normalVelocity" | "tracers" with Plane = tracer index) for the N
+   /// elements with 1-based global ids GlobalID[0..N): Rows is [N][NVertLevels], host memory
+   void writeRows(const std::string &Var, int Plane, const I4 *GlobalID, I8 N, const R8 *Rows);
+   void readRows(const std::string &Var, int Plane, const I4 *GlobalID, I8 N, R8 *Rows) const;
+
+ private:
+   int Fd = -1;
+   std::string Path;
+   std::map<std::string, I8> Begin;
+   I8 rowOffset(const std::string &Var, int Plane, I8 GlobalRow) const;
+};
+
 } // namespace OMEGA
 #endif

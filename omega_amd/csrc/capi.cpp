@@ -250,6 +250,57 @@ int omg_mesh_file_read_f64(const omg_mesh_file *f, const char *name, int64_t rec
    OMG_CATCH
 }
 
+// ---------------------------------------------------------------- restart file
+struct omg_restart_file {
+   std::unique_ptr<RestartFile> F;
+};
+int omg_restart_create(const char *path, int64_t ncells_global, int64_t nedges_global, int nvertlevels, int ntracers,
+                       double simulation_time, int64_t steps_done) {
+   OMG_TRY
+   OMG_ARG(path);
+   RestartFile::create(path, ncells_global, nedges_global, nvertlevels, ntracers, simulation_time, steps_done);
+   OMG_CATCH
+}
+int omg_restart_open(const char *path, int write, omg_restart_file **out) {
+   OMG_TRY
+   OMG_ARG(path && out);
+   auto *R = new omg_restart_file;
+   try {
+      R->F.reset(new RestartFile(path, write != 0));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_restart_close(omg_restart_file *f) {
+   delete f;
+   return 0;
+}
+int omg_restart_info(const omg_restart_file *f, int64_t *ncells, int64_t *nedges, int *nvertlevels, int *ntracers,
+                     double *simulation_time, int64_t *steps_done) {
+   OMG_TRY
+   OMG_ARG(f && ncells && nedges && nvertlevels && ntracers && simulation_time && steps_done);
+   *ncells = f->F->NCells, *nedges = f->F->NEdges, *nvertlevels = f->F->NVertLevels, *ntracers = f->F->NTracers;
+   *simulation_time = f->F->SimulationTime, *steps_done = f->F->StepsDone;
+   OMG_CATCH
+}
+int omg_restart_write_rows(omg_restart_file *f, const char *var, int plane, const int32_t *global_id, int64_t n,
+                           const double *rows) {
+   OMG_TRY
+   OMG_ARG(f && var && global_id && rows);
+   f->F->writeRows(var, plane, global_id, n, rows);
+   OMG_CATCH
+}
+int omg_restart_read_rows(const omg_restart_file *f, const char *var, int plane, const int32_t *global_id, int64_t n,
+                          double *rows) {
+   OMG_TRY
+   OMG_ARG(f && var && global_id && rows);
+   f->F->readRows(var, plane, global_id, n, rows);
+   OMG_CATCH
+}
+
 // ---------------------------------------------------------------- Decomp
 int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo_width, const int32_t *cell_task,
                       omg_decomp **out) {
