@@ -87,3 +87,32 @@ def test_rk4_step_conserves_volume_and_tracer_content(P):
     # restore the initial state for any test that follows
     P.state.copy_to_device(P.h, P.u, 0)
     P.tracers.copy_to_device(P.tr, 0)
+
+
+def test_repeated_evaluations_are_bitwise_deterministic(P):
+    """No atomics and no order-dependent accumulation anywhere on the path: 30 evaluations of the fused
+    RHS and two runs of three RK4 steps from the same state give identical bits (a data race between
+    workgroups or between the band / interior launches would show up here as a rare mismatch)."""
+    P.tend.set_fused(True)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    ref = [P.tend.get(i).copy() for i in range(3)]
+    for _ in range(30):
+        P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    for i in range(3):
+        assert np.array_equal(P.tend.get(i), ref[i])
+    runs = []
+    for _ in range(2):
+        P.state.copy_to_device(P.h, P.u, 0)
+        P.tracers.copy_to_device(P.tr, 0)
+        st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+        for _ in range(3):
+            st.do_step(P.state)
+        oa.device_synchronize()
+        h, u = P.state.copy_to_host(0)
+        runs.append((h, u, P.tracers.copy_to_host(0)))
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    P.state.copy_to_device(P.h, P.u, 0)
+    P.tracers.copy_to_device(P.tr, 0)
