@@ -348,3 +348,27 @@ def test_randomised_configurations(case):
         check("u", u, ost["u"][0], m.NEdgesOwned)
         if NT > 0:
             check("tr", P.tracers.copy_to_host(0)[:NT], ost["tr"][0][:NT], m.NCellsOwned)
+
+
+def test_bench_shaped_problem_against_the_oracle():
+    """The bench's own setup at a size the oracle still finishes in a second: Morton-ordered planar mesh,
+    80 levels, 6 tracers (tiles of 32 elements, 5 level chunks per tile), fused RHS + RK4 step."""
+    from omega_amd.meshgen import reorder_cells_morton
+    g = reorder_cells_morton(planar_hex(160, 128, 30.0e3))
+    P = Problem(g, 80, 6)
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    m = P.mesh
+    check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+    check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+    check("trTend", P.tend.get(2), trT, m.NCellsOwned)
+    st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    st.do_step(P.state)
+    oa.device_synchronize()
+    P.oracle.step("rk4", ost, 600.0)
+    h, u = P.state.copy_to_host(0)
+    check("h", h, ost["h"][0], m.NCellsOwned)
+    check("u", u, ost["u"][0], m.NEdgesOwned)
+    check("tr", P.tracers.copy_to_host(0), ost["tr"][0], m.NCellsOwned)
