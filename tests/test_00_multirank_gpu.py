@@ -25,6 +25,8 @@ pytestmark = pytest.mark.gpu
     ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4],                   # band AND interior launches, overlapped
     ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4, "--no-overlap"],   # same, exchange after the stage
     ["--halo-width", 4, "--nx", 72, "--ny", 12, "--levels", 3, "--steps", 3],
+    ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4, "--tracers", 0],   # no tracer kernel: exchange starts after the u band
+    ["--no-del4", "--mesh", "ico3", "--levels", 4],                          # sphere, pentagon ring launches, 2 ranks
 ])
 def test_two_ranks_one_gpu(extra):
     outs = run_ranks("gpu", 2, extra, timeout=900)
