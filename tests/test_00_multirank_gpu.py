@@ -44,3 +44,10 @@ def test_generic_fallback_kernels_in_a_child_process():
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     assert " passed" in out and "failed" not in out
+
+
+def test_four_ranks_one_gpu():
+    """Four ranks (2 x 2 blocks of a 48 x 48 mesh: every rank has several neighbours, corner halos travel
+    through two of them) on one GPU, overlapped exchanges."""
+    outs = run_ranks("gpu", 4, ["--no-del4", "--nx", 48, "--ny", 48, "--levels", 3], timeout=900)
+    assert all("OK" in o for o in outs)
