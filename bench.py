@@ -51,12 +51,12 @@ def algorithmic_bytes_per_cell_level(nt, kernel=None):
     """SURVEY.md 8(d) B_staged = 8*(39 + 5*NT) B per cell-level for the whole RHS (NE = 3NC,
     NV = 2NC); per kernel: the arrays that kernel must read / write once."""
     per_kernel = {
-        "VortVertexBody": 8 * (1 + 3 + 3 * 2),                 # h, u -> 3 vertex arrays
+        "VortVertexBody": 8 * (1 + 3 + 2 * 2),                 # h, u -> RelVort, 1/LayerThickVertex
         "FusedCell1Body": 8 * (3 + 1 + nt + 3 + nt),            # u, h, tr -> KE, Div, hTend, Del2Tr
         "Del2CellRingBody": 8 * (1 + 2 + 1),                    # Div, RelVort -> Del2Div
         "Del2VertexSelBody": 8 * (1 + 2 + 2),                   # Div, RelVort -> Del2RelVort
-        "CellPVBody<side 0>": 8 * (3 + 1 + 2 * 2 + 3),          # u, h, 2 vertex arrays -> running PV sums
-        "CellPVFinalBody": 8 * (3 + 1 + 3 * 2 + 3 + 3 + 2 + 3),  # + sums, RelVort, KE, Div, Del2Div, Del2RV -> uTend
+        "CellPVBody<side 0>": 8 * (3 + 1 + 2 * 2 + 3),          # u, h, RelVort, InvThick -> running PV sums
+        "CellPVFinalBody": 8 * (3 + 1 + 2 * 2 + 3 + 3 + 2 + 3),  # + sums, KE, Div, Del2Div, Del2RV -> uTend
         "FusedCell3Body": 8 * (nt + nt + 1 + 3 + nt),           # tr, Del2Tr, h, u -> trTend
     }
     per_kernel["CellPVBody<side 0>+FusedCell3Body"] = 8 * (nt + nt + 1 + 3 + nt + 2 * 2 + 3)

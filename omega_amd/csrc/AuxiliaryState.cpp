@@ -16,6 +16,7 @@ AuxiliaryState::AuxiliaryState(const std::string &Name_, const HorzMesh *Mesh_, 
    VorticityAux.RelVortVertex           = Array2DReal("RelVortVertex", NV, K);
    VorticityAux.NormRelVortVertex       = Array2DReal("NormRelVortVertex", NV, K);
    VorticityAux.NormPlanetVortVertex    = Array2DReal("NormPlanetVortVertex", NV, K);
+   VorticityAux.InvThickVertex          = Array2DReal("InvThickVertex", NV, K);
    VorticityAux.NormRelVortEdge         = Array2DReal("NormRelVortEdge", NE, K);
    VorticityAux.NormPlanetVortEdge      = Array2DReal("NormPlanetVortEdge", NE, K);
    VelocityDel2Aux.Del2Edge             = Array2DReal("Del2Edge", NE, K);
@@ -38,6 +39,7 @@ AuxPtrs AuxiliaryState::ptrs() const {
    A.RelVortVertex        = VorticityAux.RelVortVertex.Ptr;
    A.NormRelVortVertex    = VorticityAux.NormRelVortVertex.Ptr;
    A.NormPlanetVortVertex = VorticityAux.NormPlanetVortVertex.Ptr;
+   A.InvThickVertex       = VorticityAux.InvThickVertex.Ptr;
    A.NormRelVortEdge      = VorticityAux.NormRelVortEdge.Ptr;
    A.NormPlanetVortEdge   = VorticityAux.NormPlanetVortEdge.Ptr;
    A.Del2Edge             = VelocityDel2Aux.Del2Edge.Ptr;

@@ -24,6 +24,7 @@ struct LayerThicknessAuxVars {
 };
 struct VorticityAuxVars {
    Array2DReal RelVortVertex, NormRelVortVertex, NormPlanetVortVertex, NormRelVortEdge, NormPlanetVortEdge;
+   Array2DReal InvThickVertex; ///< 1/LayerThickVertex: internal to the fused RHS (not a reference array)
 };
 struct VelocityDel2AuxVars {
    Array2DReal Del2Edge, Del2DivCell, Del2RelVortVertex;

@@ -15,7 +15,8 @@ struct VortVertexBody {
    MeshView M;
    int K;
    const Real *H, *U;
-   Real *RelVort, *NormRelVort, *NormPlanetVort;
+   Real *RelVort, *NormRelVort, *NormPlanetVort, *InvThick;
+   int StoreNorm, StoreInv;
    struct Lds {
       Real *KiteC, *VortC, *F;
       int *Cell, *Edge;
@@ -59,13 +60,27 @@ struct VortVertexBody {
       }
       const T Inv = 1. / LayerThickVertex;
       stk<T>(RelVort, IVertex, K, Kv, RelVortTmp);
-      stk<T>(NormRelVort, IVertex, K, Kv, RelVortTmp * Inv);
-      stk<T>(NormPlanetVort, IVertex, K, Kv, L.F[Le] * Inv);
+      if (StoreNorm) {
+         stk<T>(NormRelVort, IVertex, K, Kv, RelVortTmp * Inv);
+         stk<T>(NormPlanetVort, IVertex, K, Kv, L.F[Le] * Inv);
+      }
+      if (StoreInv)
+         stk<T>(InvThick, IVertex, K, Kv, Inv);
    }
 };
 
-void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S) {
-   VortVertexBody B{M, K, H, U, A.RelVortVertex, A.NormRelVortVertex, A.NormPlanetVortVertex};
+void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S,
+                           bool StoreNorm, bool StoreInv) {
+   VortVertexBody B{M,
+                    K,
+                    H,
+                    U,
+                    A.RelVortVertex,
+                    A.NormRelVortVertex,
+                    A.NormPlanetVortVertex,
+                    A.InvThickVertex,
+                    StoreNorm ? 1 : 0,
+                    StoreInv ? 1 : 0};
    launchTile(B, M.NVerticesAll, K, S);
 }
 

@@ -624,7 +624,13 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
    int K;
    TendParams P;
    const Real *H, *U;
-   const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
+   const Real *RelVort, *InvThickV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
+   /// normalised vorticities at a vertex, rebuilt as the vertex kernel computes them (VorticityAuxVars.h:50-53)
+   template <class T> __device__ __forceinline__ void normVort(int V, unsigned Off, T &QR, T &QF) const {
+      const T Iv = ldo<T>(InvThickV, Off);
+      QR         = ldo<T>(RelVort, Off) * Iv;
+      QF         = M.FVertex[V] * Iv;
+   }
    Real *Tend;
    const I4 *EdgeList = nullptr; ///< if set, element i of the sweep is edge EdgeList[i]
    StageEpi E{};                 ///< velocity stage update (EPI)
@@ -705,8 +711,11 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
       T TendV = splat<T>(0.0);
       if (PVOn) {
          // NormRelVortEdge / NormPlanetVortEdge of this edge (VorticityAuxVars.h:68-74)
-         const T QRe = 0.5 * (ldo<T>(NormRelVortV, OffV0) + ldo<T>(NormRelVortV, OffV1));
-         const T QFe = 0.5 * (ldo<T>(NormPlanetVortV, OffV0) + ldo<T>(NormPlanetVortV, OffV1));
+         T QR0, QF0, QR1, QF1;
+         normVort<T>(L.V0[Le], OffV0, QR0, QF0);
+         normVort<T>(L.V1[Le], OffV1, QR1, QF1);
+         const T QRe = 0.5 * (QR0 + QR1);
+         const T QFe = 0.5 * (QF0 + QF1);
          T VortTmp   = splat<T>(0.0);
 #pragma unroll
          for (int Sd = 0; Sd < 2; ++Sd) {
@@ -717,8 +726,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
 #pragma unroll
             for (int J = 0; J < TME; ++J) {
                const unsigned Off = rowOff<T>(L.ChV[BV + J], K, Kv);
-               QR[J]              = ldo<T>(NormRelVortV, Off);
-               QF[J]              = ldo<T>(NormPlanetVortV, Off);
+               normVort<T>(L.ChV[BV + J], Off, QR[J], QF[J]);
             }
 #pragma unroll
             for (int J = 0; J < TM1; ++J) {
@@ -794,21 +802,22 @@ template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
    MeshView M;
    int K;
    TendParams P;
-   const Real *H, *U, *NormRelVortV, *NormPlanetVortV;
+   const Real *H, *U, *RelVortV, *InvThickV; // NormRelVort = RelVort*InvThick, NormPlanetVort = FVertex*InvThick
    Real *Partial; // [NEdgesSize][K] running PV sums
    const int *List = nullptr; // optional cell list (the launches for the rarer valences)
    struct Lds {
-      Real *Wt;
+      Real *Wt, *FV;
       int *Edge, *NbrF, *Ring, *Role, *N;
    };
    __host__ __device__ size_t ldsBytes(int Tile) const {
-      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(int) * Tile * TME) * 4 +
-             ldsRound8(sizeof(int) * Tile);
+      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) +
+             ldsRound8(sizeof(int) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile);
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
       LdsCarver C{Ptr};
       Lds L;
       L.Wt   = C.take<Real>(Tile * TME * TM1);
+      L.FV   = C.take<Real>(Tile * TME);
       L.Edge = C.take<int>(Tile * TME);
       L.NbrF = C.take<int>(Tile * TME);
       L.Ring = C.take<int>(Tile * TME);
@@ -829,6 +838,7 @@ template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
          L.Edge[I]      = M.EdgesOnCell[G];
          L.NbrF[I]      = M.NbrFlagOnCell[G];
          L.Ring[I]      = M.RingVertOnCell[G];
+         L.FV[I]        = M.FVertex[M.RingVertOnCell[G]];
          L.Role[I]      = M.PVRoleOnCell[G];
       }
       for (int I = Tid; I < Cnt; I += NThr)
@@ -860,8 +870,9 @@ template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
             Uj[J]       = ldo<T>(U, OffE[J]);
             Hn[J]       = ldo<T>(H, rowOff<T>(F & 0x3fffffff, K, Kv));
             const unsigned OffV = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
-            QR[J]               = ldo<T>(NormRelVortV, OffV);
-            QF[J]               = ldo<T>(NormPlanetVortV, OffV);
+            const T Iv          = ldo<T>(InvThickV, OffV);
+            QR[J]               = ldo<T>(RelVortV, OffV) * Iv; // VorticityAuxVars.h:50-53
+            QF[J]               = L.FV[Le * TME + J] * Iv;
          }
          const T Hs = ldo<T>(H, rowOff<T>(ICell, K, Kv));
 #pragma unroll
@@ -907,17 +918,17 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
    MeshView M;
    int K;
    TendParams P;
-   const Real *H, *U, *NormRelVortV, *NormPlanetVortV, *Partial;
+   const Real *H, *U, *RelVortV, *InvThickV, *Partial;
    const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort;
    Real *Tend;
    const int *List = nullptr;
    StageEpi E{}; // velocity stage update (EPI)
    struct Lds {
-      Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs;
+      Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs, *FV;
       int *Edge, *NbrF, *Ring, *Role, *N;
    };
    size_t ldsBytes(int Tile) const {
-      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) * 5 +
+      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) * 6 +
              ldsRound8(sizeof(Real) * Tile) + ldsRound8(sizeof(int) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile);
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
@@ -929,6 +940,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
       L.C2     = C.take<Real>(Tile * TME);
       L.C4     = C.take<Real>(Tile * TME);
       L.BDn    = C.take<Real>(Tile * TME);
+      L.FV     = C.take<Real>(Tile * TME);
       L.BDs    = C.take<Real>(Tile);
       L.Edge   = C.take<int>(Tile * TME);
       L.NbrF   = C.take<int>(Tile * TME);
@@ -953,6 +965,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
          L.Edge[I]       = E;
          L.NbrF[I]       = F;
          L.Ring[I]       = M.RingVertOnCell[G];
+         L.FV[I]         = M.FVertex[M.RingVertOnCell[G]];
          L.Role[I]       = M.PVRoleOnCell[G];
          L.InvDc[I]      = M.InvDcEdge[E];
          L.InvDvS[I]     = M.RingSignOnCell[G] * M.InvDvEdge[E];
@@ -991,8 +1004,9 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
             OffV[J] = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
             Uj[J]   = ldo<T>(U, OffE[J]);
             Hn[J]   = ldo<T>(H, OffN[J]);
-            QR[J]   = ldo<T>(NormRelVortV, OffV[J]);
-            QF[J]   = ldo<T>(NormPlanetVortV, OffV[J]);
+            const T Iv = ldo<T>(InvThickV, OffV[J]);
+            QR[J]      = ldo<T>(RelVortV, OffV[J]) * Iv;
+            QF[J]      = L.FV[Le * TME + J] * Iv;
          }
 #pragma unroll
          for (int J = 0; J < N; ++J) {
@@ -1348,7 +1362,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    };
    // L1
    Mark(0);
-   launchVertexAuxState1(M, K, A, H, U, S);
+   // the vertex kernel stores RelVort and 1/LayerThickVertex; the two normalised vorticities are rebuilt from
+   // them where they are consumed, and only the generic edge kernel still reads the reference's arrays
+   launchVertexAuxState1(M, K, A, H, U, S, /*StoreNorm*/ !M.PVChainOK, /*StoreInv*/ true);
    Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    bool Cell1Done = false;
@@ -1406,17 +1422,17 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          // the rarer valences (MaxEdges-1, MaxEdges-2: e.g. the pentagons of a mesh stored with
          // maxEdges = 6 or 7) run the same ring code, instantiated for their size, over cell lists
          constexpr int NM1 = TME - 1, NM2 = TME >= 6 ? TME - 2 : TME - 1;
-         CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
+         CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
          if (M.NRingCellsM0 > 0)
             launchTile(B0, M.NCellsAll, K, S);
          FusedKernelNames[4] = "CellPVBody<side 0>";
          if (M.NRingCellsM1 > 0) {
-            CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+            CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                              M.RingCellsM1};
             launchTile(Bm, M.NRingCellsM1, K, S);
          }
          if (TME >= 6 && M.NRingCellsM2 > 0) {
-            CellPVBody<TME, Fast, 0, NM2> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+            CellPVBody<TME, Fast, 0, NM2> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                              M.RingCellsM2};
             launchTile(Bm, M.NRingCellsM2, K, S);
          }
@@ -1434,8 +1450,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 P,
                                                 H,
                                                 U,
-                                                A.NormRelVortVertex,
-                                                A.NormPlanetVortVertex,
+                                                A.RelVortVertex,
+                                                A.InvThickVertex,
                                                 EdgeScratch,
                                                 A.RelVortVertex,
                                                 A.KineticEnergyCell,
@@ -1455,13 +1471,13 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                }
                if (M.NRingCellsM1 > 0) {
                   CellPVFinalBody<TME, NM1, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
-                                                   B1.NormRelVortV, B1.NormPlanetVortV, B1.Partial, B1.RelVort, B1.KE,
+                                                   B1.RelVortV, B1.InvThickV, B1.Partial, B1.RelVort, B1.KE,
                                                    B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM1, EU};
                   launchTile(Bm, M.NRingCellsM1, K, S);
                }
                if (TME >= 6 && M.NRingCellsM2 > 0) {
                   CellPVFinalBody<TME, NM2, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
-                                                   B1.NormRelVortV, B1.NormPlanetVortV, B1.Partial, B1.RelVort, B1.KE,
+                                                   B1.RelVortV, B1.InvThickV, B1.Partial, B1.RelVort, B1.KE,
                                                    B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM2, EU};
                   launchTile(Bm, M.NRingCellsM2, K, S);
                }
@@ -1476,8 +1492,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                         P,
                                                         H,
                                                         U,
-                                                        A.NormRelVortVertex,
-                                                        A.NormPlanetVortVertex,
+                                                        A.RelVortVertex,
+                                                        A.InvThickVertex,
                                                         EdgeScratch,
                                                         A.RelVortVertex,
                                                         A.KineticEnergyCell,
@@ -1498,16 +1514,16 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             Finished            = true;
             FusedKernelNames[5] = "CellPVFinalBody";
          } else {
-            CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch};
+            CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
             if (M.NRingCellsM0 > 0)
                launchTile(B1, M.NCellsAll, K, S);
             if (M.NRingCellsM1 > 0) {
-               CellPVBody<TME, Fast, 1, NM1> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+               CellPVBody<TME, Fast, 1, NM1> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                 M.RingCellsM1};
                launchTile(Bm, M.NRingCellsM1, K, S);
             }
             if (TME >= 6 && M.NRingCellsM2 > 0) {
-               CellPVBody<TME, Fast, 1, NM2> Bm{M, K, P, H, U, A.NormRelVortVertex, A.NormPlanetVortVertex, EdgeScratch,
+               CellPVBody<TME, Fast, 1, NM2> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                 M.RingCellsM2};
                launchTile(Bm, M.NRingCellsM2, K, S);
             }
@@ -1539,8 +1555,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 H,
                                                 U,
                                                 A.RelVortVertex,
-                                                A.NormRelVortVertex,
-                                                A.NormPlanetVortVertex,
+                                                A.InvThickVertex,
                                                 A.KineticEnergyCell,
                                                 A.VelocityDivCell,
                                                 A.Del2DivCell,
@@ -1563,8 +1578,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                       H,
                                       U,
                                       A.RelVortVertex,
-                                      A.NormRelVortVertex,
-                                      A.NormPlanetVortVertex,
+                                      A.InvThickVertex,
                                       A.KineticEnergyCell,
                                       A.VelocityDivCell,
                                       A.Del2DivCell,

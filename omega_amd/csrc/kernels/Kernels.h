@@ -14,6 +14,7 @@ struct AuxPtrs {
    Real *FluxLayerThickEdge, *MeanLayerThickEdge;                  // E x K
    Real *SshCell;                                                  // C x K
    Real *RelVortVertex, *NormRelVortVertex, *NormPlanetVortVertex; // V x K
+   Real *InvThickVertex; // V x K: 1/LayerThickVertex (VorticityAuxVars.h:47), fused RHS only -- see launchVertexAuxState1
    Real *NormRelVortEdge, *NormPlanetVortEdge;                     // E x K
    Real *Del2Edge, *Del2DivCell, *Del2RelVortVertex;               // E, C, V x K
    Real *HTracersEdge, *Del2TracersCell;                           // NT x E x K, NT x C x K
@@ -34,7 +35,11 @@ struct TendParams {
 };
 
 // ---- AuxiliaryState launches, one per reference parallelFor (AuxiliaryState.cpp:79-182) ----
-void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S);
+/// StoreNorm: write NormRelVortVertex / NormPlanetVortVertex (the reference's arrays); StoreInv: write
+/// InvThickVertex instead, from which the fused PV kernels rebuild both with the same multiplication
+/// (RelVort*Inv, FVertex*Inv: one vertex array less to write and to gather)
+void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S,
+                           bool StoreNorm = true, bool StoreInv = false);
 void launchCellAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *U, hipStream_t S);
 void launchEdgeAuxState1(const MeshView &M, const AuxPtrs &A, int Isotropic, hipStream_t S);
 void launchEdgeAuxState2(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, int FluxUpwind,
