@@ -243,7 +243,7 @@ def main():
         # WRITE_SIZE on this same command, gfx950 correction applied; profiles/): only valid for the
         # workload and partition they were collected on
         traffic = traffic_src = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_v6_bench_qu30_pmc.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_v7_bench_qu30_pmc.json")
         if args.workload == "qu30" and N == 1 and not args.unfused and os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
@@ -252,7 +252,7 @@ def main():
             # `..., true>` instantiations are the RK4 stage-fused variants; the RHS timed here is the plain one
             plain = [k for k in cands if not k.endswith(", true>")] or cands
             if plain:
-                traffic, traffic_src = pmc[plain[0]]["hbm_bytes_per_launch"], "profiles/r01_v6_bench_qu30_pmc.json"
+                traffic, traffic_src = pmc[plain[0]]["hbm_bytes_per_launch"], "profiles/r01_v7_bench_qu30_pmc.json"
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src,
