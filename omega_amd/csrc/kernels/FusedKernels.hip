@@ -616,7 +616,7 @@ struct FusedEdgeBody {
 // that cell as one of their two cells, so per side only the chain's vertices and the far cells
 // are gathered (a+b == b+a exactly, so which end vertex / cell comes first does not matter for
 // the means; the upwind choice keeps its flag).
-template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
+template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEdgeChainBody {
    static constexpr int MinWaves = OMEGA_EDGE_MINW;
    static constexpr int MaxW     = OMEGA_EDGE_MAXW;
    static constexpr int TM1      = TME - 1;
@@ -624,23 +624,31 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
    int K;
    TendParams P;
    const Real *H, *U;
-   const Real *RelVort, *InvThickV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
-   /// normalised vorticities at a vertex, rebuilt as the vertex kernel computes them (VorticityAuxVars.h:50-53)
-   template <class T> __device__ __forceinline__ void normVort(int V, unsigned Off, T &QR, T &QF) const {
-      const T Iv = ldo<T>(InvThickV, Off);
-      QR         = ldo<T>(RelVort, Off) * Iv;
-      QF         = M.FVertex[V] * Iv;
+   /// INV (the irregular-edge list launch next to the cell-centric kernels): VortA = InvThickVertex and the
+   /// normalised vorticities are rebuilt as the vertex kernel computes them (VorticityAuxVars.h:50-53);
+   /// otherwise (this kernel as the whole edge pass) VortA / VortB = NormRelVortVertex / NormPlanetVortVertex
+   const Real *RelVort, *VortA, *VortB, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
+   template <class T> __device__ __forceinline__ void normVort(Real FV, unsigned Off, T &QR, T &QF) const {
+      if (INV) {
+         const T Iv = ldo<T>(VortA, Off);
+         QR         = ldo<T>(RelVort, Off) * Iv;
+         QF         = FV * Iv;
+      } else {
+         QR = ldo<T>(VortA, Off);
+         QF = ldo<T>(VortB, Off);
+      }
    }
    Real *Tend;
    const I4 *EdgeList = nullptr; ///< if set, element i of the sweep is edge EdgeList[i]
    StageEpi E{};                 ///< velocity stage update (EPI)
    __device__ int edgeOf(int I) const { return EdgeList ? EdgeList[I] : I; }
    struct Lds {
-      Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
+      Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1, *FCh, *F0, *F1; // F*: FVertex of ChV / V0 / V1
       int *ChV, *ChF, *ChE, *C0, *C1, *V0, *V1;
    };
    size_t ldsBytes(int Tile) const {
-      return ldsRound8(sizeof(Real) * Tile * 2 * TM1) + ldsRound8(sizeof(Real) * Tile) * 8 +
+      return ldsRound8(sizeof(Real) * Tile * 2 * TM1) + ldsRound8(sizeof(Real) * Tile) * 10 +
+             ldsRound8(sizeof(Real) * Tile * 2 * TME) +
              ldsRound8(sizeof(int) * Tile * 2 * TME) + ldsRound8(sizeof(int) * Tile * 2 * TM1) * 2 +
              ldsRound8(sizeof(int) * Tile) * 4;
    }
@@ -656,6 +664,9 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
       L.C4       = C.take<Real>(Tile);
       L.BD0      = C.take<Real>(Tile);
       L.BD1      = C.take<Real>(Tile);
+      L.F0       = C.take<Real>(Tile);
+      L.F1       = C.take<Real>(Tile);
+      L.FCh      = C.take<Real>(Tile * 2 * TME);
       L.ChV      = C.take<int>(Tile * 2 * TME);
       L.ChF      = C.take<int>(Tile * 2 * TM1);
       L.ChE      = C.take<int>(Tile * 2 * TM1);
@@ -677,6 +688,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
       for (int I = Tid; I < Cnt * 2 * TME; I += NThr) {
          const int Ei = I / (2 * TME);
          L.ChV[I]     = M.PVChainVert[(size_t)edgeOf(First + Ei) * 2 * TME + (I - Ei * 2 * TME)];
+         L.FCh[I]     = M.FVertex[L.ChV[I]];
       }
       for (int I = Tid; I < Cnt; I += NThr) {
          const int E     = edgeOf(First + I);
@@ -694,6 +706,8 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
          L.C1[I]       = C1;
          L.V0[I]       = M.VerticesOnEdge[2 * E];
          L.V1[I]       = M.VerticesOnEdge[2 * E + 1];
+         L.F0[I]       = M.FVertex[M.VerticesOnEdge[2 * E]];
+         L.F1[I]       = M.FVertex[M.VerticesOnEdge[2 * E + 1]];
       }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
@@ -712,8 +726,8 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
       if (PVOn) {
          // NormRelVortEdge / NormPlanetVortEdge of this edge (VorticityAuxVars.h:68-74)
          T QR0, QF0, QR1, QF1;
-         normVort<T>(L.V0[Le], OffV0, QR0, QF0);
-         normVort<T>(L.V1[Le], OffV1, QR1, QF1);
+         normVort<T>(L.F0[Le], OffV0, QR0, QF0);
+         normVort<T>(L.F1[Le], OffV1, QR1, QF1);
          const T QRe = 0.5 * (QR0 + QR1);
          const T QFe = 0.5 * (QF0 + QF1);
          T VortTmp   = splat<T>(0.0);
@@ -726,7 +740,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedEdgeChainBody {
 #pragma unroll
             for (int J = 0; J < TME; ++J) {
                const unsigned Off = rowOff<T>(L.ChV[BV + J], K, Kv);
-               normVort<T>(L.ChV[BV + J], Off, QR[J], QF[J]);
+               normVort<T>(L.FCh[BV + J], Off, QR[J], QF[J]);
             }
 #pragma unroll
             for (int J = 0; J < TM1; ++J) {
@@ -1363,8 +1377,10 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // L1
    Mark(0);
    // the vertex kernel stores RelVort and 1/LayerThickVertex; the two normalised vorticities are rebuilt from
-   // them where they are consumed, and only the generic edge kernel still reads the reference's arrays
-   launchVertexAuxState1(M, K, A, H, U, S, /*StoreNorm*/ !M.PVChainOK, /*StoreInv*/ true);
+   // them where they are consumed; without the cell-centric tables the edge kernels read the reference's arrays
+   static const int EdgeModeV = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
+   const bool CellCentric     = EdgeModeV == 0 && M.CellPVOK && EdgeScratch;
+   launchVertexAuxState1(M, K, A, H, U, S, /*StoreNorm*/ !CellCentric, /*StoreInv*/ CellCentric);
    Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    bool Cell1Done = false;
@@ -1549,14 +1565,15 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       if (M.NIrregularEdges > 0) {
          auto LaunchList = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
-            FusedEdgeChainBody<TME, Fast, EP> B{M,
-                                                K,
-                                                P,
-                                                H,
-                                                U,
-                                                A.RelVortVertex,
-                                                A.InvThickVertex,
-                                                A.KineticEnergyCell,
+            FusedEdgeChainBody<TME, Fast, EP, true> B{M,
+                                                      K,
+                                                      P,
+                                                      H,
+                                                      U,
+                                                      A.RelVortVertex,
+                                                      A.InvThickVertex,
+                                                      nullptr,
+                                                      A.KineticEnergyCell,
                                                 A.VelocityDivCell,
                                                 A.Del2DivCell,
                                                 A.Del2RelVortVertex,
@@ -1578,7 +1595,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                       H,
                                       U,
                                       A.RelVortVertex,
-                                      A.InvThickVertex,
+                                      A.NormRelVortVertex,
+                                      A.NormPlanetVortVertex,
                                       A.KineticEnergyCell,
                                       A.VelocityDivCell,
                                       A.Del2DivCell,
