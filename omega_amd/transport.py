@@ -38,9 +38,10 @@ class TorchTransport:
         ops, staged = [], []
         # the C++ side says which HIP stream the pack / unpack kernels of THIS exchange run on (the stepper's
         # communication stream when the exchange is overlapped with interior compute): RCCL must order on it
-        if direct and stream_handle:
+        own = None if self.stream is None else int(self.stream.cuda_stream)
+        if direct and stream_handle and int(stream_handle) != own:
             ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream_handle)))
-        else:
+        else:   # the stream this transport was created for (sequential exchanges), or the default stream
             ctx = torch.cuda.stream(self.stream) if (self.stream is not None) else _Null()
         with ctx:
             for i, t in enumerate(tasks):
