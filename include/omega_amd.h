@@ -234,6 +234,18 @@ int omg_tend_compute_tracer_only(omg_tend *t, const omg_state *s, omg_aux *a, co
  * since the reference time (the time steppers set it per stage). */
 int omg_tend_use_manufactured_solution(omg_tend *t, const omg_mesh *m, double wavelength_x, double wavelength_y,
                                        double amplitude);
+/* Custom tendencies as a caller-supplied function (Tendencies::CustomTendencyType, O/src/ocn/Tendencies.h:51-53:
+ * std::function<void(Array2DReal Tend, const OceanState*, const AuxiliaryState*, int ThickTimeLevel,
+ * int VelTimeLevel, TimeInstant)>, called at the end of the thickness / velocity group, Tendencies.cpp:288-291,
+ * 416-419).  The callback ADDS its term to tend_dev ([n_rows_size][nvertlayers] device doubles, elements
+ * [0, n_rows_all) are to be written) on `stream`; it is handed the state the tendencies are evaluated on as raw
+ * device arrays (layer thickness [NCellsSize][K] at the thickness time level, normal velocity [NEdgesSize][K] at
+ * the velocity time level) and the model time in seconds.  which: 0 thickness, 1 velocity.  fn == NULL clears
+ * that hook.  With a custom hook set the Runge-Kutta stage updates run as separate kernels. */
+typedef int (*omg_custom_tend_fn)(void *ctx, double *tend_dev, const double *layer_thickness_dev,
+                                  const double *normal_velocity_dev, int n_rows_all, int n_rows_size, int nvertlayers,
+                                  double time_seconds, void *stream);
+int omg_tend_set_custom_tendency(omg_tend *t, int which, omg_custom_tend_fn fn, void *ctx);
 int omg_tend_clear_custom_tendencies(omg_tend *t);
 int omg_tend_set_time(omg_tend *t, double seconds);
 int omg_tend_kernel_timing(omg_tend *t, int enable);
@@ -261,6 +273,13 @@ int omg_stepper_get_time(const omg_stepper *st, double *seconds);
  * exchange starts when the band of cells whose values travel is final and runs on a communication stream
  * while the stage's interior cells are computed).  0 / 1. */
 int omg_stepper_set_option(omg_stepper *st, const char *name, int value);
+/* TimeStepper::changeTimeStep (O/src/timeStepping/TimeStepper.h:141-143) */
+int omg_stepper_change_time_step(omg_stepper *st, double time_step_seconds);
+/* the update kernel of TimeStepper::updateThicknessByTend / updateVelocityByTend (O/src/timeStepping/
+ * TimeStepper.cpp:378-441) on raw device arrays: out[r][k] = in[r][k] + coeff * tend[r][k] for r < n_rows
+ * (out may alias in) */
+int omg_update_by_tend(double *out_dev, const double *in_dev, const double *tend_dev, double coeff, int n_rows,
+                       int nvertlayers, void *stream);
 int omg_stepper_coeff_seconds(double mult, double time_step_seconds, double *out);
 
 #ifdef __cplusplus

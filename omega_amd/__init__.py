@@ -61,6 +61,9 @@ class TendConfig(C.Structure):
 TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, PI, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p)
 
+CUSTOM_TEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                             C.c_double, C.c_void_p)
+
 _lib = None
 
 
@@ -244,10 +247,13 @@ class MeshFile:
     """An MPAS mesh / initial-state file (NetCDF classic CDF-1/2/5) opened by the library's own reader;
     `.gm` is the GlobalMesh to build a Decomp from (the arrays live inside the file handle)."""
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, mesh: bool = True):
         h = C.c_void_p()
         _chk(lib().omg_mesh_file_open(os.fsencode(path), C.byref(h)))
         self.h = h
+        self.gm = None
+        if not mesh:   # a state-only file (initial conditions, forcing): variables through read()
+            return
         gm = GlobalMesh.__new__(GlobalMesh)
         gm.s = GlobalMeshC()
         gm.keep = {"file": self}
@@ -685,6 +691,27 @@ class Tendencies:
         _chk(lib().omg_tend_use_manufactured_solution(self.h, mesh.h, C.c_double(wavelength_x), C.c_double(wavelength_y),
                                                       C.c_double(amplitude)))
 
+    def set_custom_tendency(self, which: int, fn):
+        """Tendencies::CustomThicknessTend (which 0) / CustomVelocityTend (which 1) as a Python callable
+        fn(tend_ptr, h_ptr, u_ptr, n_rows_all, n_rows_size, K, time_seconds, stream_handle); None clears it."""
+        if not hasattr(self, "_custom"):
+            self._custom = {}
+        if fn is None:
+            _chk(lib().omg_tend_set_custom_tendency(self.h, which, C.cast(None, CUSTOM_TEND_FN), None))
+            self._custom.pop(which, None)
+            return
+
+        def _cb(_ctx, tend, h, u, nall, nsize, k, t, stream):
+            try:
+                fn(tend, h, u, nall, nsize, k, t, stream)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._custom[which] = CUSTOM_TEND_FN(_cb)
+        _chk(lib().omg_tend_set_custom_tendency(self.h, which, self._custom[which], None))
+
     def clear_custom_tendencies(self):
         _chk(lib().omg_tend_clear_custom_tendencies(self.h))
 
@@ -742,6 +769,9 @@ class TimeStepper:
         _chk(lib().omg_stepper_get_time(self.h, C.byref(v)))
         return v.value
 
+    def change_time_step(self, dt: float):
+        _chk(lib().omg_stepper_change_time_step(self.h, C.c_double(dt)))
+
     def set_option(self, name: str, value: bool):
         """RungeKutta4: "FuseStageUpdates" (default on), "StoreStageTendencies" (default off)."""
         _chk(lib().omg_stepper_set_option(self.h, name.encode(), int(value)))
@@ -751,6 +781,12 @@ class TimeStepper:
             lib().omg_stepper_destroy(self.h)
         except Exception:
             pass
+
+
+def update_by_tend(out_ptr: int, in_ptr: int, tend_ptr: int, coeff: float, n_rows: int, k: int, stream_handle=None):
+    """out = in + coeff * tend on raw [n_rows][k] device arrays (TimeStepper::update*ByTend's kernel)."""
+    _chk(lib().omg_update_by_tend(C.c_void_p(out_ptr), C.c_void_p(in_ptr), C.c_void_p(tend_ptr), C.c_double(coeff),
+                                  n_rows, k, C.c_void_p(stream_handle) if stream_handle else None))
 
 
 def coeff_seconds(mult: float, dt: float) -> float:

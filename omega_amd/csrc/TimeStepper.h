@@ -61,6 +61,13 @@ class TimeStepper {
    /// hand the stage times to Tendencies::ModelTime (the reference passes a TimeInstant).
    R8 StartTime = 0.0;
    R8 simTime() const { return StartTime + (R8)NStepsDone * TimeStep; }
+   /// TimeStepper::changeTimeStep (TimeStepper.h:141-143): the model time reached so far is kept
+   void changeTimeStep(R8 NewTimeStepSeconds) {
+      OMEGA_REQUIRE(NewTimeStepSeconds > 0, "TimeStepper: time step must be positive");
+      StartTime  = simTime();
+      NStepsDone = 0;
+      TimeStep   = NewTimeStepSeconds;
+   }
 
  protected:
    /// end-of-step: halo exchange of the new level, then rotate (State->updateTimeLevels();

@@ -915,6 +915,25 @@ int omg_tend_use_manufactured_solution(omg_tend *t, const omg_mesh *m, double wa
                                     R8 Time, hipStream_t S) { Ms->velocityTendency(Tend, Time, S); };
    OMG_CATCH
 }
+int omg_tend_set_custom_tendency(omg_tend *t, int which, omg_custom_tend_fn fn, void *ctx) {
+   OMG_TRY
+   OMG_ARG(t && (which == 0 || which == 1));
+   Tendencies::CustomTendencyType F;
+   if (fn) {
+      const HorzMesh *M = t->T->Mesh;
+      const int NAll = which == 0 ? M->NCellsAll : M->NEdgesAll, NSize = which == 0 ? M->NCellsSize : M->NEdgesSize;
+      F = [fn, ctx, NAll, NSize](const Array2DReal &Tend, const OceanState *State, const AuxiliaryState *, int ThickLvl,
+                                 int VelLvl, R8 Time, hipStream_t S) {
+         Array2DReal H, U;
+         OMEGA_REQUIRE(State->getLayerThickness(H, ThickLvl) == 0 && State->getNormalVelocity(U, VelLvl) == 0,
+                       "custom tendency: bad time level");
+         OMEGA_REQUIRE(fn(ctx, Tend.Ptr, H.Ptr, U.Ptr, NAll, NSize, Tend.Ext[1], Time, (void *)S) == 0,
+                       "custom tendency callback reported an error");
+      };
+   }
+   (which == 0 ? t->T->CustomThicknessTend : t->T->CustomVelocityTend) = F;
+   OMG_CATCH
+}
 int omg_tend_clear_custom_tendencies(omg_tend *t) {
    OMG_TRY
    OMG_ARG(t);
@@ -1009,6 +1028,18 @@ int omg_stepper_do_step(omg_stepper *st, omg_state *s, void *stream) {
    OMG_TRY
    OMG_ARG(st && s);
    st->St->doStep(s->S.get(), (hipStream_t)stream);
+   OMG_CATCH
+}
+int omg_stepper_change_time_step(omg_stepper *st, double dt) {
+   OMG_TRY
+   OMG_ARG(st && dt > 0);
+   st->St->changeTimeStep(dt);
+   OMG_CATCH
+}
+int omg_update_by_tend(double *out, const double *in, const double *tend, double coeff, int n_rows, int k, void *stream) {
+   OMG_TRY
+   OMG_ARG(out && in && tend && n_rows >= 0 && k > 0);
+   launchUpdateByTend(n_rows, k, out, in, tend, coeff, (hipStream_t)stream);
    OMG_CATCH
 }
 int omg_stepper_set_start_time(omg_stepper *st, double seconds) {

@@ -583,6 +583,11 @@ static void fill0(double *a, size_t n) { memset(a, 0, n * sizeof(double)); }
 static const orc_manufactured *g_custom = NULL;
 static double g_time = 0.0, g_sim_time = 0.0;
 void orc_set_custom_tendency(const orc_manufactured *ms) { g_custom = ms; }
+/* DecayVelocityTendency of the reference's time-stepper test (O/test/timeStepping/TimeStepperTest.cpp:49-73):
+ * NormalVelTend(IEdge, K) -= Coeff * NormalVelEdge(IEdge, K) as the custom velocity tendency */
+static int g_decay_on = 0;
+static double g_decay_coeff = 0.5;
+void orc_set_decay_velocity_tendency(int On, double Coeff) { g_decay_on = On, g_decay_coeff = Coeff; }
 void orc_set_time(double t) { g_time = t; }
 void orc_set_sim_time(double t) { g_sim_time = t, g_time = t; }
 
@@ -665,6 +670,13 @@ void orc_tend_velocity_only(const orc_mesh *m, const orc_config *c, const orc_au
       orc_bottom_drag_on_edge(m, N, uTend, u, a->KineticEnergyCell, a->MeanLayerThickEdge, c->BottomDragCoeff);
    if (g_custom) /* CustomVelocityTend :416-419 */
       orc_manufactured_velocity_tend(m, g_custom, uTend, g_time);
+   if (g_decay_on) { /* CustomVelocityTend = DecayVelocityTendency, TimeStepperTest.cpp:66-72 */
+      const int K = m->NVertLayers;
+#pragma omp parallel for
+      for (int IEdge = 0; IEdge < N; ++IEdge)
+         for (int k = 0; k < K; ++k)
+            uTend[(size_t)IEdge * K + k] -= g_decay_coeff * u[(size_t)IEdge * K + k];
+   }
 }
 
 /* Tendencies::computeTracerTendenciesOnly, O/src/ocn/Tendencies.cpp:427-486 */

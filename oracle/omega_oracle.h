@@ -98,6 +98,8 @@ void orc_manufactured_velocity_tend(const orc_mesh *m, const orc_manufactured *m
  * that time per stage from orc_set_sim_time (RungeKutta4Stepper.cpp:87, RungeKutta2Stepper.cpp:44,58,
  * ForwardBackwardStepper.cpp:50,59,67). */
 void orc_set_custom_tendency(const orc_manufactured *ms);
+/* DecayVelocityTendency (O/test/timeStepping/TimeStepperTest.cpp:49-73) as the custom velocity tendency */
+void orc_set_decay_velocity_tendency(int On, double Coeff);
 void orc_set_time(double ElapsedSec);
 void orc_set_sim_time(double SimTimeSec);
 

@@ -296,6 +296,11 @@ class Oracle:
         self.L.orc_set_custom_tendency(C.byref(ms))
         return ms
 
+    def use_decay_velocity_tendency(self, coeff=None):
+        """The custom velocity tendency of the reference's TimeStepperTest (du/dt = -coeff u,
+        TimeStepperTest.cpp:49-73); process-wide switch, None turns it off."""
+        self.L.orc_set_decay_velocity_tendency(0 if coeff is None else 1, C.c_double(0.0 if coeff is None else coeff))
+
     def set_time(self, t: float):
         """model time (s since the reference time) seen by the custom tendencies in direct tendency calls"""
         self.L.orc_set_time(C.c_double(t))

@@ -33,6 +33,26 @@ def test_two_ranks_one_gpu(extra):
     assert all("OK" in o for o in outs)
 
 
+def test_halo_width_3_with_del4_bound_on_the_gpu():
+    """bench.py's former N > 1 setting (reference default HaloWidth 3 + del4): bounded, non-zero deviation from
+    the single-rank oracle (see tests/test_multirank_cpu.py)."""
+    from tests.test_multirank_cpu import HALO3_DEL4_BOUND
+    outs = run_ranks("gpu", 2, ["--nx", 24, "--ny", 24, "--rtol", HALO3_DEL4_BOUND], timeout=900)
+    assert all("OK" in o and "max deviation" in o for o in outs)
+
+
+@pytest.mark.parametrize("world,extra", [
+    (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6]),                 # overlapped
+    (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6, "--no-overlap"]),
+    (4, ["--halo-width", 4, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 6]),
+])
+def test_bench_setting_halo_width_4_with_del4_is_bit_exact(world, extra):
+    """What `bench.py --gpus N` runs: HaloWidth 4, every Default.yml term incl. del4, 6 tracers, RK4 with
+    stage-fused updates and (un)overlapped exchanges -- owned elements equal the single-rank oracle bit for bit."""
+    outs = run_ranks("gpu", world, extra, timeout=900)
+    assert all("OK" in o for o in outs)
+
+
 def test_generic_fallback_kernels_in_a_child_process():
     """Meshes whose EdgesOnEdge / EdgesOnCell lists are not in MPAS ring order take the generic kernels
     (FusedEdgeBody, FusedDel2CellBody, FusedDel2VertexBody, separate update sweeps).  No generated mesh

@@ -54,6 +54,12 @@ CASES = [
     ("ico4", 0, 0, 60, 2, {}),                                 # 2562 cells, 60 levels, T+S
     ("ico3pad8", 0, 0, 6, 1, {}),                              # same mesh stored with maxEdges = 8: pentagons
                                                                # fall outside the ring kernels' valences
+    # the DEFAULT wind interpolation (isotropic, kite-weighted: InterpCellToEdge, HorzOperators.h:161-180)
+    (16, 16, 30e3, 8, 2, {"WindForcingTendencyEnable": 1, "BottomDragTendencyEnable": 1, "BottomDragCoeff": 1.0e-3,
+                          "WindInterpIsotropic": 1}),
+    ("ico3", 0, 0, 6, 1, {"WindForcingTendencyEnable": 1, "WindInterpIsotropic": 1}),   # same, on the sphere
+    (20, 24, 30e3, 80, 37, {}),                                # BASELINE configs[4]: 80 levels, 37 BGC tracers
+    ("ico3", 0, 0, 80, 37, {}),                                # 37 tracers with the pentagon ring launches
 ]
 
 _SPHERES = {}

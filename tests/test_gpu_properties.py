@@ -20,12 +20,21 @@ from tests.problem import Problem
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def P():
+# bench.py's workloads "qu30" (BASELINE configs[3] on one GPU) and "orrs18to6_eighth" (the per-GPU share of
+# configs[4]: 37 BGC tracers; one tracer array = 11 GB)
+@pytest.fixture(scope="module", params=[("qu30", 680, 680, 30.0e3, 80, 6), ("orrs18to6_eighth", 680, 680, 6.0e3, 80, 37)],
+                ids=lambda p: p[0])
+def P(request):
+    import gc
     assert oa.device_count() > 0
     oa.device_init(0)
-    g = reorder_cells_morton(planar_hex(680, 680, 30.0e3))
-    return Problem(g, 80, 6, oracle=False)
+    _, nx, ny, dc, K, NT = request.param
+    g = reorder_cells_morton(planar_hex(nx, ny, dc))
+    prob = Problem(g, K, NT, oracle=False)
+    prob.dt = 600.0 * dc / 30.0e3   # Default.yml's 10 min at 30 km, scaled with the cell size
+    yield prob
+    del prob
+    gc.collect()
 
 
 def _sums(P, h_like, tr_like):
@@ -75,7 +84,7 @@ def test_tracer_tendency_is_linear_in_the_tracer(P):
 def test_rk4_step_conserves_volume_and_tracer_content(P):
     nc = P.mesh.NCellsOwned
     v0, c0 = _sums(P, P.h, P.tr * P.h[None])
-    st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    st = oa.TimeStepper("RungeKutta4", P.dt, P.tend, P.aux, P.mesh, None, P.tracers)
     st.do_step(P.state)
     oa.device_synchronize()
     h, _ = P.state.copy_to_host(0)
@@ -97,7 +106,7 @@ def test_repeated_evaluations_are_bitwise_deterministic(P):
     P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
     oa.device_synchronize()
     ref = [P.tend.get(i).copy() for i in range(3)]
-    for _ in range(30):
+    for _ in range(30 if P.NT <= 6 else 5):
         P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
     oa.device_synchronize()
     for i in range(3):
@@ -106,7 +115,7 @@ def test_repeated_evaluations_are_bitwise_deterministic(P):
     for _ in range(2):
         P.state.copy_to_device(P.h, P.u, 0)
         P.tracers.copy_to_device(P.tr, 0)
-        st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+        st = oa.TimeStepper("RungeKutta4", P.dt, P.tend, P.aux, P.mesh, None, P.tracers)
         for _ in range(3):
             st.do_step(P.state)
         oa.device_synchronize()
