@@ -160,6 +160,26 @@ int omg_mesh_get_array_i4(const omg_mesh *m, const char *name, int32_t *out, siz
 int omg_mesh_get_array_r8(const omg_mesh *m, const char *name, double *out, size_t n);
 int omg_mesh_set_fvertex(omg_mesh *m, const double *host_values /* [NVerticesSize] */);
 
+/* ---- HorzOperators (O/src/ocn/HorzOperators.h:9-187; constructors HorzOperators.cpp:7-28): the reference's
+ *      reusable operators as sweeps over elements [0, n) (n < 0: all local elements) x nvertlayers levels of raw
+ *      device arrays [NXxSize][nvertlayers]:
+ *        divergence        DivCell(i,k)   = -sum_j DvEdge*EdgeSignOnCell(i,j)*VecEdge(e_j,k)/AreaCell(i)        :13-33
+ *        gradient          GradEdge(e,k)  = (Scalar(c1,k) - Scalar(c0,k))/DcEdge(e)                             :47-60
+ *        curl              CurlVertex(v,k)= sum_j DcEdge*EdgeSignOnVertex(v,j)*VecEdge(e_j,k)/AreaTriangle(v)   :71-93
+ *        tangential_recon  ReconEdge(e,k) = sum_j WeightsOnEdge(e,j)*VecEdge(EdgesOnEdge(e,j),k)                :107-126
+ *        interp_cell_to_edge (1-D arrays) isotropic != 0: kite-area weighted over the cells of the edge's two
+ *                          vertices (:161-180), else the mean of its two cells (:153-159) ---- */
+int omg_horz_divergence(const omg_mesh *m, const double *vec_edge_dev, double *div_cell_dev, int nvertlayers, int n,
+                        void *stream);
+int omg_horz_gradient(const omg_mesh *m, const double *scalar_cell_dev, double *grad_edge_dev, int nvertlayers, int n,
+                      void *stream);
+int omg_horz_curl(const omg_mesh *m, const double *vec_edge_dev, double *curl_vertex_dev, int nvertlayers, int n,
+                  void *stream);
+int omg_horz_tangential_recon(const omg_mesh *m, const double *vec_edge_dev, double *recon_edge_dev, int nvertlayers,
+                              int n, void *stream);
+int omg_horz_interp_cell_to_edge(const omg_mesh *m, const double *array_cell_dev, double *array_edge_dev,
+                                 int isotropic, int n, void *stream);
+
 /* ---- options (O/configs/Default.yml:25-52; Tendencies::readTendConfig O/src/ocn/Tendencies.cpp:123-213;
  *      AuxiliaryState::readConfigOptions O/src/ocn/AuxiliaryState.cpp:259-308) ---- */
 typedef struct omg_tend_config {

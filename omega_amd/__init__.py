@@ -525,6 +525,43 @@ class HorzMesh:
             pass
 
 
+class HorzOperators:
+    """DivergenceOnCell / GradientOnEdge / CurlOnVertex / TangentialReconOnEdge / InterpCellToEdge
+    (HorzOperators.h:9-187) on host arrays staged through device buffers (test / tooling use; the
+    C entry points omg_horz_* take raw device pointers)."""
+
+    def __init__(self, mesh: HorzMesh):
+        self.mesh = mesh
+
+    def _run(self, fn, x: np.ndarray, rows_out: int, n: int, *extra):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        one_d = x.ndim == 1
+        k = 1 if one_d else x.shape[1]
+        din = DeviceBuffer(x)
+        dout = DeviceBuffer(np.zeros((rows_out,) if one_d else (rows_out, k)))
+        if one_d:
+            _chk(fn(self.mesh.h, C.c_void_p(din.ptr), C.c_void_p(dout.ptr), *extra, n, None))
+        else:
+            _chk(fn(self.mesh.h, C.c_void_p(din.ptr), C.c_void_p(dout.ptr), k, n, None))
+        device_synchronize()
+        return dout.to_host()
+
+    def divergence(self, vec_edge, n=-1):
+        return self._run(lib().omg_horz_divergence, vec_edge, self.mesh.NCellsSize, n)
+
+    def gradient(self, scalar_cell, n=-1):
+        return self._run(lib().omg_horz_gradient, scalar_cell, self.mesh.NEdgesSize, n)
+
+    def curl(self, vec_edge, n=-1):
+        return self._run(lib().omg_horz_curl, vec_edge, self.mesh.NVerticesSize, n)
+
+    def tangential_recon(self, vec_edge, n=-1):
+        return self._run(lib().omg_horz_tangential_recon, vec_edge, self.mesh.NEdgesSize, n)
+
+    def interp_cell_to_edge(self, array_cell, isotropic: bool, n=-1):
+        return self._run(lib().omg_horz_interp_cell_to_edge, array_cell, self.mesh.NEdgesSize, n, int(isotropic))
+
+
 def default_config(**over) -> TendConfig:
     c = TendConfig()
     lib().omg_tend_config_default(C.byref(c))

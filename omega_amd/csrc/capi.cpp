@@ -5,6 +5,7 @@
 #include "Decomp.h"
 #include "Halo.h"
 #include "HorzMesh.h"
+#include "HorzOperators.h"
 #include "OceanState.h"
 #include "Tendencies.h"
 #include "CustomTendencyTerms.h"
@@ -567,6 +568,28 @@ static void requireDevice(const HorzMesh *M) {
 }
 
 // ---------------------------------------------------------------- options
+#define OMG_HORZ_OP(NAME, LAUNCH, NALL)                                                                              \
+   int NAME(const omg_mesh *m, const double *in, double *out, int k, int n, void *stream) {                        \
+      OMG_TRY                                                                                                      \
+      OMG_ARG(m && in && out && k > 0);                                                                            \
+      OMEGA_REQUIRE(!m->M->HostOnly, #NAME ": needs a device mesh");                                               \
+      OMG_ARG(n <= m->M->NALL);                                                                                    \
+      LAUNCH(m->M->view(), n < 0 ? m->M->NALL : n, k, out, in, (hipStream_t)stream);                               \
+      OMG_CATCH                                                                                                    \
+   }
+OMG_HORZ_OP(omg_horz_divergence, launchDivergenceOnCell, NCellsAll)
+OMG_HORZ_OP(omg_horz_gradient, launchGradientOnEdge, NEdgesAll)
+OMG_HORZ_OP(omg_horz_curl, launchCurlOnVertex, NVerticesAll)
+OMG_HORZ_OP(omg_horz_tangential_recon, launchTangentialReconOnEdge, NEdgesAll)
+#undef OMG_HORZ_OP
+int omg_horz_interp_cell_to_edge(const omg_mesh *m, const double *cell, double *edge, int isotropic, int n, void *stream) {
+   OMG_TRY
+   OMG_ARG(m && cell && edge && n <= m->M->NEdgesAll);
+   OMEGA_REQUIRE(!m->M->HostOnly, "omg_horz_interp_cell_to_edge: needs a device mesh");
+   launchInterpCellToEdge(m->M->view(), n < 0 ? m->M->NEdgesAll : n, edge, cell, isotropic, (hipStream_t)stream);
+   OMG_CATCH
+}
+
 void omg_tend_config_default(omg_tend_config *c) {
    const TendParams P;
    c->ThicknessFluxTendencyEnable   = P.ThicknessFluxTendencyEnable;

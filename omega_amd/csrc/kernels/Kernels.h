@@ -120,6 +120,14 @@ void launchManufacturedThickness(int NCells, int K, Real *Tend, const Real *XCel
 void launchManufacturedVelocity(int NEdges, int K, Real *Tend, const Real *XEdge, const Real *YEdge, const Real *FEdge,
                                 const Real *AngleEdge, const ManufacturedParams &P, Real ElapsedSec, hipStream_t S);
 
+// ---- HorzOperators (HorzOperators.h:9-187): sweeps over elements [0, N) x K levels ----
+void launchDivergenceOnCell(const MeshView &M, int N, int K, Real *DivCell, const Real *VecEdge, hipStream_t S);
+void launchGradientOnEdge(const MeshView &M, int N, int K, Real *GradEdge, const Real *ScalarCell, hipStream_t S);
+void launchCurlOnVertex(const MeshView &M, int N, int K, Real *CurlVertex, const Real *VecEdge, hipStream_t S);
+void launchTangentialReconOnEdge(const MeshView &M, int N, int K, Real *ReconEdge, const Real *VecEdge, hipStream_t S);
+void launchInterpCellToEdge(const MeshView &M, int N, Real *ArrayEdge, const Real *ArrayCell, int Isotropic,
+                            hipStream_t S);
+
 // ---- TimeStepper update kernels (TimeStepper.cpp:378-524) ----
 void launchUpdateByTend(int NRows, int K, Real *X1, const Real *X2, const Real *Tend, Real Coeff, hipStream_t S);
 void launchUpdateTracersByTend(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *CurTr, const Real *H1,
