@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import omega_amd as oa  # noqa: E402
+oa.lib()   # load libomega_amd.so (and with it ROCm's own libamdhip64 / librccl) before anything imports torch
 from omega_amd.meshgen import (icosahedral_points, planar_hex, reorder_cells_blocked, reorder_cells_morton,  # noqa: E402
                                spherical_voronoi, synthetic_state)
 
@@ -85,9 +86,13 @@ def main():
                     help="N > 1: exchange halos after the producing stage instead of overlapped with its interior part")
     ap.add_argument("--no-fuse-stages", action="store_true",
                     help="RK4 with the separate update kernels instead of stage updates folded into the RHS kernels")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (production); gloo = host-staged rehearsal of the N>1 code path")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="rccl (= nccl) = RCCL send/recv over xGMI issued inside the library (production); "
+                         "gloo = host-staged rehearsal of the N>1 code path")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--halo-width", type=int, default=0,
+                    help="0 = 4 for N > 1 (partition-independent results with the del4 terms: two RHS evaluations per "
+                         "exchange consume 2 x 2 layers), 3 for N = 1; the reference default is 3")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,19 +104,21 @@ def main():
     N = world
 
     nx, ny, dc, K, NT, desc = WORKLOADS[args.workload]
-    dist = torch = None
+    dist = None
     stream = None
+    if args.backend == "nccl":
+        args.backend = "rccl"
     if N > 1:
+        # torch.distributed is the rendezvous / side channel only (gloo, CPU): it distributes the RCCL unique id and
+        # carries the timing reductions; the halo data path is RCCL inside libomega_amd.  torch never touches the GPU.
+        import datetime
         import torch
         import torch.distributed as dist
         if args.single_device:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
     oa.device_init(local_rank)
+    halo_width = args.halo_width if args.halo_width > 0 else (4 if N > 1 else 3)
 
     t0 = time.time()
     if args.workload.startswith("ico"):   # sphere: cells already numbered along a Morton curve in (lon, z)
@@ -125,7 +132,7 @@ def main():
     elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
     gm = oa.GlobalMesh(g)
-    decomp = oa.Decomp(gm, N, rank, 3)
+    decomp = oa.Decomp(gm, N, rank, halo_width)
     mesh = oa.HorzMesh(decomp, K)
     halo = oa.Halo(decomp) if N > 1 else None
     cell_id, edge_id = decomp.get_array("CellID"), decomp.get_array("EdgeID")
@@ -141,17 +148,16 @@ def main():
     tr = to_local(trg, cell_id, mesh.NCellsSize)
     del hg, ug, trg
 
-    if N > 1 and args.backend == "nccl":
-        tstream = torch.cuda.Stream()
-        stream = oa.Stream(handle=tstream.cuda_stream)
-        from omega_amd.transport import TorchTransport
-        transport = TorchTransport(halo, per_cell=K * (1 + NT), per_edge=K, device=f"cuda:{local_rank}", stream=tstream)
-    elif N > 1:  # gloo rehearsal: host-staged messages, default stream (torch's .cpu() orders on it)
-        stream = None
-        from omega_amd.transport import TorchTransport
-        transport = TorchTransport(halo, per_cell=K * (1 + NT), per_edge=K, device=f"cuda:{local_rank}", stream=None)
-    else:
-        stream = oa.Stream()
+    comm = None
+    stream = oa.Stream()
+    if N > 1 and args.backend == "rccl":
+        ident = [oa.RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = oa.RcclComm(ident[0], N, rank)     # collective: ncclCommInitRank
+        halo.use_rccl(comm)
+    elif N > 1:  # gloo rehearsal: host-staged messages (both ranks may share one GPU)
+        from omega_amd.transport import GlooStagedTransport
+        GlooStagedTransport(halo)
 
     cfg = oa.default_config()
     state = oa.OceanState(mesh, halo, K, 2)
@@ -172,7 +178,7 @@ def main():
     def allmax(x):
         if N == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -204,32 +210,32 @@ def main():
     sypd = t_rk4 = rk4_error = None
     overlap = N > 1 and not (args.no_overlap or args.no_fuse_stages or args.unfused)
     if nrk > 0:
-        # The RHS number above must survive a problem in the stepping part (the multi-GPU exchange path
-        # cannot be rehearsed on the one-GPU development boxes): a deterministic failure of the overlapped
-        # exchange falls back to the sequential one, a failure of that is reported in the JSON line.
-        for attempt in (0, 1):
-            try:
-                stepper = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
-                stepper.set_option("FuseStageUpdates", not args.no_fuse_stages)
-                stepper.set_option("OverlapHaloExchange", overlap)
-                stepper.do_step(state, stream=stream)  # warm-up (allocations, RCCL connections)
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(nrk):
-                    stepper.do_step(state, stream=stream)
-                barrier()
-                t_rk4 = allmax(time.perf_counter() - t1) / nrk
-                sypd = (args.dt / t_rk4) / 365.0
-                hh, _ = state.copy_to_host(0)
-                assert np.isfinite(hh[: mesh.NCellsOwned]).all(), "state went non-finite during the RK4 steps"
-                rk4_error = None
-                break
-            except Exception as exc:  # noqa: BLE001
-                rk4_error = f"{type(exc).__name__}: {exc}"
-                sypd = t_rk4 = None
-                if not overlap:
-                    break
-                overlap = False
+        if rank == 0:   # if a rank dies in the stepping part, the RHS measurement is at least in the log
+            print(f"[bench] RHS: {ms_per_step:.4f} ms/step, {value:.4e} cell-level-updates/s on {N} GPU(s); "
+                  f"RK4 ({'overlapped' if overlap else 'sequential'} exchanges) next", file=sys.stderr, flush=True)
+        # No retry and no fall-back: a failure of the (overlapped) exchange is reported and the run ends non-zero.
+        # RCCL work is never re-issued in a process whose exchange failed.
+        try:
+            stepper = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
+            stepper.set_option("FuseStageUpdates", not args.no_fuse_stages)
+            stepper.set_option("OverlapHaloExchange", overlap)
+            stepper.do_step(state, stream=stream)  # warm-up (allocations, RCCL connections)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(nrk):
+                stepper.do_step(state, stream=stream)
+            barrier()
+            t_rk4 = allmax(time.perf_counter() - t1) / nrk
+            sypd = (args.dt / t_rk4) / 365.0
+            hh, _ = state.copy_to_host(0)
+            if not np.isfinite(hh[: mesh.NCellsOwned]).all():
+                raise FloatingPointError("state went non-finite during the RK4 steps")
+        except Exception as exc:  # noqa: BLE001
+            rk4_error = f"rank {rank}: {type(exc).__name__}: {exc}"
+            sypd = t_rk4 = None
+            print(f"[bench] RK4 FAILED on {rk4_error}", file=sys.stderr, flush=True)
+            if N > 1 and rank != 0:
+                os._exit(3)   # the launcher tears the job down; peers must not wait for this rank
 
     # ------------------------------------------------ roofline of the dominant kernel (rank 0's view)
     roofline = None
@@ -239,20 +245,32 @@ def main():
         ach = algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels / (ms * 1e-3) / 1e9
         rhs_ms = sum(m for _, m in ktimes)
         rhs_ach = algorithmic_bytes_per_cell_level(NT) * local_cell_levels / (rhs_ms * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE on this same command, gfx950 correction applied; profiles/): only valid for the
-        # workload and partition they were collected on
+        # HBM bytes per launch of that kernel from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, gfx950 correction applied).  Only a file
+        # measured on exactly the kernel sources that run here (hash recorded in the file) and on this workload
+        # counts; otherwise traffic is null rather than stale.
         traffic = traffic_src = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_v7_bench_qu30_pmc.json")
-        if args.workload == "qu30" and N == 1 and not args.unfused and os.path.exists(pmc_file):
-            with open(pmc_file) as fh:
-                pmc = json.load(fh)
-            base = name.split("<")[0].split("+")[0]
-            cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and k.split("<")[0] == base]
-            # `..., true>` instantiations are the RK4 stage-fused variants; the RHS timed here is the plain one
-            plain = [k for k in cands if not k.endswith(", true>")] or cands
-            if plain:
-                traffic, traffic_src = pmc[plain[0]]["hbm_bytes_per_launch"], "profiles/r01_v7_bench_qu30_pmc.json"
+        if N == 1 and not args.unfused:
+            import glob
+            from tools.summarise_profile import kernel_source_sha
+            sha = kernel_source_sha()
+            for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+                with open(pmc_file) as fh:
+                    pmc = json.load(fh)
+                wl = "qu30"
+                pa = pmc.get("bench_args") or []
+                if "--workload" in pa:
+                    wl = pa[pa.index("--workload") + 1]
+                if pmc.get("kernel_source_sha") != sha or wl != args.workload:
+                    continue
+                base = name.split("<")[0].split("+")[0]
+                cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and k.split("<")[0] == base]
+                # `..., true>` instantiations are the RK4 stage-fused variants; the RHS timed here is the plain one
+                plain = [k for k in cands if not k.endswith(", true>")] or cands
+                if plain:
+                    traffic = pmc[plain[0]]["hbm_bytes_per_launch"]
+                    traffic_src = os.path.relpath(pmc_file, ROOT) + " (kernel_source_sha " + sha + ")"
+                    break
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src,
@@ -266,7 +284,7 @@ def main():
     # ------------------------------------------------ CPU baseline (rank 0, N = 1 only): the oracle
     cpu = None
     if N == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(K, NT, dc)
+        cpu = cpu_baseline(nx, ny, K, NT, dc, args.dt) if nx > 0 else None
 
     if rank == 0:
         out = {"metric": "tendency_cell_level_updates_per_sec", "value": value, "unit": "cell-level-updates/s",
@@ -275,7 +293,11 @@ def main():
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
-                          "partition": f"rcb{N}", "halo_width": 3, "mesh_order": "hilbert" if args.block < 0 else "morton" if args.block == 0 else f"blocked{args.block}",
+                          "partition": f"rcb{N}", "halo_width": halo_width,
+                          "halo_wire": "none (1 rank)" if N == 1 else
+                          ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
+                           "host-staged gloo (rehearsal)"),
+                          "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "hilbert" if args.block < 0 else "morton" if args.block == 0 else f"blocked{args.block}",
                           "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1)},
                "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
                        "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
@@ -289,12 +311,20 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(K, NT, dc):
-    """The CPU oracle (kind "port": restatement of the reference functors, OpenMP over elements)
-    timed on a bounded sample: a 1/16-size mesh of the same shape, same levels / tracers."""
+def cpu_baseline(nx, ny, K, NT, dc, dt):
+    """The CPU oracle (kind "port": restatement of the reference functors with the reference's launch structure,
+    OpenMP over elements, built -O3 -march=native on this host) timed on the SAME mesh and state as the GPU run:
+    a few RHS evaluations and one RK4 step (bounded to about 20-30 s of CPU work)."""
     from oracle import oracle as O
-    nxs = nys = 170
+    O.use_native_build()
+    budget_cells = 500_000 * 80 * (8 + 2 * 6)      # about the QU30 workload: larger ones are sampled
+    scale = 1
+    while (nx // scale) * (ny // scale) * K * (8 + 2 * NT) > budget_cells:
+        scale *= 2
+    nxs, nys = nx // scale, ny // scale
     gs = planar_hex(nxs, nys, dc)
+    if scale == 1:
+        gs = reorder_cells_morton(gs)
     M = O.Mesh.single_rank(gs, K)
     hs, us, trs = synthetic_state(gs, K, NT)
 
@@ -303,39 +333,31 @@ def cpu_baseline(K, NT, dc):
         out[..., :-1, :] = a
         return out
     hs, us, trs = pad(hs), pad(us), pad(trs)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))  # a one-GPU box's CPU share is 16 cores
+    cores = O.default_threads()
     O.lib().orc_set_num_threads(cores)
     orc = O.Oracle(M, NT)
-    orc.compute_all_tendencies(hs, us, trs)  # warm-up
+    orc.compute_all_tendencies(hs, us, trs)  # warm-up (first touch of every aux array)
     n, t0 = 0, time.perf_counter()
     while True:
         orc.compute_all_tendencies(hs, us, trs)
         n += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or n >= 50:
+        if el > 10.0 or n >= 20:
             break
     v = gs["nCells"] * K * n / el
-    # SYPD of the CPU path: RK4 steps of the oracle on the same sample, scaled by the cell ratio
     st = orc.make_state(hs, us, trs)
-    orc.step("rk4", st, 600.0)  # warm-up
-    nst, t1 = 0, time.perf_counter()
-    while True:
-        orc.step("rk4", st, 600.0, sim_time=600.0 * (nst + 1))
-        nst += 1
-        el2 = time.perf_counter() - t1
-        if el2 > 5.0 or nst >= 10:
-            break
-    ratio = WORKLOADS["qu30"][0] * WORKLOADS["qu30"][1] / gs["nCells"]
-    sypd_cpu = (600.0 / (el2 / nst * ratio)) / 365.0
-    return {"value": v, "unit": "cell-level-updates/s", "cores": cores, "kind": "port",
-            "sypd": sypd_cpu, "rk4_steps": nst,
-            "sample": f"{n} RHS evaluations and {nst} RK4 steps of a {nxs}x{nys}-cell ({gs['nCells']} cells = 1/16 of the "
-                      f"workload) x {K}L x {NT} tracers mesh, reference launch structure (23 passes), OpenMP threads = "
-                      f"cores; sypd = dt 600 s / (sample step time x 16)"}
+    t1 = time.perf_counter()
+    orc.step("rk4", st, dt)
+    el2 = time.perf_counter() - t1
+    ratio = (nx * ny) / gs["nCells"]
+    sypd_cpu = (dt / (el2 * ratio)) / 365.0
+    frac = "the full workload mesh" if scale == 1 else f"a 1/{scale * scale}-size mesh of the same shape"
+    return {"value": v, "unit": "cell-level-updates/s", "cores": cores,
+            "kind": "port" if scale == 1 else f"port, 1/{scale * scale} sample", "sypd": sypd_cpu, "rk4_steps": 1,
+            "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp (oracle/Makefile: native)",
+            "sample": f"{n} RHS evaluations and 1 RK4 step on {frac} ({nxs}x{nys} = {gs['nCells']} cells x {K}L x "
+                      f"{NT} tracers), reference launch structure (23 passes), OpenMP threads = cores"
+                      + ("" if scale == 1 else f"; sypd scaled by the cell ratio {ratio:.0f}")}
 
 
 if __name__ == "__main__":

@@ -146,8 +146,26 @@ int omg_halo_list_size(const omg_halo *h, int i, int elem, int recv, int *n);
 int omg_halo_get_list(const omg_halo *h, int i, int elem, int recv, int32_t *out);
 int omg_halo_required_bytes(const omg_halo *h, int i, size_t per_cell, size_t per_edge, size_t per_vertex,
                             size_t *bytes);
-int omg_halo_set_buffers(omg_halo *h, int i, void *send_dev, void *recv_dev, size_t bytes);
+/* a caller-supplied wire (test rigs: messages staged through the host over gloo / MPI).  The pointers handed to
+ * fn are slices of the Halo's own contiguous send / receive buffers in device memory. */
 int omg_halo_set_transport(omg_halo *h, omg_transport_fn fn, void *ctx);
+/* The production wire: RCCL send / recv over xGMI issued inside the library on the exchange's HIP stream
+ * (ncclGroupStart, ncclRecv + ncclSend per neighbour, ncclGroupEnd) -- what the MPI_Irecv / MPI_Isend / MPI_Test
+ * sequence of O/src/base/Halo.h:851-907, Halo.cpp:607-757 becomes.  One process per GPU, device selected with
+ * omg_device_init first.  Rank 0 calls omg_rccl_get_unique_id and distributes the OMG_RCCL_ID_BYTES bytes by any side
+ * channel; omg_rccl_create is collective over all nranks processes (ncclCommInitRank). */
+enum { OMG_RCCL_ID_BYTES = 128 };
+typedef struct omg_rccl omg_rccl;
+int omg_rccl_get_unique_id(char *id /* [OMG_RCCL_ID_BYTES] */);
+int omg_rccl_create(const char *id, int nranks, int rank, omg_rccl **out);
+int omg_rccl_destroy(omg_rccl *c);
+/* what RCCL itself reports: communicator size, this rank, library version code, grouped exchanges issued so far */
+int omg_rccl_info(const omg_rccl *c, int *nranks, int *rank, int *version, int64_t *exchanges);
+/* one grouped exchange on raw device buffers (same argument meaning as omg_transport_fn; byte counts multiples of 8) */
+int omg_rccl_exchange(omg_rccl *c, int n, const int *peers, void *const *send_ptrs, const size_t *send_bytes,
+                      void *const *recv_ptrs, const size_t *recv_bytes, void *stream);
+/* route this Halo's exchanges through the communicator (which must outlive the Halo's exchanges) */
+int omg_halo_use_rccl(omg_halo *h, omg_rccl *c);
 /* Halo::exchangeFullArrayHalo on a raw device array [nt][rows_size][k] (nt = 1 for 2-D) */
 int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int elem, void *stream);
 

@@ -396,6 +396,42 @@ class Decomp:
             pass
 
 
+class RcclComm:
+    """RCCL communicator owned by the library (omega_amd/csrc/Rccl.cpp).  `unique_id()` on rank 0, distribute the
+    128 bytes by any side channel, then every rank constructs RcclComm(id, nranks, rank) after device_init."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(RcclComm.ID_BYTES)
+        _chk(lib().omg_rccl_get_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int):
+        assert len(unique_id) == RcclComm.ID_BYTES
+        h = C.c_void_p()
+        _chk(lib().omg_rccl_create(C.create_string_buffer(unique_id, RcclComm.ID_BYTES), nranks, rank, C.byref(h)))
+        self.h = h
+
+    def info(self) -> dict:
+        n, r, v, e = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        _chk(lib().omg_rccl_info(self.h, C.byref(n), C.byref(r), C.byref(v), C.byref(e)))
+        return {"nranks": n.value, "rank": r.value, "version": v.value, "exchanges": e.value}
+
+    def exchange(self, peers, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream=None):
+        n = len(peers)
+        _chk(lib().omg_rccl_exchange(self.h, n, (C.c_int * n)(*peers), (C.c_void_p * n)(*send_ptrs),
+                                     (C.c_size_t * n)(*send_bytes), (C.c_void_p * n)(*recv_ptrs),
+                                     (C.c_size_t * n)(*recv_bytes), _sh(stream)))
+
+    def __del__(self):
+        try:
+            lib().omg_rccl_destroy(self.h)
+        except Exception:
+            pass
+
+
 class Halo:
     def __init__(self, decomp: Decomp):
         self.decomp = decomp
@@ -428,8 +464,10 @@ class Halo:
         _chk(lib().omg_halo_required_bytes(self.h, i, C.c_size_t(per_cell), C.c_size_t(per_edge), C.c_size_t(per_vertex), C.byref(b)))
         return b.value
 
-    def set_buffers(self, i: int, send_ptr: int, recv_ptr: int, nbytes: int):
-        _chk(lib().omg_halo_set_buffers(self.h, i, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_size_t(nbytes)))
+    def use_rccl(self, comm: "RcclComm"):
+        """Route the exchanges through RCCL send / recv issued inside the library (production wire)."""
+        _chk(lib().omg_halo_use_rccl(self.h, comm.h))
+        self._comm = comm
 
     def set_transport(self, fn):
         """fn(tasks, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream_handle) -> int"""

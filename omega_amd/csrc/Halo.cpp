@@ -1,5 +1,6 @@
 // Halo.cpp -- see Halo.h.
 #include "Halo.h"
+#include "Rccl.h"
 #include "kernels/Kernels.h"
 
 #include <algorithm>
@@ -69,42 +70,18 @@ Halo::Halo(const std::string &, const Decomp *D) {
                SendLists[Kd][N].push_back((*Kinds[Kd].LocOf)[IDs[I]]);
       }
    }
-   SendBuf.assign(NNghbr, nullptr);
-   RecvBuf.assign(NNghbr, nullptr);
-   BufBytes.assign(NNghbr, 0);
-   OwnedSend.resize(NNghbr);
-   OwnedRecv.resize(NNghbr);
-   External.assign(NNghbr, 0);
+   SendPtrs.assign(NNghbr, nullptr);
+   RecvPtrs.assign(NNghbr, nullptr);
 }
 
 Halo::~Halo() {}
 
-void Halo::ensureDevice() {
-   if (DeviceReady)
-      return;
-   for (int Kd = 0; Kd < 3; ++Kd) {
-      SendListsD[Kd].resize(NNghbr);
-      RecvListsD[Kd].resize(NNghbr);
-      for (int N = 0; N < NNghbr; ++N) {
-         auto Up = [](const std::vector<I4> &V, const char *Nm) {
-            Array1DI4 A(Nm, (int)std::max<size_t>(V.size(), 1));
-            if (!V.empty())
-               copyToDevice(A.Ptr, V.data(), V.size() * sizeof(I4));
-            return A;
-         };
-         SendListsD[Kd][N] = Up(SendLists[Kd][N], "HaloSendList");
-         RecvListsD[Kd][N] = Up(RecvLists[Kd][N], "HaloRecvList");
-      }
-   }
-   DeviceReady = true;
-}
-
-void Halo::setBuffers(int N, void *SendPtr, void *RecvPtr, size_t Bytes) {
-   OMEGA_REQUIRE(N >= 0 && N < NNghbr, "Halo::setBuffers: neighbour index out of range");
-   SendBuf[N]  = SendPtr;
-   RecvBuf[N]  = RecvPtr;
-   BufBytes[N] = Bytes;
-   External[N] = 1;
+void Halo::useRccl(RcclComm *Comm) {
+   OMEGA_REQUIRE(Comm != nullptr, "Halo::useRccl: no communicator");
+   OMEGA_REQUIRE(Comm->Rank == MyTask, "Halo::useRccl: the communicator's rank is not this Halo's task");
+   for (I4 T : NeighborList)
+      OMEGA_REQUIRE(T < Comm->NRanks, "Halo::useRccl: a neighbour task is outside the communicator");
+   setTransport(&RcclComm::transport, Comm);
 }
 
 size_t Halo::requiredBytes(int N, size_t TC, size_t TE, size_t TV) const {
@@ -113,61 +90,84 @@ size_t Halo::requiredBytes(int N, size_t TC, size_t TE, size_t TV) const {
    return std::max(S, R) * sizeof(Real);
 }
 
-void Halo::ensureBuffers(const std::vector<size_t> &Need) {
-   for (int N = 0; N < NNghbr; ++N) {
-      if (Need[N] <= BufBytes[N])
-         continue;
-      OMEGA_REQUIRE(!External[N], "Halo: caller-owned exchange buffer too small for this exchange");
-      HIP_CHECK(hipDeviceSynchronize()); // growing: nothing may still use the old buffers
-      OwnedSend[N] = std::make_shared<DeviceBuffer>(Need[N]);
-      OwnedRecv[N] = std::make_shared<DeviceBuffer>(Need[N]);
-      SendBuf[N]   = OwnedSend[N]->Ptr;
-      RecvBuf[N]   = OwnedRecv[N]->Ptr;
-      BufBytes[N]  = Need[N];
+void Halo::ensureBuffers(size_t SendBytes, size_t RecvBytes) {
+   const bool GrowS = !SendBuf || SendBuf->Bytes < SendBytes, GrowR = !RecvBuf || RecvBuf->Bytes < RecvBytes;
+   if (!GrowS && !GrowR)
+      return;
+   HIP_CHECK(hipDeviceSynchronize()); // growing: nothing may still use the old buffers
+   if (GrowS)
+      SendBuf = std::make_shared<DeviceBuffer>(SendBytes);
+   if (GrowR)
+      RecvBuf = std::make_shared<DeviceBuffer>(RecvBytes);
+}
+
+const Halo::Plan &Halo::planFor(const std::vector<Piece> &Pieces) {
+   std::vector<int> Key;
+   for (const Piece &P : Pieces) {
+      Key.push_back((int)P.Elem), Key.push_back(P.NT), Key.push_back(P.RowsSize), Key.push_back(P.K);
+      OMEGA_REQUIRE(P.K == Pieces[0].K, "Halo: arrays exchanged together must have the same number of levels");
    }
+   auto It = Plans.find(Key);
+   if (It != Plans.end())
+      return It->second;
+   Plan Pl;
+   Pl.K = Pieces[0].K;
+   Pl.SendOff.assign(NNghbr, 0), Pl.RecvOff.assign(NNghbr, 0);
+   Pl.SendBytes.assign(NNghbr, 0), Pl.RecvBytes.assign(NNghbr, 0);
+   const size_t RowBytes = (size_t)Pl.K * sizeof(Real);
+   auto Build            = [&](const std::vector<std::vector<I4>> *Lists, std::vector<size_t> &Off,
+                    std::vector<size_t> &Bytes, const char *Nm, size_t &NRows) {
+      std::vector<I4> Jobs;
+      for (int N = 0; N < NNghbr; ++N) {
+         Off[N] = Jobs.size() / 2 * RowBytes;
+         for (size_t Ip = 0; Ip < Pieces.size(); ++Ip) {
+            const Piece &P            = Pieces[Ip];
+            const std::vector<I4> &L = Lists[P.Elem][N];
+            for (int T = 0; T < P.NT; ++T)
+               for (I4 Row : L) {
+                  const size_t Plane = (size_t)T * P.RowsSize + (size_t)Row;
+                  OMEGA_REQUIRE(Plane < ((size_t)1 << 31), "Halo: array too large for the 32-bit job table");
+                  Jobs.push_back((I4)Ip), Jobs.push_back((I4)Plane);
+               }
+         }
+         Bytes[N] = Jobs.size() / 2 * RowBytes - Off[N];
+      }
+      NRows = Jobs.size() / 2;
+      Array1DI4 D(Nm, (int)std::max<size_t>(Jobs.size(), 2));
+      if (!Jobs.empty())
+         copyToDevice(D.Ptr, Jobs.data(), Jobs.size() * sizeof(I4));
+      return D;
+   };
+   Pl.SendJobs = Build(SendLists, Pl.SendOff, Pl.SendBytes, "HaloSendJobs", Pl.NSendRows);
+   Pl.RecvJobs = Build(RecvLists, Pl.RecvOff, Pl.RecvBytes, "HaloRecvJobs", Pl.NRecvRows);
+   return Plans.emplace(Key, std::move(Pl)).first->second;
 }
 
 I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
    if (NNghbr == 0)
       return 0;
    OMEGA_REQUIRE(Transport != nullptr, "Halo: no transport set for a multi-rank exchange");
-   ensureDevice();
-   std::vector<size_t> SendBytes(NNghbr, 0), RecvBytes(NNghbr, 0), Need(NNghbr, 0);
+   OMEGA_REQUIRE(!Pieces.empty() && Pieces.size() <= (size_t)HaloMaxPieces, "Halo: too many arrays in one exchange");
+   const Plan &Pl        = planFor(Pieces);
+   const size_t RowBytes = (size_t)Pl.K * sizeof(Real);
+   ensureBuffers(Pl.NSendRows * RowBytes, Pl.NRecvRows * RowBytes);
+   HaloBases B{};
+   for (size_t I = 0; I < Pieces.size(); ++I)
+      B.P[I] = Pieces[I].Ptr;
    for (int N = 0; N < NNghbr; ++N) {
-      for (const Piece &P : Pieces) {
-         SendBytes[N] += SendLists[P.Elem][N].size() * (size_t)P.NT * P.K * sizeof(Real);
-         RecvBytes[N] += RecvLists[P.Elem][N].size() * (size_t)P.NT * P.K * sizeof(Real);
-      }
-      Need[N] = std::max(SendBytes[N], RecvBytes[N]);
+      SendPtrs[N] = static_cast<char *>(SendBuf->Ptr) + Pl.SendOff[N];
+      RecvPtrs[N] = static_cast<char *>(RecvBuf->Ptr) + Pl.RecvOff[N];
    }
-   ensureBuffers(Need);
-   // pack (Halo.h:324-414)
-   for (int N = 0; N < NNghbr; ++N) {
-      size_t Off = 0;
-      for (const Piece &P : Pieces) {
-         const int NList = (int)SendLists[P.Elem][N].size();
-         launchHaloPack(reinterpret_cast<Real *>(static_cast<char *>(SendBuf[N]) + Off), P.Ptr,
-                        SendListsD[P.Elem][N].Ptr, NList, P.NT, P.RowsSize, P.K, S);
-         Off += (size_t)NList * P.NT * P.K * sizeof(Real);
-      }
-   }
-   const int Err = Transport(TransportCtx, NNghbr, NeighborList.data(), SendBuf.data(), SendBytes.data(),
-                             RecvBuf.data(), RecvBytes.data(), (void *)S);
+   // pack: one launch for every neighbour and array (Halo.h:324-414)
+   launchHaloPackAll(static_cast<Real *>(SendBuf->Ptr), B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, S);
+   const int Err = Transport(TransportCtx, NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
+                             RecvPtrs.data(), Pl.RecvBytes.data(), (void *)S);
    if (Err != 0)
       return -1;
-   // unpack (Halo.h:566-653)
-   for (int N = 0; N < NNghbr; ++N) {
-      size_t Off = 0;
-      for (const Piece &P : Pieces) {
-         const int NList = (int)RecvLists[P.Elem][N].size();
-         launchHaloUnpack(P.Ptr, reinterpret_cast<const Real *>(static_cast<char *>(RecvBuf[N]) + Off),
-                          RecvListsD[P.Elem][N].Ptr, NList, P.NT, P.RowsSize, P.K, S);
-         Off += (size_t)NList * P.NT * P.K * sizeof(Real);
-      }
-   }
+   // unpack: one launch (Halo.h:566-653)
+   launchHaloUnpackAll(B, static_cast<const Real *>(RecvBuf->Ptr), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, S);
    return 0;
 }
-
 I4 Halo::exchangeFullArrayHalo(const Array2DReal &A, MeshElement E, hipStream_t S) {
    return exchangePieces({Piece{A.Ptr, E, 1, A.Ext[0], A.Ext[1]}}, S);
 }

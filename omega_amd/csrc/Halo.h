@@ -8,18 +8,21 @@
 // packed as Buf[(T*NList + I)*K + k] (Halo.h:344-351, 390-397).
 //
 // MI355X-first design: lists are derived locally (every rank can derive any rank's
-// numbering, Decomp.h), packing/unpacking are HIP kernels on the caller's stream, and the
-// wire is a pluggable transport invoked in stream order -- in production RCCL send/recv
-// over xGMI issued through torch.distributed (backend "nccl" = RCCL) on the same HIP
-// stream; no host polling, no device-wide fences (the reference fences the whole device
-// and polls MPI_Test, Halo.cpp:703-757, Halo.h:851-907).  exchangeState() ships h, u and
-// tracers of one exchange point as ONE message per neighbour (the reference makes three
-// rounds).
+// numbering, Decomp.h); ONE pack kernel gathers every row that travels -- all neighbours, all
+// arrays of the exchange point -- into one contiguous device buffer through a device-resident
+// job table (per exchange signature: which array, which row), the wire is a pluggable transport
+// invoked in stream order -- in production RcclComm (Rccl.h): grouped ncclSend / ncclRecv over
+// xGMI issued from C++ on the same HIP stream -- and ONE unpack kernel scatters the received
+// rows; no host polling, no device-wide fences (the reference fences the whole device and polls
+// MPI_Test, Halo.cpp:703-757, Halo.h:851-907).  exchangeState() ships h, u and tracers of one
+// exchange point as ONE message per neighbour (the reference makes three rounds).
 #ifndef OMEGA_AMD_HALO_H
 #define OMEGA_AMD_HALO_H
 
 #include "Base.h"
 #include "Decomp.h"
+
+#include <map>
 
 namespace OMEGA {
 
@@ -45,8 +48,8 @@ class Halo {
       Transport    = Fn;
       TransportCtx = Ctx;
    }
-   /// Use caller-owned device buffers (e.g. torch tensors registered with RCCL).
-   void setBuffers(int INghbr, void *SendPtr, void *RecvPtr, size_t Bytes);
+   /// production wire: grouped RCCL send / recv on the exchange's stream (the communicator outlives the Halo)
+   void useRccl(class RcclComm *Comm);
    /// Bytes needed per neighbour for exchanging arrays of `TotSizeCell`, `TotSizeEdge`,
    /// `TotSizeVertex` values per element in one message.
    size_t requiredBytes(int INghbr, size_t TotSizeCell, size_t TotSizeEdge, size_t TotSizeVertex) const;
@@ -62,18 +65,26 @@ class Halo {
       MeshElement Elem;
       int NT, RowsSize, K;
    };
+   /// Everything about an exchange that does not depend on the array pointers: the job tables of the pack and
+   /// the unpack kernel (one job = one row of K values: which piece, which row of its [NT*RowsSize][K] plane
+   /// stack; job j owns buffer row j) and the per-neighbour message extents inside the contiguous buffers.
+   /// Message layout per neighbour = the reference's, piece after piece: Buf[(T*NList + I)*K + k]
+   /// (Halo.h:344-351, 390-397).
+   struct Plan {
+      int K = 0;
+      size_t NSendRows = 0, NRecvRows = 0;
+      Array1DI4 SendJobs, RecvJobs; ///< [NRows][2] = (piece, row)
+      std::vector<size_t> SendOff, RecvOff, SendBytes, RecvBytes; ///< per neighbour, bytes
+   };
+   const Plan &planFor(const std::vector<Piece> &Pieces);
    I4 exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S);
-   void ensureDevice();
-   void ensureBuffers(const std::vector<size_t> &Need);
+   void ensureBuffers(size_t SendBytes, size_t RecvBytes);
 
    HaloTransportFn Transport = nullptr;
    void *TransportCtx        = nullptr;
-   bool DeviceReady          = false;
-   std::vector<Array1DI4> SendListsD[3], RecvListsD[3];
-   std::vector<void *> SendBuf, RecvBuf;
-   std::vector<size_t> BufBytes;
-   std::vector<std::shared_ptr<DeviceBuffer>> OwnedSend, OwnedRecv;
-   std::vector<char> External;
+   std::map<std::vector<int>, Plan> Plans; ///< keyed by (Elem, NT, RowsSize, K) of every piece
+   std::shared_ptr<DeviceBuffer> SendBuf, RecvBuf;
+   std::vector<void *> SendPtrs, RecvPtrs;
 };
 
 } // namespace OMEGA

@@ -34,6 +34,8 @@ struct Reader {
    I8 offset() { return Version == 1 ? (I8)be(4) : (I8)be(8); }   ///< OFFSET: 32 bit in CDF-1
    std::string name() {
       const I8 N = nonNeg();
+      if (N < 0 || N > 4096) // NC_MAX_NAME is 256: anything longer is a corrupt header, not a name to allocate
+         OMEGA_ABORT("NcFile: implausible name length in the header of " + Path);
       std::string S((size_t)N, '\0');
       bytes(S.data(), (size_t)N);
       skip((4 - N % 4) % 4);
@@ -65,6 +67,8 @@ void skipAttributes(Reader &R) {
       R.name();
       const int T   = (int)R.i4();
       const I8 Cnt  = R.nonNeg();
+      if (Cnt < 0 || Cnt > ((I8)1 << 40))
+         OMEGA_ABORT("NcFile: implausible attribute length in the header of " + R.Path);
       const I8 Size = Cnt * typeSize(T);
       R.skip(Size + (4 - Size % 4) % 4);
    }
@@ -280,7 +284,17 @@ const R8 *MeshFile::real(const std::string &Mpas, I8 Expect, bool Required) {
    return A.data();
 }
 
-MeshFile::MeshFile(const std::string &Path) : Nc(Path) {
+MeshFile::MeshFile(const std::string &Path) : Nc(Path) {}
+
+const GlobalMeshDesc &MeshFile::desc() {
+   if (!MeshLoaded) {
+      loadMesh();
+      MeshLoaded = true;
+   }
+   return Desc;
+}
+
+void MeshFile::loadMesh() {
    GlobalMeshDesc &D = Desc;
    D.NCells       = (I4)dimEither(Nc, "NCells", "nCells");
    D.NEdges       = (I4)dimEither(Nc, "NEdges", "nEdges");
@@ -300,19 +314,29 @@ MeshFile::MeshFile(const std::string &Path) : Nc(Path) {
    if (Nc.hasVar("nEdgesOnCell") || Nc.hasVar("NEdgesOnCell")) {
       std::vector<I4> N;
       Nc.read(Nc.hasVar("NEdgesOnCell") ? "NEdgesOnCell" : "nEdgesOnCell", N);
+      OMEGA_REQUIRE((I8)N.size() == NC, "MeshFile: nEdgesOnCell has the wrong length");
+      for (I8 C = 0; C < NC; ++C)
+         if (N[(size_t)C] < 0 || N[(size_t)C] > ME)
+            OMEGA_ABORT("MeshFile: nEdgesOnCell(" + std::to_string(C) + ") = " + std::to_string(N[(size_t)C]) +
+                        " is outside [0, maxEdges]");
       for (const char *Nm : {"cellsOnCell", "edgesOnCell", "verticesOnCell"}) {
          std::vector<I4> &A = IntArrays[Nm];
          for (I8 C = 0; C < NC; ++C)
             for (I8 J = N[(size_t)C]; J < ME; ++J)
                A[(size_t)(C * ME + J)] = -1;
       }
-      if (Nc.hasVar("nEdgesOnEdge") || Nc.hasVar("NEdgesOnEdge")) {
-         std::vector<I4> Ne;
-         Nc.read(Nc.hasVar("NEdgesOnEdge") ? "NEdgesOnEdge" : "nEdgesOnEdge", Ne);
-         std::vector<I4> &A = IntArrays["edgesOnEdge"];
-         for (I8 E = 0; E < NE; ++E)
-            for (I8 J = Ne[(size_t)E]; J < 2 * ME; ++J)
-               A[(size_t)(E * 2 * ME + J)] = -1;
+   }
+   if (Nc.hasVar("nEdgesOnEdge") || Nc.hasVar("NEdgesOnEdge")) {
+      std::vector<I4> Ne;
+      Nc.read(Nc.hasVar("NEdgesOnEdge") ? "NEdgesOnEdge" : "nEdgesOnEdge", Ne);
+      OMEGA_REQUIRE((I8)Ne.size() == NE, "MeshFile: nEdgesOnEdge has the wrong length");
+      std::vector<I4> &A = IntArrays["edgesOnEdge"];
+      for (I8 E = 0; E < NE; ++E) {
+         if (Ne[(size_t)E] < 0 || Ne[(size_t)E] > 2 * ME)
+            OMEGA_ABORT("MeshFile: nEdgesOnEdge(" + std::to_string(E) + ") = " + std::to_string(Ne[(size_t)E]) +
+                        " is outside [0, 2*maxEdges]");
+         for (I8 J = Ne[(size_t)E]; J < 2 * ME; ++J)
+            A[(size_t)(E * 2 * ME + J)] = -1;
       }
    }
    // geometry (HorzMesh.cpp:424-523)

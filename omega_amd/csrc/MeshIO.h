@@ -60,13 +60,17 @@ class NcFile {
 /// An MPAS mesh file as the global mesh the decomposition starts from.
 class MeshFile {
  public:
+   /// opens the file and parses its header; the mesh arrays are read on the first desc() call, so a file that
+   /// only holds an initial state / forcing can be opened and read through file().read()
    explicit MeshFile(const std::string &Path);
-   const GlobalMeshDesc &desc() const { return Desc; }
+   const GlobalMeshDesc &desc();
    const NcFile &file() const { return Nc; }
 
  private:
    NcFile Nc;
    GlobalMeshDesc Desc;
+   bool MeshLoaded = false;
+   void loadMesh();
    std::map<std::string, std::vector<I4>> IntArrays;
    std::map<std::string, std::vector<R8>> RealArrays;
    const I4 *conn(const std::string &OmegaName, const std::string &MpasName, I8 Expect);

@@ -10,6 +10,7 @@
 #include "Tendencies.h"
 #include "CustomTendencyTerms.h"
 #include "MeshIO.h"
+#include "Rccl.h"
 #include "TimeStepper.h"
 
 #include <cstring>
@@ -23,6 +24,9 @@ struct omg_decomp {
 };
 struct omg_halo {
    std::unique_ptr<Halo> H;
+};
+struct omg_rccl {
+   std::unique_ptr<RcclComm> C;
 };
 struct omg_mesh {
    std::unique_ptr<HorzMesh> M;
@@ -434,10 +438,54 @@ int omg_halo_required_bytes(const omg_halo *h, int i, size_t pc, size_t pe, size
    *bytes = h->H->requiredBytes(i, pc, pe, pv);
    OMG_CATCH
 }
-int omg_halo_set_buffers(omg_halo *h, int i, void *send_dev, void *recv_dev, size_t bytes) {
+int omg_rccl_get_unique_id(char *id) {
    OMG_TRY
-   OMG_ARG(h);
-   h->H->setBuffers(i, send_dev, recv_dev, bytes);
+   OMG_ARG(id);
+   RcclComm::getUniqueId(id);
+   OMG_CATCH
+}
+int omg_rccl_create(const char *id, int nranks, int rank, omg_rccl **out) {
+   OMG_TRY
+   OMG_ARG(id && out);
+   auto *R = new omg_rccl;
+   try {
+      R->C.reset(new RcclComm(id, nranks, rank));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_rccl_destroy(omg_rccl *c) {
+   delete c;
+   return 0;
+}
+int omg_rccl_info(const omg_rccl *c, int *nranks, int *rank, int *version, int64_t *exchanges) {
+   OMG_TRY
+   OMG_ARG(c);
+   if (nranks)
+      *nranks = c->C->NRanks;
+   if (rank)
+      *rank = c->C->Rank;
+   if (version)
+      *version = c->C->Version;
+   if (exchanges)
+      *exchanges = c->C->NExchanges;
+   OMG_CATCH
+}
+int omg_rccl_exchange(omg_rccl *c, int n, const int *peers, void *const *send_ptrs, const size_t *send_bytes,
+                      void *const *recv_ptrs, const size_t *recv_bytes, void *stream) {
+   OMG_TRY
+   OMG_ARG(c && n >= 0 && (n == 0 || (peers && send_ptrs && send_bytes && recv_ptrs && recv_bytes)));
+   if (c->C->exchange(n, peers, send_ptrs, send_bytes, recv_ptrs, recv_bytes, (hipStream_t)stream) != 0)
+      OMEGA_ABORT(c->C->lastError());
+   OMG_CATCH
+}
+int omg_halo_use_rccl(omg_halo *h, omg_rccl *c) {
+   OMG_TRY
+   OMG_ARG(h && c);
+   h->H->useRccl(c->C.get());
    OMG_CATCH
 }
 int omg_halo_set_transport(omg_halo *h, omg_transport_fn fn, void *ctx) {

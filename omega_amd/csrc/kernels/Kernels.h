@@ -143,5 +143,15 @@ void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr,
 void launchHaloPack(Real *Buf, const Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S);
 void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S);
 
+/// Every row of one exchange in ONE launch: job j = (piece, row) copies the K values of row `row` of
+/// piece `piece` (base pointers in HaloBases; a 3-D array is its [NT*RowsSize][K] plane stack) to / from buffer
+/// row j.  The job tables live on the device (Halo::Plan).
+constexpr int HaloMaxPieces = 4;
+struct HaloBases {
+   Real *P[HaloMaxPieces];
+};
+void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, hipStream_t S);
+void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, hipStream_t S);
+
 } // namespace OMEGA
 #endif

@@ -465,6 +465,52 @@ void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int N
    launchHaloCopy<false>(const_cast<Real *>(Buf), A, List, NList, NT, RowsSize, K, S);
 }
 
+// All rows of one exchange (every neighbour, every array) in one launch: buffer row j <-> row Jobs[2j+1] of the
+// plane stack of piece Jobs[2j].  threadIdx.x walks the level chunks of a row (coalesced on both sides),
+// threadIdx.y the rows of the workgroup.
+template <class T, bool Pack> __global__ void __launch_bounds__(256)
+haloCopyAllKernel(Real *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int K) {
+   for (size_t J = (size_t)blockIdx.x * blockDim.y + threadIdx.y; J < NRows; J += (size_t)gridDim.x * blockDim.y) {
+      const int Piece  = Jobs[2 * J];
+      const size_t Row = (size_t)(unsigned)Jobs[2 * J + 1];
+      Real *A          = B.P[Piece] + Row * K;
+      Real *Bf         = Buf + J * K;
+      for (int Kv = threadIdx.x; Kv < KV; Kv += blockDim.x) {
+         if (Pack)
+            reinterpret_cast<T *>(Bf)[Kv] = reinterpret_cast<const T *>(A)[Kv];
+         else
+            reinterpret_cast<T *>(A)[Kv] = reinterpret_cast<const T *>(Bf)[Kv];
+      }
+   }
+}
+template <bool Pack>
+static void launchHaloCopyAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, hipStream_t S) {
+   if (NRows == 0)
+      return;
+   const int W  = (K % 2 == 0) ? 2 : 1;
+   const int KV = K / W;
+   int TX       = 1;
+   while (TX < KV && TX < 64)
+      TX *= 2;
+   const int TY  = 256 / TX;
+   size_t Blocks = (NRows + TY - 1) / TY;
+   if (Blocks > 8192)
+      Blocks = 8192;
+   if (W == 2)
+      hipLaunchKernelGGL((haloCopyAllKernel<dv2, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, Buf, B, Jobs, NRows,
+                         KV, K);
+   else
+      hipLaunchKernelGGL((haloCopyAllKernel<double, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, Buf, B, Jobs,
+                         NRows, KV, K);
+   HIP_CHECK(hipGetLastError());
+}
+void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, hipStream_t S) {
+   launchHaloCopyAll<true>(Buf, B, Jobs, NRows, K, S);
+}
+void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, hipStream_t S) {
+   launchHaloCopyAll<false>(const_cast<Real *>(Buf), B, Jobs, NRows, K, S);
+}
+
 // ---------------------------------------------------------------------------------------
 // ManufacturedSolution (CustomTendencyTerms.cpp): one thread per (element, level); the source term
 // is level independent, so it is evaluated once per element row and added to every level.

@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "build", "libomega_oracle.so")
+_SO_NATIVE = os.path.join(_HERE, "build", "native", "libomega_oracle.so")
 
 PD = C.POINTER(C.c_double)
 PI = C.POINTER(C.c_int)
@@ -76,14 +77,35 @@ class OrcState(C.Structure):
                 ("hTend", PD), ("uTend", PD), ("trTend", PD)]
 
 
-def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+def build(force: bool = False, native: bool = False) -> str:
+    """Compile the oracle with gcc (recipe: oracle/Makefile).  native: the `-O3 -march=native` variant for
+    the CPU-baseline timing, always compiled on the machine that runs it (never shipped)."""
     src = os.path.join(_HERE, "omega_oracle.c")
     hdr = os.path.join(_HERE, "omega_oracle.h")
+    if native:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+        return _SO_NATIVE
     if (force or not os.path.exists(_SO)
             or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
+
+
+def default_threads() -> int:
+    """OpenMP team of the oracle: the host cores this process may use, capped at OMEGA_ORACLE_THREADS (default 16 =
+    a one-GPU box's CPU share).  Tests and bench.py's cpu_baseline use the same number."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, int(os.environ.get("OMEGA_ORACLE_THREADS", "16"))))
+
+
+def use_native_build():
+    """bench.py's cpu_baseline: load the -O3 -march=native build (must be called before the first lib())."""
+    global _SO
+    assert _lib is None, "oracle library already loaded"
+    _SO = build(native=True)
 
 
 _lib = None
@@ -100,11 +122,7 @@ def lib():
         # OpenMP team size: a GPU box exposes every hardware thread of the host but gives the job a
         # 16-core share; a team of hundreds of spinning threads on 16 cores makes each of the many
         # small parallel regions of a time step take milliseconds
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        L.orc_set_num_threads(max(1, min(avail, int(os.environ.get("OMEGA_ORACLE_THREADS", "8")))))
+        L.orc_set_num_threads(default_threads())
         _lib = L
     return _lib
 

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--halo-width", type=int, default=3)
     ap.add_argument("--no-del4", action="store_true", help="disable the two radius-2 (del4) terms")
     ap.add_argument("--no-overlap", action="store_true", help="RK4 (gpu mode): exchange after the stage instead of overlapped")
+    ap.add_argument("--user-stream", action="store_true",
+                    help="gpu mode: step on a non-blocking stream created with omg_stream_create instead of the default stream")
     ap.add_argument("--rtol", type=float, default=0.0,
                     help="0 = owned elements must equal the single-rank run bit for bit; > 0 = the partitioned run may "
                          "deviate by at most this (relative to the field's max), and MUST deviate (the setting is known "
@@ -90,8 +92,8 @@ def main():
             a3[:, rl, :] = rb.numpy()
 
     if gpu:
-        from omega_amd.transport import TorchTransport
-        TorchTransport(halo, per_cell=max(K * (1 + NT), 3 * K), per_edge=3 * K, per_vertex=3 * K, device="cuda:0")
+        from omega_amd.transport import GlooStagedTransport
+        GlooStagedTransport(halo)
 
     # ---------------- (a) HaloTest: global ids on owned, garbage on halo, exchange, compare ----------------
     for elem in (0, 1, 2):
@@ -134,8 +136,9 @@ def main():
             # make sure this mesh has both, or the test would not exercise it
             nb, ni = P.mesh.get_int("NBandCells"), P.mesh.get_int("NInteriorCells")
             assert nb > 0 and (ni > 0 or a.nx * a.ny <= 24 * 24), (nb, ni)
+        user_stream = oa.Stream() if a.user_stream else None   # hipStreamNonBlocking: no implicit ordering with stream 0
         for _ in range(a.steps):
-            st.do_step(P.state)
+            st.do_step(P.state, stream=user_stream)
         oa.device_synchronize()
         h, u = P.state.copy_to_host(0)
         tr = P.tracers.copy_to_host(0)
