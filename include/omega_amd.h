@@ -40,6 +40,14 @@ enum { OMG_ON_CELL = 0, OMG_ON_EDGE = 1, OMG_ON_VERTEX = 2 }; /* O/src/base/Halo
 
 const char *omg_last_error(void);
 
+/* Row pitch of the library's own device arrays whose last index is the vertical level: every array the *_device_ptr
+ * entry points return is [rows][omg_level_pitch(K)] doubles of which the first K per row are the levels (columns
+ * of at least one 128-byte line are padded to whole lines: K = 60 -> 64; K a multiple of 16 or below 16: pitch = K).
+ * Host arrays handed to / returned by the copy entry points and halo messages are always compact [rows][K].
+ * Entry points that take RAW device arrays from the caller (omg_halo_exchange, omg_horz_*, omg_update_by_tend,
+ * omg_local_weighted_sum_dd) have an explicit row_pitch argument (0 = compact). */
+int omg_level_pitch(int nvertlayers);
+
 /* ---- device / stream / event plumbing (Kokkos::initialize, Kokkos::fence, Pacer timers) ---- */
 int omg_device_count(int *n);
 int omg_device_init(int device_id);
@@ -81,8 +89,8 @@ int omg_copy_to_host(void *dst, const void *src, size_t bytes);
  *      omg_combine_dd: the reference's MPI_SUMDD operator applied in order to npairs (hi, lo) pairs -- how the
  *      per-rank partial sums are combined after an all-gather (globalSum). ---- */
 int omg_local_sum_dd(const double *a, const double *b, size_t n, void *stream, double *hi_lo);
-int omg_local_weighted_sum_dd(const double *w, const double *a, const double *b, int nrows, int k, void *stream,
-                              double *hi_lo);
+int omg_local_weighted_sum_dd(const double *w, const double *a, const double *b, int nrows, int k, int row_pitch,
+                              void *stream, double *hi_lo); /* row_pitch of a and b in values, 0 = k */
 int omg_combine_dd(const double *pairs, int npairs, double *hi_lo);
 
 /* ---- MPAS mesh / initial-state file (O/src/base/Decomp.cpp:108-395 readMesh and O/src/ocn/HorzMesh.cpp:424-523
@@ -166,8 +174,10 @@ int omg_rccl_exchange(omg_rccl *c, int n, const int *peers, void *const *send_pt
                       void *const *recv_ptrs, const size_t *recv_bytes, void *stream);
 /* route this Halo's exchanges through the communicator (which must outlive the Halo's exchanges) */
 int omg_halo_use_rccl(omg_halo *h, omg_rccl *c);
-/* Halo::exchangeFullArrayHalo on a raw device array [nt][rows_size][k] (nt = 1 for 2-D) */
-int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int elem, void *stream);
+/* Halo::exchangeFullArrayHalo on a raw device array [nt][rows_size][row_pitch] (nt = 1 for 2-D) of which the first
+ * k values of every row are exchanged (row_pitch 0 = compact rows of k) */
+int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
+                      void *stream);
 
 /* ---- HorzMesh (O/src/ocn/HorzMesh.cpp:44-140 constructor; HorzMesh.h:100-265 members).
  *      host_only != 0 builds the host arrays only (no device mirrors; compute calls fail). ---- */
@@ -180,21 +190,21 @@ int omg_mesh_set_fvertex(omg_mesh *m, const double *host_values /* [NVerticesSiz
 
 /* ---- HorzOperators (O/src/ocn/HorzOperators.h:9-187; constructors HorzOperators.cpp:7-28): the reference's
  *      reusable operators as sweeps over elements [0, n) (n < 0: all local elements) x nvertlayers levels of raw
- *      device arrays [NXxSize][nvertlayers]:
+ *      device arrays [NXxSize][row_pitch] (row_pitch 0 = compact rows of nvertlayers; input and output share it):
  *        divergence        DivCell(i,k)   = -sum_j DvEdge*EdgeSignOnCell(i,j)*VecEdge(e_j,k)/AreaCell(i)        :13-33
  *        gradient          GradEdge(e,k)  = (Scalar(c1,k) - Scalar(c0,k))/DcEdge(e)                             :47-60
  *        curl              CurlVertex(v,k)= sum_j DcEdge*EdgeSignOnVertex(v,j)*VecEdge(e_j,k)/AreaTriangle(v)   :71-93
  *        tangential_recon  ReconEdge(e,k) = sum_j WeightsOnEdge(e,j)*VecEdge(EdgesOnEdge(e,j),k)                :107-126
  *        interp_cell_to_edge (1-D arrays) isotropic != 0: kite-area weighted over the cells of the edge's two
  *                          vertices (:161-180), else the mean of its two cells (:153-159) ---- */
-int omg_horz_divergence(const omg_mesh *m, const double *vec_edge_dev, double *div_cell_dev, int nvertlayers, int n,
-                        void *stream);
-int omg_horz_gradient(const omg_mesh *m, const double *scalar_cell_dev, double *grad_edge_dev, int nvertlayers, int n,
-                      void *stream);
-int omg_horz_curl(const omg_mesh *m, const double *vec_edge_dev, double *curl_vertex_dev, int nvertlayers, int n,
-                  void *stream);
+int omg_horz_divergence(const omg_mesh *m, const double *vec_edge_dev, double *div_cell_dev, int nvertlayers,
+                        int row_pitch, int n, void *stream);
+int omg_horz_gradient(const omg_mesh *m, const double *scalar_cell_dev, double *grad_edge_dev, int nvertlayers,
+                      int row_pitch, int n, void *stream);
+int omg_horz_curl(const omg_mesh *m, const double *vec_edge_dev, double *curl_vertex_dev, int nvertlayers,
+                  int row_pitch, int n, void *stream);
 int omg_horz_tangential_recon(const omg_mesh *m, const double *vec_edge_dev, double *recon_edge_dev, int nvertlayers,
-                              int n, void *stream);
+                              int row_pitch, int n, void *stream);
 int omg_horz_interp_cell_to_edge(const omg_mesh *m, const double *array_cell_dev, double *array_edge_dev,
                                  int isotropic, int n, void *stream);
 
@@ -275,14 +285,14 @@ int omg_tend_use_manufactured_solution(omg_tend *t, const omg_mesh *m, double wa
 /* Custom tendencies as a caller-supplied function (Tendencies::CustomTendencyType, O/src/ocn/Tendencies.h:51-53:
  * std::function<void(Array2DReal Tend, const OceanState*, const AuxiliaryState*, int ThickTimeLevel,
  * int VelTimeLevel, TimeInstant)>, called at the end of the thickness / velocity group, Tendencies.cpp:288-291,
- * 416-419).  The callback ADDS its term to tend_dev ([n_rows_size][nvertlayers] device doubles, elements
- * [0, n_rows_all) are to be written) on `stream`; it is handed the state the tendencies are evaluated on as raw
- * device arrays (layer thickness [NCellsSize][K] at the thickness time level, normal velocity [NEdgesSize][K] at
- * the velocity time level) and the model time in seconds.  which: 0 thickness, 1 velocity.  fn == NULL clears
+ * 416-419).  The callback ADDS its term to tend_dev ([n_rows_size][row_pitch] device doubles, the first
+ * nvertlayers values of rows [0, n_rows_all) are to be written) on `stream`; it is handed the state the tendencies
+ * are evaluated on as raw device arrays of the same row pitch (layer thickness [NCellsSize][row_pitch] at the
+ * thickness time level, normal velocity [NEdgesSize][row_pitch] at the velocity time level) and the model time.  which: 0 thickness, 1 velocity.  fn == NULL clears
  * that hook.  With a custom hook set the Runge-Kutta stage updates run as separate kernels. */
 typedef int (*omg_custom_tend_fn)(void *ctx, double *tend_dev, const double *layer_thickness_dev,
                                   const double *normal_velocity_dev, int n_rows_all, int n_rows_size, int nvertlayers,
-                                  double time_seconds, void *stream);
+                                  int row_pitch, double time_seconds, void *stream);
 int omg_tend_set_custom_tendency(omg_tend *t, int which, omg_custom_tend_fn fn, void *ctx);
 int omg_tend_clear_custom_tendencies(omg_tend *t);
 int omg_tend_set_time(omg_tend *t, double seconds);

@@ -62,7 +62,7 @@ TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, PI, C.POINTER(C.c_void_
                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p)
 
 CUSTOM_TEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                             C.c_double, C.c_void_p)
+                             C.c_int, C.c_double, C.c_void_p)
 
 _lib = None
 
@@ -337,10 +337,16 @@ def local_sum_dd(a_ptr: int, n: int, b_ptr: int = 0, stream=None) -> tuple:
     return out[0], out[1]
 
 
-def local_weighted_sum_dd(w_ptr: int, a_ptr: int, nrows: int, k: int, b_ptr: int = 0, stream=None) -> tuple:
+def level_pitch(k: int) -> int:
+    """Row pitch (in values) of the library's own level-indexed device arrays (omg_level_pitch)."""
+    return lib().omg_level_pitch(k)
+
+
+def local_weighted_sum_dd(w_ptr: int, a_ptr: int, nrows: int, k: int, b_ptr: int = 0, stream=None, row_pitch: int = 0) -> tuple:
+    """row_pitch: pitch of the [rows][k] arrays in values (level_pitch(k) for arrays owned by the library, 0 = compact)"""
     out = (C.c_double * 2)()
     _chk(lib().omg_local_weighted_sum_dd(C.c_void_p(w_ptr), C.c_void_p(a_ptr), C.c_void_p(b_ptr) if b_ptr else None,
-                                         nrows, k, _sh(stream), out))
+                                         nrows, k, row_pitch, _sh(stream), out))
     return out[0], out[1]
 
 
@@ -482,8 +488,8 @@ class Halo:
         self._cb = TRANSPORT_FN(_cb)
         _chk(lib().omg_halo_set_transport(self.h, self._cb, None))
 
-    def exchange(self, dev_ptr: int, nt: int, rows_size: int, k: int, elem: int, stream=None):
-        _chk(lib().omg_halo_exchange(self.h, C.cast(C.c_void_p(dev_ptr), PD), nt, rows_size, k, elem, _sh(stream)))
+    def exchange(self, dev_ptr: int, nt: int, rows_size: int, k: int, elem: int, stream=None, row_pitch: int = 0):
+        _chk(lib().omg_halo_exchange(self.h, C.cast(C.c_void_p(dev_ptr), PD), nt, rows_size, k, row_pitch, elem, _sh(stream)))
 
     def __del__(self):
         try:
@@ -580,7 +586,7 @@ class HorzOperators:
         if one_d:
             _chk(fn(self.mesh.h, C.c_void_p(din.ptr), C.c_void_p(dout.ptr), *extra, n, None))
         else:
-            _chk(fn(self.mesh.h, C.c_void_p(din.ptr), C.c_void_p(dout.ptr), k, n, None))
+            _chk(fn(self.mesh.h, C.c_void_p(din.ptr), C.c_void_p(dout.ptr), k, 0, n, None))
         device_synchronize()
         return dout.to_host()
 
@@ -768,7 +774,7 @@ class Tendencies:
 
     def set_custom_tendency(self, which: int, fn):
         """Tendencies::CustomThicknessTend (which 0) / CustomVelocityTend (which 1) as a Python callable
-        fn(tend_ptr, h_ptr, u_ptr, n_rows_all, n_rows_size, K, time_seconds, stream_handle); None clears it."""
+        fn(tend_ptr, h_ptr, u_ptr, n_rows_all, n_rows_size, K, row_pitch, time_seconds, stream_handle); None clears it."""
         if not hasattr(self, "_custom"):
             self._custom = {}
         if fn is None:
@@ -776,9 +782,9 @@ class Tendencies:
             self._custom.pop(which, None)
             return
 
-        def _cb(_ctx, tend, h, u, nall, nsize, k, t, stream):
+        def _cb(_ctx, tend, h, u, nall, nsize, k, pitch, t, stream):
             try:
-                fn(tend, h, u, nall, nsize, k, t, stream)
+                fn(tend, h, u, nall, nsize, k, pitch, t, stream)
                 return 0
             except Exception:  # never let an exception cross the C boundary
                 import traceback

@@ -8,25 +8,25 @@ AuxiliaryState::AuxiliaryState(const std::string &Name_, const HorzMesh *Mesh_, 
     : Mesh(Mesh_), MeshHalo(MeshHalo_), Name(Name_), NVertLayers(K), NTracers(NT) {
    const int NC = Mesh->NCellsSize, NE = Mesh->NEdgesSize, NV = Mesh->NVerticesSize;
    const int NTa = NT > 0 ? NT : 1;
-   KineticAux.KineticEnergyCell         = Array2DReal("KineticEnergyCell", NC, K);
-   KineticAux.VelocityDivCell           = Array2DReal("VelocityDivCell", NC, K);
-   LayerThicknessAux.FluxLayerThickEdge = Array2DReal("FluxLayerThickEdge", NE, K);
-   LayerThicknessAux.MeanLayerThickEdge = Array2DReal("MeanLayerThickEdge", NE, K);
-   LayerThicknessAux.SshCell            = Array2DReal("SshCell", NC, K);
-   VorticityAux.RelVortVertex           = Array2DReal("RelVortVertex", NV, K);
-   VorticityAux.NormRelVortVertex       = Array2DReal("NormRelVortVertex", NV, K);
-   VorticityAux.NormPlanetVortVertex    = Array2DReal("NormPlanetVortVertex", NV, K);
-   VorticityAux.InvThickVertex          = Array2DReal("InvThickVertex", NV, K);
-   VorticityAux.NormRelVortEdge         = Array2DReal("NormRelVortEdge", NE, K);
-   VorticityAux.NormPlanetVortEdge      = Array2DReal("NormPlanetVortEdge", NE, K);
-   VelocityDel2Aux.Del2Edge             = Array2DReal("Del2Edge", NE, K);
-   VelocityDel2Aux.Del2DivCell          = Array2DReal("Del2DivCell", NC, K);
-   VelocityDel2Aux.Del2RelVortVertex    = Array2DReal("Del2RelVortVertex", NV, K);
+   KineticAux.KineticEnergyCell         = Array2DReal::levels("KineticEnergyCell", NC, K);
+   KineticAux.VelocityDivCell           = Array2DReal::levels("VelocityDivCell", NC, K);
+   LayerThicknessAux.FluxLayerThickEdge = Array2DReal::levels("FluxLayerThickEdge", NE, K);
+   LayerThicknessAux.MeanLayerThickEdge = Array2DReal::levels("MeanLayerThickEdge", NE, K);
+   LayerThicknessAux.SshCell            = Array2DReal::levels("SshCell", NC, K);
+   VorticityAux.RelVortVertex           = Array2DReal::levels("RelVortVertex", NV, K);
+   VorticityAux.NormRelVortVertex       = Array2DReal::levels("NormRelVortVertex", NV, K);
+   VorticityAux.NormPlanetVortVertex    = Array2DReal::levels("NormPlanetVortVertex", NV, K);
+   VorticityAux.InvThickVertex          = Array2DReal::levels("InvThickVertex", NV, K);
+   VorticityAux.NormRelVortEdge         = Array2DReal::levels("NormRelVortEdge", NE, K);
+   VorticityAux.NormPlanetVortEdge      = Array2DReal::levels("NormPlanetVortEdge", NE, K);
+   VelocityDel2Aux.Del2Edge             = Array2DReal::levels("Del2Edge", NE, K);
+   VelocityDel2Aux.Del2DivCell          = Array2DReal::levels("Del2DivCell", NC, K);
+   VelocityDel2Aux.Del2RelVortVertex    = Array2DReal::levels("Del2RelVortVertex", NV, K);
    WindForcingAux.NormalStressEdge      = Array1DReal("NormalStressEdge", NE);
    WindForcingAux.ZonalStressCell       = Array1DReal("ZonalStressCell", NC);
    WindForcingAux.MeridStressCell       = Array1DReal("MeridStressCell", NC);
-   TracerAux.HTracersEdge               = Array3DReal("HTracersEdge", NTa, NE, K);
-   TracerAux.Del2TracersCell            = Array3DReal("Del2TracersCell", NTa, NC, K);
+   TracerAux.HTracersEdge               = Array3DReal::levels("HTracersEdge", NTa, NE, K);
+   TracerAux.Del2TracersCell            = Array3DReal::levels("Del2TracersCell", NTa, NC, K);
 }
 
 AuxPtrs AuxiliaryState::ptrs() const {
@@ -88,8 +88,8 @@ I4 AuxiliaryState::exchangeHalo(hipStream_t S) {
       return 0;
    Array2DReal Z, Mv;
    // 1-D arrays are exchanged as (N, 1)
-   Z.Ptr = WindForcingAux.ZonalStressCell.Ptr, Z.Ext[0] = Mesh->NCellsSize, Z.Ext[1] = 1;
-   Mv.Ptr = WindForcingAux.MeridStressCell.Ptr, Mv.Ext[0] = Mesh->NCellsSize, Mv.Ext[1] = 1;
+   Z.Ptr = WindForcingAux.ZonalStressCell.Ptr, Z.Ext[0] = Mesh->NCellsSize, Z.Ext[1] = 1, Z.Pitch = 1;
+   Mv.Ptr = WindForcingAux.MeridStressCell.Ptr, Mv.Ext[0] = Mesh->NCellsSize, Mv.Ext[1] = 1, Mv.Pitch = 1;
    I4 Err = MeshHalo->exchangeFullArrayHalo(Z, OnCell, S);
    Err += MeshHalo->exchangeFullArrayHalo(Mv, OnCell, S);
    return Err;

@@ -65,25 +65,47 @@ class DeviceBuffer {
    size_t Bytes = 0;
 };
 
+/// Row pitch (in values) of a device array whose last index is the vertical level: a column of K levels is
+/// padded to whole 128-byte cache lines (16 doubles) once it is at least one line long, so every column starts
+/// on a line boundary and the kernels' 16-level chunks never straddle two lines (K = 60 -> 64: the EC30to60 /
+/// QU240 configurations).  Host arrays and message buffers stay compact ([rows][K]); only copies see the pitch.
+inline int levelPitch(int K) { return (K >= 16 && K % 16 != 0) ? (K + 15) / 16 * 16 : K; }
+
 /// Rank-N device array handle: pointer + extents, shared ownership of the
-/// allocation (copies alias, as Kokkos views do).
+/// allocation (copies alias, as Kokkos views do).  `Pitch` is the distance in values between consecutive
+/// rows of the last index (== Ext[N-1] unless the array was made with levels()).
 template <class T, int N> struct DeviceArray {
    T *Ptr = nullptr;
    int Ext[N > 0 ? N : 1] = {};
+   int Pitch = 0;
    std::string Label;
    std::shared_ptr<DeviceBuffer> Buf;
 
    DeviceArray() = default;
-   DeviceArray(const std::string &L, int E0, int E1 = 1, int E2 = 1) : Label(L) {
+   DeviceArray(const std::string &L, int E0, int E1 = 1, int E2 = 1, int Pitch_ = 0) : Label(L) {
       int E[3] = {E0, E1, E2};
       size_t Cnt = 1;
       for (int I = 0; I < N; ++I) {
          Ext[I] = E[I];
-         Cnt *= (size_t)E[I];
+         Cnt *= (size_t)(I == N - 1 && Pitch_ > 0 ? Pitch_ : E[I]);
       }
-      Buf = std::make_shared<DeviceBuffer>(Cnt * sizeof(T));
-      Ptr = static_cast<T *>(Buf->Ptr);
+      Pitch = Pitch_ > 0 ? Pitch_ : Ext[N - 1];
+      Buf   = std::make_shared<DeviceBuffer>(Cnt * sizeof(T));
+      Ptr   = static_cast<T *>(Buf->Ptr);
    }
+   /// an array whose last index is the vertical level: rows padded to levelPitch(K) (zero-filled pad)
+   static DeviceArray levels(const std::string &L, int E0, int E1 = 1, int E2 = 1) {
+      const int K = N == 1 ? E0 : (N == 2 ? E1 : E2);
+      return DeviceArray(L, E0, E1, E2, levelPitch(K));
+   }
+   /// number of rows of the last index (product of the other extents)
+   size_t rows() const {
+      size_t Cnt = Ptr ? 1 : 0;
+      for (int I = 0; I + 1 < N; ++I)
+         Cnt *= (size_t)Ext[I];
+      return Cnt;
+   }
+   /// logical number of values (what a compact host copy holds)
    size_t size() const {
       size_t Cnt = Ptr ? 1 : 0;
       for (int I = 0; I < N; ++I)
@@ -127,8 +149,19 @@ using HostArrayReal = HostArray<Real>;
 void deviceInit(int DeviceId);                 ///< hipSetDevice + sanity check (gfx950)
 void copyToDevice(void *Dst, const void *Src, size_t Bytes, hipStream_t S = nullptr);
 void copyToHost(void *Dst, const void *Src, size_t Bytes, hipStream_t S = nullptr);
+/// rows x width values between a compact host array and a device array of row pitch `Pitch` (values)
+void copyRowsToDevice(Real *Dst, int Pitch, const Real *Src, size_t Rows, int Width);
+void copyRowsToHost(Real *Dst, const Real *Src, int Pitch, size_t Rows, int Width);
 void deviceFill0(void *Dst, size_t Bytes, hipStream_t S);
 void deviceCopy(void *Dst, const void *Src, size_t Bytes, hipStream_t S);
+
+/// compact host data <-> a (possibly level-padded) device array
+template <int N> void copyToDevice(const DeviceArray<Real, N> &D, const Real *Host) {
+   copyRowsToDevice(D.Ptr, D.Pitch, Host, D.rows(), D.Ext[N - 1]);
+}
+template <int N> void copyToHost(Real *Host, const DeviceArray<Real, N> &D) {
+   copyRowsToHost(Host, D.Ptr, D.Pitch, D.rows(), D.Ext[N - 1]);
+}
 
 template <class T, int N>
 DeviceArray<T, N> createDeviceMirrorCopy(const std::string &L, const HostArray<T> &H) {

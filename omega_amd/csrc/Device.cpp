@@ -52,6 +52,29 @@ void copyToHost(void *Dst, const void *Src, size_t Bytes, hipStream_t S) {
       HIP_CHECK(hipMemcpy(Dst, Src, Bytes, hipMemcpyDeviceToHost));
    }
 }
+// Host copies are not hot-path calls; they synchronise the device first so that they are ordered against work on
+// ANY stream, including the non-blocking streams of omg_stream_create (a plain hipMemcpy only orders against the
+// null stream).
+void copyRowsToDevice(Real *Dst, int Pitch, const Real *Src, size_t Rows, int Width) {
+   if (!Rows || !Width)
+      return;
+   HIP_CHECK(hipDeviceSynchronize());
+   if (Pitch == Width)
+      HIP_CHECK(hipMemcpy(Dst, Src, Rows * Width * sizeof(Real), hipMemcpyHostToDevice));
+   else
+      HIP_CHECK(hipMemcpy2D(Dst, (size_t)Pitch * sizeof(Real), Src, (size_t)Width * sizeof(Real),
+                            (size_t)Width * sizeof(Real), Rows, hipMemcpyHostToDevice));
+}
+void copyRowsToHost(Real *Dst, const Real *Src, int Pitch, size_t Rows, int Width) {
+   if (!Rows || !Width)
+      return;
+   HIP_CHECK(hipDeviceSynchronize());
+   if (Pitch == Width)
+      HIP_CHECK(hipMemcpy(Dst, Src, Rows * Width * sizeof(Real), hipMemcpyDeviceToHost));
+   else
+      HIP_CHECK(hipMemcpy2D(Dst, (size_t)Width * sizeof(Real), Src, (size_t)Pitch * sizeof(Real),
+                            (size_t)Width * sizeof(Real), Rows, hipMemcpyDeviceToHost));
+}
 void deviceFill0(void *Dst, size_t Bytes, hipStream_t S) {
    if (Bytes)
       HIP_CHECK(hipMemsetAsync(Dst, 0, Bytes, S));

@@ -105,13 +105,15 @@ const Halo::Plan &Halo::planFor(const std::vector<Piece> &Pieces) {
    std::vector<int> Key;
    for (const Piece &P : Pieces) {
       Key.push_back((int)P.Elem), Key.push_back(P.NT), Key.push_back(P.RowsSize), Key.push_back(P.K);
-      OMEGA_REQUIRE(P.K == Pieces[0].K, "Halo: arrays exchanged together must have the same number of levels");
+      Key.push_back(P.Pitch);
+      OMEGA_REQUIRE(P.K == Pieces[0].K && P.Pitch == Pieces[0].Pitch && P.Pitch >= P.K,
+                    "Halo: arrays exchanged together must have the same number of levels and row pitch");
    }
    auto It = Plans.find(Key);
    if (It != Plans.end())
       return It->second;
    Plan Pl;
-   Pl.K = Pieces[0].K;
+   Pl.K = Pieces[0].K, Pl.Pitch = Pieces[0].Pitch;
    Pl.SendOff.assign(NNghbr, 0), Pl.RecvOff.assign(NNghbr, 0);
    Pl.SendBytes.assign(NNghbr, 0), Pl.RecvBytes.assign(NNghbr, 0);
    const size_t RowBytes = (size_t)Pl.K * sizeof(Real);
@@ -159,25 +161,29 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
       RecvPtrs[N] = static_cast<char *>(RecvBuf->Ptr) + Pl.RecvOff[N];
    }
    // pack: one launch for every neighbour and array (Halo.h:324-414)
-   launchHaloPackAll(static_cast<Real *>(SendBuf->Ptr), B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, S);
+   launchHaloPackAll(static_cast<Real *>(SendBuf->Ptr), B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, Pl.Pitch, S);
    const int Err = Transport(TransportCtx, NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
                              RecvPtrs.data(), Pl.RecvBytes.data(), (void *)S);
    if (Err != 0)
       return -1;
    // unpack: one launch (Halo.h:566-653)
-   launchHaloUnpackAll(B, static_cast<const Real *>(RecvBuf->Ptr), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, S);
+   launchHaloUnpackAll(B, static_cast<const Real *>(RecvBuf->Ptr), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, S);
    return 0;
 }
 I4 Halo::exchangeFullArrayHalo(const Array2DReal &A, MeshElement E, hipStream_t S) {
-   return exchangePieces({Piece{A.Ptr, E, 1, A.Ext[0], A.Ext[1]}}, S);
+   return exchangePieces({Piece{A.Ptr, E, 1, A.Ext[0], A.Ext[1], A.Pitch}}, S);
 }
 I4 Halo::exchangeFullArrayHalo(const Array3DReal &A, MeshElement E, hipStream_t S) {
-   return exchangePieces({Piece{A.Ptr, E, A.Ext[0], A.Ext[1], A.Ext[2]}}, S);
+   return exchangePieces({Piece{A.Ptr, E, A.Ext[0], A.Ext[1], A.Ext[2], A.Pitch}}, S);
+}
+I4 Halo::exchangeRaw(Real *Ptr, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S) {
+   return exchangePieces({Piece{Ptr, E, NT, RowsSize, K, Pitch > 0 ? Pitch : K}}, S);
 }
 I4 Halo::exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT, hipStream_t S) {
-   std::vector<Piece> P{Piece{H.Ptr, OnCell, 1, H.Ext[0], H.Ext[1]}, Piece{U.Ptr, OnEdge, 1, U.Ext[0], U.Ext[1]}};
+   std::vector<Piece> P{Piece{H.Ptr, OnCell, 1, H.Ext[0], H.Ext[1], H.Pitch},
+                        Piece{U.Ptr, OnEdge, 1, U.Ext[0], U.Ext[1], U.Pitch}};
    if (Tr && NT > 0)
-      P.push_back(Piece{Tr->Ptr, OnCell, NT, Tr->Ext[1], Tr->Ext[2]});
+      P.push_back(Piece{Tr->Ptr, OnCell, NT, Tr->Ext[1], Tr->Ext[2], Tr->Pitch});
    return exchangePieces(P, S);
 }
 

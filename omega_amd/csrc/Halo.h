@@ -56,6 +56,8 @@ class Halo {
 
    I4 exchangeFullArrayHalo(const Array2DReal &A, MeshElement E, hipStream_t S);
    I4 exchangeFullArrayHalo(const Array3DReal &A, MeshElement E, hipStream_t S);
+   /// caller-owned raw device array [NT][RowsSize][Pitch] of which K values per row are levels
+   I4 exchangeRaw(Real *Ptr, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S);
    /// One aggregated message per neighbour: [h on cells][u on edges][tracers on cells].
    I4 exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT, hipStream_t S);
 
@@ -63,7 +65,7 @@ class Halo {
    struct Piece {
       Real *Ptr;
       MeshElement Elem;
-      int NT, RowsSize, K;
+      int NT, RowsSize, K, Pitch; ///< Pitch: row pitch of the array in values (>= K)
    };
    /// Everything about an exchange that does not depend on the array pointers: the job tables of the pack and
    /// the unpack kernel (one job = one row of K values: which piece, which row of its [NT*RowsSize][K] plane
@@ -71,7 +73,7 @@ class Halo {
    /// Message layout per neighbour = the reference's, piece after piece: Buf[(T*NList + I)*K + k]
    /// (Halo.h:344-351, 390-397).
    struct Plan {
-      int K = 0;
+      int K = 0, Pitch = 0;
       size_t NSendRows = 0, NRecvRows = 0;
       Array1DI4 SendJobs, RecvJobs; ///< [NRows][2] = (piece, row)
       std::vector<size_t> SendOff, RecvOff, SendBytes, RecvBytes; ///< per neighbour, bytes

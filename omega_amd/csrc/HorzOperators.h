@@ -11,12 +11,19 @@
 
 namespace OMEGA {
 
+/// input and output of one operator call must share the row pitch (both made with Array2DReal::levels, or both compact)
+inline int samePitch(const Array2DReal &A, const Array2DReal &B) {
+   OMEGA_REQUIRE(A.Pitch == B.Pitch && A.Ext[1] == B.Ext[1], "HorzOperators: arrays of different level count / row pitch");
+   return A.Pitch;
+}
+
 class DivergenceOnCell {
  public:
    explicit DivergenceOnCell(HorzMesh const *Mesh) : Mesh(Mesh) {}
    /// DivCell(i, k) for i < N (N < 0: NCellsAll)
    void operator()(const Array2DReal &DivCell, const Array2DReal &VecEdge, hipStream_t S = nullptr, int N = -1) const {
-      launchDivergenceOnCell(Mesh->view(), N < 0 ? Mesh->NCellsAll : N, DivCell.Ext[1], DivCell.Ptr, VecEdge.Ptr, S);
+      launchDivergenceOnCell(Mesh->view(), N < 0 ? Mesh->NCellsAll : N, DivCell.Ext[1], samePitch(DivCell, VecEdge),
+                             DivCell.Ptr, VecEdge.Ptr, S);
    }
 
  private:
@@ -28,7 +35,8 @@ class GradientOnEdge {
    explicit GradientOnEdge(HorzMesh const *Mesh) : Mesh(Mesh) {}
    void operator()(const Array2DReal &GradEdge, const Array2DReal &ScalarCell, hipStream_t S = nullptr,
                    int N = -1) const {
-      launchGradientOnEdge(Mesh->view(), N < 0 ? Mesh->NEdgesAll : N, GradEdge.Ext[1], GradEdge.Ptr, ScalarCell.Ptr, S);
+      launchGradientOnEdge(Mesh->view(), N < 0 ? Mesh->NEdgesAll : N, GradEdge.Ext[1], samePitch(GradEdge, ScalarCell),
+                           GradEdge.Ptr, ScalarCell.Ptr, S);
    }
 
  private:
@@ -40,8 +48,8 @@ class CurlOnVertex {
    explicit CurlOnVertex(HorzMesh const *Mesh) : Mesh(Mesh) {}
    void operator()(const Array2DReal &CurlVertex, const Array2DReal &VecEdge, hipStream_t S = nullptr,
                    int N = -1) const {
-      launchCurlOnVertex(Mesh->view(), N < 0 ? Mesh->NVerticesAll : N, CurlVertex.Ext[1], CurlVertex.Ptr, VecEdge.Ptr,
-                         S);
+      launchCurlOnVertex(Mesh->view(), N < 0 ? Mesh->NVerticesAll : N, CurlVertex.Ext[1], samePitch(CurlVertex, VecEdge),
+                         CurlVertex.Ptr, VecEdge.Ptr, S);
    }
 
  private:
@@ -53,8 +61,8 @@ class TangentialReconOnEdge {
    explicit TangentialReconOnEdge(HorzMesh const *Mesh) : Mesh(Mesh) {}
    void operator()(const Array2DReal &ReconEdge, const Array2DReal &VecEdge, hipStream_t S = nullptr,
                    int N = -1) const {
-      launchTangentialReconOnEdge(Mesh->view(), N < 0 ? Mesh->NEdgesAll : N, ReconEdge.Ext[1], ReconEdge.Ptr,
-                                  VecEdge.Ptr, S);
+      launchTangentialReconOnEdge(Mesh->view(), N < 0 ? Mesh->NEdgesAll : N, ReconEdge.Ext[1],
+                                  samePitch(ReconEdge, VecEdge), ReconEdge.Ptr, VecEdge.Ptr, S);
    }
 
  private:

@@ -13,8 +13,8 @@ OceanState::OceanState(const std::string &Name_, const HorzMesh *Mesh, Halo *Mes
    NVertLayers = NVertLayers_;
    NTimeLevels = NTimeLevels_;
    for (int I = 0; I < NTimeLevels; ++I) {
-      LayerThickness.emplace_back("LayerThickness" + std::to_string(I), NCellsSize, NVertLayers);
-      NormalVelocity.emplace_back("NormalVelocity" + std::to_string(I), NEdgesSize, NVertLayers);
+      LayerThickness.push_back(Array2DReal::levels("LayerThickness" + std::to_string(I), NCellsSize, NVertLayers));
+      NormalVelocity.push_back(Array2DReal::levels("NormalVelocity" + std::to_string(I), NEdgesSize, NVertLayers));
    }
 }
 
@@ -63,9 +63,9 @@ I4 OceanState::copyToDevice(const Real *HH, const Real *HU, I4 TimeLevel) {
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
    if (HH)
-      OMEGA::copyToDevice(LayerThickness[Idx].Ptr, HH, LayerThickness[Idx].bytes());
+      OMEGA::copyToDevice(LayerThickness[Idx], HH);
    if (HU)
-      OMEGA::copyToDevice(NormalVelocity[Idx].Ptr, HU, NormalVelocity[Idx].bytes());
+      OMEGA::copyToDevice(NormalVelocity[Idx], HU);
    return 0;
 }
 I4 OceanState::copyToHost(Real *HH, Real *HU, I4 TimeLevel) const {
@@ -73,9 +73,9 @@ I4 OceanState::copyToHost(Real *HH, Real *HU, I4 TimeLevel) const {
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
    if (HH)
-      OMEGA::copyToHost(HH, LayerThickness[Idx].Ptr, LayerThickness[Idx].bytes());
+      OMEGA::copyToHost(HH, LayerThickness[Idx]);
    if (HU)
-      OMEGA::copyToHost(HU, NormalVelocity[Idx].Ptr, NormalVelocity[Idx].bytes());
+      OMEGA::copyToHost(HU, NormalVelocity[Idx]);
    return 0;
 }
 
@@ -85,8 +85,8 @@ Tracers::Tracers(const HorzMesh *Mesh, Halo *MeshHalo_, int NVertLayers_, int NT
    NTracers = NTracers_, NTimeLevels = NTimeLevels_, NVertLayers = NVertLayers_;
    NCellsOwned = Mesh->NCellsOwned, NCellsAll = Mesh->NCellsAll, NCellsSize = Mesh->NCellsSize;
    for (int I = 0; I < NTimeLevels; ++I)
-      TracerArrays.emplace_back("TracerArrays" + std::to_string(I), NTracers > 0 ? NTracers : 1, NCellsSize,
-                                NVertLayers);
+      TracerArrays.push_back(Array3DReal::levels("TracerArrays" + std::to_string(I), NTracers > 0 ? NTracers : 1,
+                                                 NCellsSize, NVertLayers));
 }
 I4 Tracers::getTimeIndex(I4 &TimeIndex, I4 TimeLevel) const {
    if (NTimeLevels > 1 && (TimeLevel > 1 || (TimeLevel + NTimeLevels) <= 1))
@@ -120,7 +120,7 @@ I4 Tracers::copyToDevice(const Real *H, I4 TimeLevel) {
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
    if (NTracers > 0)
-      OMEGA::copyToDevice(TracerArrays[Idx].Ptr, H, (size_t)NTracers * NCellsSize * NVertLayers * sizeof(Real));
+      OMEGA::copyToDevice(TracerArrays[Idx], H);
    return 0;
 }
 I4 Tracers::copyToHost(Real *H, I4 TimeLevel) const {
@@ -128,7 +128,7 @@ I4 Tracers::copyToHost(Real *H, I4 TimeLevel) const {
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
    if (NTracers > 0)
-      OMEGA::copyToHost(H, TracerArrays[Idx].Ptr, (size_t)NTracers * NCellsSize * NVertLayers * sizeof(Real));
+      OMEGA::copyToHost(H, TracerArrays[Idx]);
    return 0;
 }
 

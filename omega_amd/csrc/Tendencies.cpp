@@ -6,9 +6,9 @@ namespace OMEGA {
 Tendencies::Tendencies(const std::string &, const HorzMesh *Mesh_, int K, int NT, const TendParams &Options)
     : Params(Options), Mesh(Mesh_), NVertLayers(K), NTracers(NT) {
    // Tendency arrays (Tendencies.cpp:233-238)
-   LayerThicknessTend = Array2DReal("LayerThicknessTend", Mesh->NCellsSize, K);
-   NormalVelocityTend = Array2DReal("NormalVelocityTend", Mesh->NEdgesSize, K);
-   TracerTend         = Array3DReal("TracerTend", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+   LayerThicknessTend = Array2DReal::levels("LayerThicknessTend", Mesh->NCellsSize, K);
+   NormalVelocityTend = Array2DReal::levels("NormalVelocityTend", Mesh->NEdgesSize, K);
+   TracerTend         = Array3DReal::levels("TracerTend", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
 }
 
 Tendencies::~Tendencies() {
@@ -113,7 +113,7 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
    OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
                  "Tendencies: bad time level");
    if (!EdgeScratch.Ptr)
-      EdgeScratch = Array2DReal("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
+      EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
    return launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                          NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, nullptr,
                          EdgeScratch.Ptr, &Stage);
@@ -127,7 +127,7 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
                         State->getNormalVelocity(NormVel, VelLvl) == 0,
                     "Tendencies: bad time level");
       if (!EdgeScratch.Ptr)
-         EdgeScratch = Array2DReal("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
+         EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
       hipEvent_t *Ev = nullptr;
       if (TimingOn && TimingEvents.size() < 4096) {
          TimingEvents.emplace_back(FusedNumKernels + 1);

@@ -140,13 +140,13 @@ void TimeStepper::updateThicknessByTend(OceanState *S1, int L1, OceanState *S2, 
    Array2DReal H1, H2;
    OMEGA_REQUIRE(S1->getLayerThickness(H1, L1) == 0 && S2->getLayerThickness(H2, L2) == 0,
                  "TimeStepper updateThickness: error retrieving layer thick");
-   launchUpdateByTend(Mesh->NCellsAll, H1.Ext[1], H1.Ptr, H2.Ptr, Tend->LayerThicknessTend.Ptr, C, S);
+   launchUpdateByTend(Mesh->NCellsAll, H1.Pitch, H1.Ptr, H2.Ptr, Tend->LayerThicknessTend.Ptr, C, S);
 }
 void TimeStepper::updateVelocityByTend(OceanState *S1, int L1, OceanState *S2, int L2, R8 C, hipStream_t S) const {
    Array2DReal U1, U2;
    OMEGA_REQUIRE(S1->getNormalVelocity(U1, L1) == 0 && S2->getNormalVelocity(U2, L2) == 0,
                  "TimeStepper updateVelocity: error retrieving velocity");
-   launchUpdateByTend(Mesh->NEdgesAll, U1.Ext[1], U1.Ptr, U2.Ptr, Tend->NormalVelocityTend.Ptr, C, S);
+   launchUpdateByTend(Mesh->NEdgesAll, U1.Pitch, U1.Ptr, U2.Ptr, Tend->NormalVelocityTend.Ptr, C, S);
 }
 void TimeStepper::updateStateByTend(OceanState *S1, int L1, OceanState *S2, int L2, R8 C, hipStream_t S) const {
    updateThicknessByTend(S1, L1, S2, L2, C, S);
@@ -157,24 +157,24 @@ void TimeStepper::updateTracersByTend(const Array3DReal &Next, const Array3DReal
    Array2DReal H1, H2;
    OMEGA_REQUIRE(S1->getLayerThickness(H1, L1) == 0 && S2->getLayerThickness(H2, L2) == 0,
                  "TimeStepper updateTracers: error retrieving layer thick");
-   launchUpdateTracersByTend(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H1.Ext[1], Next.Ptr, Cur.Ptr,
+   launchUpdateTracersByTend(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H1.Pitch, Next.Ptr, Cur.Ptr,
                              H1.Ptr, H2.Ptr, Tend->TracerTend.Ptr, C, S);
 }
 void TimeStepper::weightTracers(const Array3DReal &Next, const Array3DReal &Cur, OceanState *St, int L1,
                                 hipStream_t S) const {
    Array2DReal H;
    OMEGA_REQUIRE(St->getLayerThickness(H, L1) == 0, "TimeStepper weightTracers: bad time level");
-   launchWeightTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Ext[1], Next.Ptr, Cur.Ptr, H.Ptr,
+   launchWeightTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Pitch, Next.Ptr, Cur.Ptr, H.Ptr,
                        S);
 }
 void TimeStepper::accumulateTracersUpdate(const Array3DReal &Accum, R8 C, hipStream_t S) const {
-   launchAccumulateTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, Accum.Ext[2], Accum.Ptr,
+   launchAccumulateTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, Accum.Pitch, Accum.Ptr,
                            Tend->TracerTend.Ptr, C, S);
 }
 void TimeStepper::finalizeTracersUpdate(const Array3DReal &Next, OceanState *St, int L, hipStream_t S) const {
    Array2DReal H;
    OMEGA_REQUIRE(St->getLayerThickness(H, L) == 0, "TimeStepper finalizeTracers: bad time level");
-   launchFinalizeTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Ext[1], Next.Ptr, H.Ptr, S);
+   launchFinalizeTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Pitch, Next.Ptr, H.Ptr, S);
 }
 
 void TimeStepper::updateTimeLevels(OceanState *State, hipStream_t S) const {
@@ -248,7 +248,7 @@ void RungeKutta4Stepper::finalizeInit() {
    OMEGA_REQUIRE(Tend && Mesh && Trc, "RungeKutta4Stepper: attachData before finalizeInit");
    const int K = Tend->LayerThicknessTend.Ext[1];
    ProvisState.reset(new OceanState("Provis" + Name, Mesh, MeshHalo, K, 1)); // 1 time level (:56-60)
-   ProvisTracers = Array3DReal("ProvisTracers", Trc->NTracers > 0 ? Trc->NTracers : 1, Mesh->NCellsSize, K);
+   ProvisTracers = Array3DReal::levels("ProvisTracers", Trc->NTracers > 0 ? Trc->NTracers : 1, Mesh->NCellsSize, K);
 }
 
 // The same scheme with every stage's updates applied in the epilogue of the kernels that produce
@@ -297,7 +297,7 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
    const int K  = Tend->LayerThicknessTend.Ext[1];
    if (!ProvisState2) {
       ProvisState2.reset(new OceanState("Provis2" + Name, Mesh, MeshHalo, K, 1));
-      ProvisTracers2 = Array3DReal("ProvisTracers2", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+      ProvisTracers2 = Array3DReal::levels("ProvisTracers2", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
    }
    Array3DReal NextTr, CurTr;
    Array2DReal CurH, CurU, NextH, NextU;

@@ -70,6 +70,17 @@ static thread_local std::string LastError;
    if (!(cond))                                                                \
    OMEGA_ABORT(std::string("invalid argument: ") + #cond)
 
+/// a device array as (pointer, rows of the last index, width, row pitch) -- see copyRowsToHost
+struct ArrRef {
+   Real *Ptr;
+   size_t Rows;
+   int Width, Pitch;
+   size_t size() const { return Rows * (size_t)Width; }
+};
+template <int N> static ArrRef arrRef(const DeviceArray<Real, N> &A) {
+   return ArrRef{A.Ptr, A.rows(), A.Ext[N - 1], A.Pitch};
+}
+
 extern "C" {
 
 const char *omg_last_error(void) { return LastError.c_str(); }
@@ -172,11 +183,11 @@ int omg_local_sum_dd(const double *a, const double *b, size_t n, void *stream, d
    localSumDD(a, b, n, (hipStream_t)stream, hi_lo);
    OMG_CATCH
 }
-int omg_local_weighted_sum_dd(const double *w, const double *a, const double *b, int nrows, int k, void *stream,
-                              double *hi_lo) {
+int omg_local_weighted_sum_dd(const double *w, const double *a, const double *b, int nrows, int k, int row_pitch,
+                              void *stream, double *hi_lo) {
    OMG_TRY
-   OMG_ARG(w && a && hi_lo && nrows >= 0 && k > 0);
-   localWeightedSumDD(w, a, b, nrows, k, (hipStream_t)stream, hi_lo);
+   OMG_ARG(w && a && hi_lo && nrows >= 0 && k > 0 && (row_pitch == 0 || row_pitch >= k));
+   localWeightedSumDD(w, a, b, nrows, k, row_pitch > 0 ? row_pitch : k, (hipStream_t)stream, hi_lo);
    OMG_CATCH
 }
 int omg_combine_dd(const double *pairs, int npairs, double *hi_lo) {
@@ -494,13 +505,11 @@ int omg_halo_set_transport(omg_halo *h, omg_transport_fn fn, void *ctx) {
    h->H->setTransport((HaloTransportFn)fn, ctx);
    OMG_CATCH
 }
-int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int elem, void *stream) {
+int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
+                      void *stream) {
    OMG_TRY
-   OMG_ARG(h && dev_array && nt >= 1 && elem >= 0 && elem < 3);
-   Array3DReal A;
-   A.Ptr    = dev_array;
-   A.Ext[0] = nt, A.Ext[1] = rows_size, A.Ext[2] = k;
-   if (h->H->exchangeFullArrayHalo(A, (MeshElement)elem, (hipStream_t)stream) != 0)
+   OMG_ARG(h && dev_array && nt >= 1 && elem >= 0 && elem < 3 && k >= 1 && (row_pitch == 0 || row_pitch >= k));
+   if (h->H->exchangeRaw(dev_array, nt, rows_size, k, row_pitch, (MeshElement)elem, (hipStream_t)stream) != 0)
       OMEGA_ABORT("Halo::exchangeFullArrayHalo failed");
    OMG_CATCH
 }
@@ -617,12 +626,12 @@ static void requireDevice(const HorzMesh *M) {
 
 // ---------------------------------------------------------------- options
 #define OMG_HORZ_OP(NAME, LAUNCH, NALL)                                                                              \
-   int NAME(const omg_mesh *m, const double *in, double *out, int k, int n, void *stream) {                        \
+   int NAME(const omg_mesh *m, const double *in, double *out, int k, int row_pitch, int n, void *stream) {         \
       OMG_TRY                                                                                                      \
-      OMG_ARG(m && in && out && k > 0);                                                                            \
+      OMG_ARG(m && in && out && k > 0 && (row_pitch == 0 || row_pitch >= k));                                      \
       OMEGA_REQUIRE(!m->M->HostOnly, #NAME ": needs a device mesh");                                               \
       OMG_ARG(n <= m->M->NALL);                                                                                    \
-      LAUNCH(m->M->view(), n < 0 ? m->M->NALL : n, k, out, in, (hipStream_t)stream);                               \
+      LAUNCH(m->M->view(), n < 0 ? m->M->NALL : n, k, row_pitch > 0 ? row_pitch : k, out, in, (hipStream_t)stream); \
       OMG_CATCH                                                                                                    \
    }
 OMG_HORZ_OP(omg_horz_divergence, launchDivergenceOnCell, NCellsAll)
@@ -841,63 +850,56 @@ int omg_aux_compute_all(omg_aux *a, const omg_state *s, const omg_tracers *t, in
    a->A->computeAll(s->S.get(), tracerArray(t, trtl), ttl, vtl, (hipStream_t)stream);
    OMG_CATCH
 }
-static void auxLookup(const AuxiliaryState &A, const std::string &Name, Real *&Ptr, size_t &Cnt) {
-   const std::map<std::string, std::pair<Real *, size_t>> M{
-       {"KineticEnergyCell", {A.KineticAux.KineticEnergyCell.Ptr, A.KineticAux.KineticEnergyCell.size()}},
-       {"VelocityDivCell", {A.KineticAux.VelocityDivCell.Ptr, A.KineticAux.VelocityDivCell.size()}},
-       {"FluxLayerThickEdge", {A.LayerThicknessAux.FluxLayerThickEdge.Ptr, A.LayerThicknessAux.FluxLayerThickEdge.size()}},
-       {"MeanLayerThickEdge", {A.LayerThicknessAux.MeanLayerThickEdge.Ptr, A.LayerThicknessAux.MeanLayerThickEdge.size()}},
-       {"SshCell", {A.LayerThicknessAux.SshCell.Ptr, A.LayerThicknessAux.SshCell.size()}},
-       {"RelVortVertex", {A.VorticityAux.RelVortVertex.Ptr, A.VorticityAux.RelVortVertex.size()}},
-       {"NormRelVortVertex", {A.VorticityAux.NormRelVortVertex.Ptr, A.VorticityAux.NormRelVortVertex.size()}},
-       {"NormPlanetVortVertex", {A.VorticityAux.NormPlanetVortVertex.Ptr, A.VorticityAux.NormPlanetVortVertex.size()}},
-       {"NormRelVortEdge", {A.VorticityAux.NormRelVortEdge.Ptr, A.VorticityAux.NormRelVortEdge.size()}},
-       {"NormPlanetVortEdge", {A.VorticityAux.NormPlanetVortEdge.Ptr, A.VorticityAux.NormPlanetVortEdge.size()}},
-       {"Del2Edge", {A.VelocityDel2Aux.Del2Edge.Ptr, A.VelocityDel2Aux.Del2Edge.size()}},
-       {"Del2DivCell", {A.VelocityDel2Aux.Del2DivCell.Ptr, A.VelocityDel2Aux.Del2DivCell.size()}},
-       {"Del2RelVortVertex", {A.VelocityDel2Aux.Del2RelVortVertex.Ptr, A.VelocityDel2Aux.Del2RelVortVertex.size()}},
-       {"HTracersEdge", {A.TracerAux.HTracersEdge.Ptr, A.TracerAux.HTracersEdge.size()}},
-       {"Del2TracersCell", {A.TracerAux.Del2TracersCell.Ptr, A.TracerAux.Del2TracersCell.size()}},
-       {"NormalStressEdge", {A.WindForcingAux.NormalStressEdge.Ptr, A.WindForcingAux.NormalStressEdge.size()}},
-       {"ZonalStressCell", {A.WindForcingAux.ZonalStressCell.Ptr, A.WindForcingAux.ZonalStressCell.size()}},
-       {"MeridStressCell", {A.WindForcingAux.MeridStressCell.Ptr, A.WindForcingAux.MeridStressCell.size()}}};
+static ArrRef auxLookup(const AuxiliaryState &A, const std::string &Name) {
+   const std::map<std::string, ArrRef> M{
+       {"KineticEnergyCell", arrRef(A.KineticAux.KineticEnergyCell)},
+       {"VelocityDivCell", arrRef(A.KineticAux.VelocityDivCell)},
+       {"FluxLayerThickEdge", arrRef(A.LayerThicknessAux.FluxLayerThickEdge)},
+       {"MeanLayerThickEdge", arrRef(A.LayerThicknessAux.MeanLayerThickEdge)},
+       {"SshCell", arrRef(A.LayerThicknessAux.SshCell)},
+       {"RelVortVertex", arrRef(A.VorticityAux.RelVortVertex)},
+       {"NormRelVortVertex", arrRef(A.VorticityAux.NormRelVortVertex)},
+       {"NormPlanetVortVertex", arrRef(A.VorticityAux.NormPlanetVortVertex)},
+       {"NormRelVortEdge", arrRef(A.VorticityAux.NormRelVortEdge)},
+       {"NormPlanetVortEdge", arrRef(A.VorticityAux.NormPlanetVortEdge)},
+       {"Del2Edge", arrRef(A.VelocityDel2Aux.Del2Edge)},
+       {"Del2DivCell", arrRef(A.VelocityDel2Aux.Del2DivCell)},
+       {"Del2RelVortVertex", arrRef(A.VelocityDel2Aux.Del2RelVortVertex)},
+       {"HTracersEdge", arrRef(A.TracerAux.HTracersEdge)},
+       {"Del2TracersCell", arrRef(A.TracerAux.Del2TracersCell)},
+       {"NormalStressEdge", arrRef(A.WindForcingAux.NormalStressEdge)},
+       {"ZonalStressCell", arrRef(A.WindForcingAux.ZonalStressCell)},
+       {"MeridStressCell", arrRef(A.WindForcingAux.MeridStressCell)}};
    auto It = M.find(Name);
    if (It == M.end())
       OMEGA_ABORT("AuxiliaryState: no array named " + Name);
-   Ptr = It->second.first;
-   Cnt = It->second.second;
+   return It->second;
 }
 int omg_aux_copy_to_host(const omg_aux *a, const char *name, double *host, size_t n) {
    OMG_TRY
    OMG_ARG(a && name && host);
-   Real *P;
-   size_t C;
-   auxLookup(*a->A, name, P, C);
-   if (n < C)
+   const ArrRef R = auxLookup(*a->A, name);
+   if (n < R.size())
       OMEGA_ABORT(std::string("output buffer too small for ") + name);
-   copyToHost(host, P, C * sizeof(Real));
+   copyRowsToHost(host, R.Ptr, R.Pitch, R.Rows, R.Width);
    OMG_CATCH
 }
 int omg_aux_copy_to_device(omg_aux *a, const char *name, const double *host, size_t n) {
    OMG_TRY
    OMG_ARG(a && name && host);
-   Real *P;
-   size_t C;
-   auxLookup(*a->A, name, P, C);
-   if (n != C)
+   const ArrRef R = auxLookup(*a->A, name);
+   if (n != R.size())
       OMEGA_ABORT(std::string("size mismatch for ") + name);
-   copyToDevice(P, host, C * sizeof(Real));
+   copyRowsToDevice(R.Ptr, R.Pitch, host, R.Rows, R.Width);
    OMG_CATCH
 }
 int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t *n) {
    OMG_TRY
    OMG_ARG(a && name && dev);
-   Real *P;
-   size_t C;
-   auxLookup(*a->A, name, P, C);
-   *dev = P;
+   const ArrRef R = auxLookup(*a->A, name);
+   *dev = R.Ptr;
    if (n)
-      *n = C;
+      *n = R.size();
    OMG_CATCH
 }
 
@@ -998,7 +1000,7 @@ int omg_tend_set_custom_tendency(omg_tend *t, int which, omg_custom_tend_fn fn, 
          Array2DReal H, U;
          OMEGA_REQUIRE(State->getLayerThickness(H, ThickLvl) == 0 && State->getNormalVelocity(U, VelLvl) == 0,
                        "custom tendency: bad time level");
-         OMEGA_REQUIRE(fn(ctx, Tend.Ptr, H.Ptr, U.Ptr, NAll, NSize, Tend.Ext[1], Time, (void *)S) == 0,
+         OMEGA_REQUIRE(fn(ctx, Tend.Ptr, H.Ptr, U.Ptr, NAll, NSize, Tend.Ext[1], Tend.Pitch, Time, (void *)S) == 0,
                        "custom tendency callback reported an error");
       };
    }
@@ -1033,17 +1035,14 @@ int omg_tend_collect_kernel_times(omg_tend *t, double *ms_sum, int *n_kernels, i
    OMG_CATCH
 }
 const char *omg_tend_kernel_name(int i) { return (i >= 0 && i < FusedNumKernels) ? FusedKernelNames[i] : ""; }
-static void tendLookup(const Tendencies &T, int Which, Real *&P, size_t &C) {
+static ArrRef tendLookup(const Tendencies &T, int Which) {
    switch (Which) {
    case 0:
-      P = T.LayerThicknessTend.Ptr, C = T.LayerThicknessTend.size();
-      break;
+      return arrRef(T.LayerThicknessTend);
    case 1:
-      P = T.NormalVelocityTend.Ptr, C = T.NormalVelocityTend.size();
-      break;
+      return arrRef(T.NormalVelocityTend);
    case 2:
-      P = T.TracerTend.Ptr, C = T.TracerTend.size();
-      break;
+      return arrRef(T.TracerTend);
    default:
       OMEGA_ABORT("Tendencies: `which` must be 0, 1 or 2");
    }
@@ -1051,25 +1050,22 @@ static void tendLookup(const Tendencies &T, int Which, Real *&P, size_t &C) {
 int omg_tend_copy_to_host(const omg_tend *t, int which, double *host, size_t n) {
    OMG_TRY
    OMG_ARG(t && host);
-   Real *P;
-   size_t C;
-   tendLookup(*t->T, which, P, C);
-   if (n < C)
+   const ArrRef R = tendLookup(*t->T, which);
+   if (n < R.size())
       OMEGA_ABORT("output buffer too small for tendency array");
-   copyToHost(host, P, C * sizeof(Real));
+   copyRowsToHost(host, R.Ptr, R.Pitch, R.Rows, R.Width);
    OMG_CATCH
 }
 int omg_tend_device_ptr(const omg_tend *t, int which, double **dev, size_t *n) {
    OMG_TRY
    OMG_ARG(t && dev);
-   Real *P;
-   size_t C;
-   tendLookup(*t->T, which, P, C);
-   *dev = P;
+   const ArrRef R = tendLookup(*t->T, which);
+   *dev = R.Ptr;
    if (n)
-      *n = C;
+      *n = R.size();
    OMG_CATCH
 }
+int omg_level_pitch(int nvertlayers) { return levelPitch(nvertlayers); }
 
 // ---------------------------------------------------------------- TimeStepper
 int omg_stepper_create(const char *type, double dt, omg_tend *t, omg_aux *a, const omg_mesh *m, omg_halo *halo,

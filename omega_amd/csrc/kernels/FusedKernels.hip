@@ -482,6 +482,7 @@ struct FusedEdgeBody {
    const Real *H, *U;
    const Real *RelVort, *NormRelVortV, *NormPlanetVortV, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
    Real *Tend;
+   int KLog = 0; ///< number of levels (K is the row pitch): set by launchTile
    struct Lds {
       Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
       int *EoE, *PVS, *C0, *C1, *V0, *V1, *N;
@@ -591,8 +592,8 @@ struct FusedEdgeBody {
          const Real InvThickEdge = 1. / HMean0;
          setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * NormalStress[IEdge] / P.Density0);
       }
-      if (P.BottomDragTendencyEnable && (Kv + 1) * W >= K) {
-         const int KBot          = K - 1;
+      if (P.BottomDragTendencyEnable && (Kv + 1) * W >= KLog) {
+         const int KBot          = KLog - 1;
          const int Comp          = KBot - Kv * W;
          const Real VelNormEdge  = sqrt(KE[(size_t)C0 * K + KBot] + KE[(size_t)C1 * K + KBot]);
          const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
@@ -641,6 +642,7 @@ template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEd
    Real *Tend;
    const I4 *EdgeList = nullptr; ///< if set, element i of the sweep is edge EdgeList[i]
    StageEpi E{};                 ///< velocity stage update (EPI)
+   int KLog = 0;                 ///< number of levels (K is the row pitch): set by launchTile
    __device__ int edgeOf(int I) const { return EdgeList ? EdgeList[I] : I; }
    struct Lds {
       Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1, *FCh, *F0, *F1; // F*: FVertex of ChV / V0 / V1
@@ -784,8 +786,8 @@ template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEd
          const Real InvThickEdge = 1. / HMean0;
          setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * NormalStress[IEdge] / P.Density0);
       }
-      if (DragOn && (Kv + 1) * W >= K) {
-         const int KBot          = K - 1;
+      if (DragOn && (Kv + 1) * W >= KLog) {
+         const int KBot          = KLog - 1;
          const int Comp          = KBot - Kv * W;
          const Real VelNormEdge  = sqrt(KE[(size_t)L.C0[Le] * K + KBot] + KE[(size_t)L.C1[Le] * K + KBot]);
          const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
@@ -1090,6 +1092,7 @@ template <bool Fast> struct EdgeFinalBody {
    const Real *H, *U, *Partial;
    const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort, *NormalStress;
    Real *Tend;
+   int KLog = 0; ///< number of levels (K is the row pitch): set by launchTile
    struct Lds {
       Real *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4, *BD0, *BD1;
       int *C0, *C1, *V0, *V1, *Reg;
@@ -1172,8 +1175,8 @@ template <bool Fast> struct EdgeFinalBody {
          const Real InvThickEdge = 1. / HMean0;
          setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * NormalStress[IEdge] / P.Density0);
       }
-      if (DragOn && (Kv + 1) * W >= K) {
-         const int KBot          = K - 1;
+      if (DragOn && (Kv + 1) * W >= KLog) {
+         const int KBot          = KLog - 1;
          const int Comp          = KBot - Kv * W;
          const Real VelNormEdge  = sqrt(KE[(size_t)L.C0[Le] * K + KBot] + KE[(size_t)L.C1[Le] * K + KBot]);
          const Real HMeanB       = 0.5 * (getc(H0, Comp) + getc(H1, Comp));
@@ -1351,7 +1354,7 @@ static bool isDefaultTermSet(const TendParams &P) {
 bool fusedRHSSupported(const MeshView &M, int K) {
    const size_t MaxRows = (size_t)(M.NEdgesSize > M.NCellsSize ? M.NEdgesSize : M.NCellsSize);
    const size_t Rows    = MaxRows > (size_t)M.NVerticesSize ? MaxRows : (size_t)M.NVerticesSize;
-   return M.MaxEdges >= 5 && M.MaxEdges <= 8 && Rows * (size_t)K * 8 < ((size_t)1 << 32);
+   return M.MaxEdges >= 5 && M.MaxEdges <= 8 && Rows * (size_t)levelPitch(K) * 8 < ((size_t)1 << 32);
 }
 
 template <int TME, bool Fast>

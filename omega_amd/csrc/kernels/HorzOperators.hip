@@ -181,17 +181,21 @@ struct TangentialReconOnEdgeBody {
    }
 };
 
-void launchDivergenceOnCell(const MeshView &M, int N, int K, Real *DivCell, const Real *VecEdge, hipStream_t S) {
-   launchTile(DivergenceOnCellBody{M, K, VecEdge, DivCell}, N, K, S);
+void launchDivergenceOnCell(const MeshView &M, int N, int K, int Pitch, Real *DivCell, const Real *VecEdge,
+                            hipStream_t S) {
+   launchTile(DivergenceOnCellBody{M, K, VecEdge, DivCell}, N, K, S, Pitch);
 }
-void launchGradientOnEdge(const MeshView &M, int N, int K, Real *GradEdge, const Real *ScalarCell, hipStream_t S) {
-   launchTile(GradientOnEdgeBody{M, K, ScalarCell, GradEdge}, N, K, S);
+void launchGradientOnEdge(const MeshView &M, int N, int K, int Pitch, Real *GradEdge, const Real *ScalarCell,
+                          hipStream_t S) {
+   launchTile(GradientOnEdgeBody{M, K, ScalarCell, GradEdge}, N, K, S, Pitch);
 }
-void launchCurlOnVertex(const MeshView &M, int N, int K, Real *CurlVertex, const Real *VecEdge, hipStream_t S) {
-   launchTile(CurlOnVertexBody{M, K, VecEdge, CurlVertex}, N, K, S);
+void launchCurlOnVertex(const MeshView &M, int N, int K, int Pitch, Real *CurlVertex, const Real *VecEdge,
+                        hipStream_t S) {
+   launchTile(CurlOnVertexBody{M, K, VecEdge, CurlVertex}, N, K, S, Pitch);
 }
-void launchTangentialReconOnEdge(const MeshView &M, int N, int K, Real *ReconEdge, const Real *VecEdge, hipStream_t S) {
-   launchTile(TangentialReconOnEdgeBody{M, K, VecEdge, ReconEdge}, N, K, S);
+void launchTangentialReconOnEdge(const MeshView &M, int N, int K, int Pitch, Real *ReconEdge, const Real *VecEdge,
+                                 hipStream_t S) {
+   launchTile(TangentialReconOnEdgeBody{M, K, VecEdge, ReconEdge}, N, K, S, Pitch);
 }
 
 // InterpCellToEdge on a 1-D cell array (HorzOperators.h:137-187): anisotropic = mean of the two cells of the

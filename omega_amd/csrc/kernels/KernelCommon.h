@@ -15,6 +15,7 @@
 #define OMEGA_AMD_KERNELCOMMON_H
 
 #include <cstdlib>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include "../Base.h"
@@ -101,7 +102,9 @@ struct Geom {
    int Tile; ///< elements per workgroup
    int W;    ///< levels per thread (1 or 2)
 };
-inline Geom makeGeom(int N, int K, int MaxW = 2) {
+inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0) {
+   if (Pitch <= 0)
+      Pitch = K;
    Geom G;
    static const int EnvW = getenv("OMEGA_W") ? atoi(getenv("OMEGA_W")) : 2;
    G.W  = (K % 2 == 0 && MaxW >= 2 && EnvW >= 2) ? 2 : 1;
@@ -112,11 +115,11 @@ inline Geom makeGeom(int N, int K, int MaxW = 2) {
    // the tile are then served by L1/L2 while still resident (at ~6 TB/s an XCD's 4 MiB L2
    // turns over in a few microseconds, so reuse separated by a whole sweep is lost).  The
    // workgroup walks the remaining level chunks with the x-stride loop of tileKernel.
-   // Columns whose byte length is not a multiple of the line (K = 60: 480 B) would make every 128-byte
-   // chunk straddle two lines; there threadIdx.x spans the whole column instead (measured on the
-   // EC30to60-sized case: 2.95 -> 2.2 ms).
+   // Columns whose byte length is not a multiple of the line would make every 128-byte chunk straddle two
+   // lines: the library's own arrays pad such rows to whole lines (Base.h: levelPitch, K = 60 -> pitch 64);
+   // for short columns (K < 16) and caller-owned compact arrays threadIdx.x spans the whole column instead.
    const int LineTX   = 128 / (8 * G.W);
-   const bool Aligned = (K * 8) % 128 == 0;
+   const bool Aligned = (Pitch * 8) % 128 == 0; // rows start on line boundaries (levelPitch pads K >= 16 to lines)
    int TX             = Aligned ? (G.KV < LineTX ? G.KV : LineTX) : (G.KV < 64 ? G.KV : 64);
    static const int EnvTX = getenv("OMEGA_TX") ? atoi(getenv("OMEGA_TX")) : 0;
    static const int EnvTY = getenv("OMEGA_TY") ? atoi(getenv("OMEGA_TY")) : 0;
@@ -184,10 +187,24 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
          }
 }
 
-template <class Body> void launchTile(const Body &B, int N, int K, hipStream_t S) {
+template <class B, class = void> struct BodyHasKLog {
+   static constexpr bool V = false;
+};
+template <class B> struct BodyHasKLog<B, decltype((void)std::declval<B &>().KLog)> {
+   static constexpr bool V = true;
+};
+/// Sweep of elements [0, N) x K levels.  Every body addresses rows through its member `K`, which this launcher
+/// sets to the row pitch of the arrays (levelPitch(K) for the library's own arrays; Pitch >= K for caller-owned
+/// ones, e.g. compact raw arrays of the C ABI); bodies that also need the level COUNT (bottom level of the drag
+/// term) declare `int KLog`.
+template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t S, int Pitch = -1) {
    if (N <= 0)
       return;
-   Geom G           = makeGeom(N, K, BodyMaxW<Body>::V);
+   Body B = B0;
+   B.K    = Pitch > 0 ? Pitch : levelPitch(K);
+   if constexpr (BodyHasKLog<Body>::V)
+      B.KLog = K;
+   Geom G           = makeGeom(N, K, BodyMaxW<Body>::V, B.K);
    const size_t Lds = B.ldsBytes(G.Tile);
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {

@@ -106,7 +106,9 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
 /// HiLo[0] + HiLo[1] is the sum, HiLo[0] its rounded value.  Synchronises the stream.
 void localSumDD(const Real *A, const Real *B, size_t N, hipStream_t S, double HiLo[2]);
 /// element rows [0, NRows) of a [RowsSize][K] array times a per-row weight (e.g. AreaCell): sum_r W[r]*sum_k A[r][k]*B[r][k]
-void localWeightedSumDD(const Real *W, const Real *A, const Real *B, int NRows, int K, hipStream_t S, double HiLo[2]);
+/// (Pitch = row pitch of A and B in values)
+void localWeightedSumDD(const Real *W, const Real *A, const Real *B, int NRows, int K, int Pitch, hipStream_t S,
+                        double HiLo[2]);
 /// ddSum (Reductions.h:24-35) over NPairs (hi, lo) pairs in order: how per-rank partial sums are combined
 void combineDD(const double *Pairs, int NPairs, double HiLo[2]);
 
@@ -120,11 +122,12 @@ void launchManufacturedThickness(int NCells, int K, Real *Tend, const Real *XCel
 void launchManufacturedVelocity(int NEdges, int K, Real *Tend, const Real *XEdge, const Real *YEdge, const Real *FEdge,
                                 const Real *AngleEdge, const ManufacturedParams &P, Real ElapsedSec, hipStream_t S);
 
-// ---- HorzOperators (HorzOperators.h:9-187): sweeps over elements [0, N) x K levels ----
-void launchDivergenceOnCell(const MeshView &M, int N, int K, Real *DivCell, const Real *VecEdge, hipStream_t S);
-void launchGradientOnEdge(const MeshView &M, int N, int K, Real *GradEdge, const Real *ScalarCell, hipStream_t S);
-void launchCurlOnVertex(const MeshView &M, int N, int K, Real *CurlVertex, const Real *VecEdge, hipStream_t S);
-void launchTangentialReconOnEdge(const MeshView &M, int N, int K, Real *ReconEdge, const Real *VecEdge, hipStream_t S);
+// ---- HorzOperators (HorzOperators.h:9-187): sweeps over elements [0, N) x K levels of arrays with row pitch Pitch ----
+void launchDivergenceOnCell(const MeshView &M, int N, int K, int Pitch, Real *DivCell, const Real *VecEdge, hipStream_t S);
+void launchGradientOnEdge(const MeshView &M, int N, int K, int Pitch, Real *GradEdge, const Real *ScalarCell, hipStream_t S);
+void launchCurlOnVertex(const MeshView &M, int N, int K, int Pitch, Real *CurlVertex, const Real *VecEdge, hipStream_t S);
+void launchTangentialReconOnEdge(const MeshView &M, int N, int K, int Pitch, Real *ReconEdge, const Real *VecEdge,
+                                 hipStream_t S);
 void launchInterpCellToEdge(const MeshView &M, int N, Real *ArrayEdge, const Real *ArrayCell, int Isotropic,
                             hipStream_t S);
 
@@ -138,10 +141,7 @@ void launchAccumulateTracers(int NT, int NRows, int RowsSize, int K, Real *Accum
                              hipStream_t S);
 void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr, const Real *HNext, hipStream_t S);
 
-// ---- Halo pack / unpack (Halo.h:324-414, 566-653) ----
-/// Buf[(T*NList + I)*K + k] = A[(T*RowsSize + List[I])*K + k]  (2-D: NT = 1)
-void launchHaloPack(Real *Buf, const Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S);
-void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S);
+// ---- Halo pack / unpack (Halo.h:324-414, 566-653): message layout Buf[(T*NList + I)*K + k] per neighbour ----
 
 /// Every row of one exchange in ONE launch: job j = (piece, row) copies the K values of row `row` of
 /// piece `piece` (base pointers in HaloBases; a 3-D array is its [NT*RowsSize][K] plane stack) to / from buffer
@@ -150,8 +150,10 @@ constexpr int HaloMaxPieces = 4;
 struct HaloBases {
    Real *P[HaloMaxPieces];
 };
-void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, hipStream_t S);
-void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, hipStream_t S);
+/// (buffer rows are compact, K values; array rows have pitch Pitch)
+void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, hipStream_t S);
+void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch,
+                         hipStream_t S);
 
 } // namespace OMEGA
 #endif

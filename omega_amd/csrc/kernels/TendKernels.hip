@@ -84,6 +84,7 @@ struct VelTendBody {
    AuxPtrs A;
    const Real *U;
    Real *Tend;
+   int KLog = 0; ///< number of levels (K is the row pitch): set by launchTile
    struct Lds {
       Real *W, *InvDc, *InvDv, *Mask, *MaskGrav, *C2, *C4;
       int *EoE, *C0, *C1, *V0, *V1, *N;
@@ -177,8 +178,8 @@ struct VelTendBody {
          const Real InvThickEdge = 1. / A.MeanLayerThickEdge[(size_t)IEdge * K];
          setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * A.NormalStressEdge[IEdge] / P.Density0);
       }
-      if (P.BottomDragTendencyEnable && (Kv + 1) * W >= K) { // bottom level KBot = K-1 (:323)
-         const int KBot          = K - 1;
+      if (P.BottomDragTendencyEnable && (Kv + 1) * W >= KLog) { // bottom level KBot = K-1 (:323)
+         const int KBot          = KLog - 1;
          const int Comp          = KBot - Kv * W;
          const Real VelNormEdge  = sqrt(A.KineticEnergyCell[(size_t)C0 * K + KBot] + A.KineticEnergyCell[(size_t)C1 * K + KBot]);
          const Real InvThickEdge = 1. / A.MeanLayerThickEdge[(size_t)IEdge * K + KBot];
@@ -304,6 +305,8 @@ template <class F> static void launchStream(const F &Fn, size_t NVec, hipStream_
    hipLaunchKernelGGL((streamKernel<F>), dim3((unsigned)Blocks), dim3(256), 0, S, Fn, NVec);
 }
 
+// (for all streaming update kernels below `K` is the ROW LENGTH of the arrays = their pitch: callers pass
+// Array.Pitch, so padded levels are swept too -- they hold zeros / garbage nobody reads)
 // X1 = X2 + Coeff*Tend over NRows*K contiguous values (updateThicknessByTend :378-401,
 // updateVelocityByTend :407-430)
 template <class T> struct UpdateFn {
@@ -423,57 +426,17 @@ void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr,
 }
 
 // ---------------------------------------------------------------------------------------
-// Halo pack / unpack (components/omega/src/base/Halo.h:324-414, 566-653).  The message
-// layout is the reference's: Buf[(T*NList + I)*K + k] (2-D arrays: T = 0 only).
-template <class T, bool Pack> __global__ void __launch_bounds__(256)
-haloCopyKernel(Real *Buf, Real *A, const I4 *List, int NList, int NT, int RowsSize, int KV, int K) {
-   const size_t Total = (size_t)NT * NList * KV;
-   for (size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x; I < Total; I += (size_t)gridDim.x * blockDim.x) {
-      const int Kv    = (int)(I % KV);
-      const size_t R  = I / KV;
-      const int IExch = (int)(R % NList);
-      const int Tt    = (int)(R / NList);
-      const size_t Ai = ((size_t)Tt * RowsSize + List[IExch]) * K + (size_t)Kv * VecW<T>::W;
-      const size_t Bi = ((size_t)Tt * NList + IExch) * K + (size_t)Kv * VecW<T>::W;
-      if (Pack)
-         *reinterpret_cast<T *>(Buf + Bi) = *reinterpret_cast<const T *>(A + Ai);
-      else
-         *reinterpret_cast<T *>(A + Ai) = *reinterpret_cast<const T *>(Buf + Bi);
-   }
-}
-template <bool Pack>
-static void launchHaloCopy(Real *Buf, Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S) {
-   if (NList <= 0 || NT <= 0)
-      return;
-   const int W        = (K % 2 == 0) ? 2 : 1;
-   const int KV       = K / W;
-   const size_t Total = (size_t)NT * NList * KV;
-   size_t Blocks      = (Total + 255) / 256;
-   if (Blocks > 4096)
-      Blocks = 4096;
-   if (W == 2)
-      hipLaunchKernelGGL((haloCopyKernel<dv2, Pack>), dim3((unsigned)Blocks), dim3(256), 0, S, Buf, A, List, NList, NT,
-                         RowsSize, KV, K);
-   else
-      hipLaunchKernelGGL((haloCopyKernel<double, Pack>), dim3((unsigned)Blocks), dim3(256), 0, S, Buf, A, List, NList,
-                         NT, RowsSize, KV, K);
-}
-void launchHaloPack(Real *Buf, const Real *A, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S) {
-   launchHaloCopy<true>(Buf, const_cast<Real *>(A), List, NList, NT, RowsSize, K, S);
-}
-void launchHaloUnpack(Real *A, const Real *Buf, const I4 *List, int NList, int NT, int RowsSize, int K, hipStream_t S) {
-   launchHaloCopy<false>(const_cast<Real *>(Buf), A, List, NList, NT, RowsSize, K, S);
-}
-
+// Halo pack / unpack (components/omega/src/base/Halo.h:324-414, 566-653).  The message layout is the
+// reference's: per neighbour and array Buf[(T*NList + I)*K + k] (2-D arrays: T = 0 only), compact rows of K.
 // All rows of one exchange (every neighbour, every array) in one launch: buffer row j <-> row Jobs[2j+1] of the
 // plane stack of piece Jobs[2j].  threadIdx.x walks the level chunks of a row (coalesced on both sides),
 // threadIdx.y the rows of the workgroup.
 template <class T, bool Pack> __global__ void __launch_bounds__(256)
-haloCopyAllKernel(Real *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int K) {
+haloCopyAllKernel(Real *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int K, int Pitch) {
    for (size_t J = (size_t)blockIdx.x * blockDim.y + threadIdx.y; J < NRows; J += (size_t)gridDim.x * blockDim.y) {
       const int Piece  = Jobs[2 * J];
       const size_t Row = (size_t)(unsigned)Jobs[2 * J + 1];
-      Real *A          = B.P[Piece] + Row * K;
+      Real *A          = B.P[Piece] + Row * Pitch;
       Real *Bf         = Buf + J * K;
       for (int Kv = threadIdx.x; Kv < KV; Kv += blockDim.x) {
          if (Pack)
@@ -484,10 +447,11 @@ haloCopyAllKernel(Real *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, 
    }
 }
 template <bool Pack>
-static void launchHaloCopyAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, hipStream_t S) {
+static void launchHaloCopyAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch,
+                              hipStream_t S) {
    if (NRows == 0)
       return;
-   const int W  = (K % 2 == 0) ? 2 : 1;
+   const int W  = (K % 2 == 0 && Pitch % 2 == 0) ? 2 : 1;
    const int KV = K / W;
    int TX       = 1;
    while (TX < KV && TX < 64)
@@ -498,23 +462,24 @@ static void launchHaloCopyAll(Real *Buf, const HaloBases &B, const I4 *Jobs, siz
       Blocks = 8192;
    if (W == 2)
       hipLaunchKernelGGL((haloCopyAllKernel<dv2, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, Buf, B, Jobs, NRows,
-                         KV, K);
+                         KV, K, Pitch);
    else
       hipLaunchKernelGGL((haloCopyAllKernel<double, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, Buf, B, Jobs,
-                         NRows, KV, K);
+                         NRows, KV, K, Pitch);
    HIP_CHECK(hipGetLastError());
 }
-void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, hipStream_t S) {
-   launchHaloCopyAll<true>(Buf, B, Jobs, NRows, K, S);
+void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, hipStream_t S) {
+   launchHaloCopyAll<true>(Buf, B, Jobs, NRows, K, Pitch, S);
 }
-void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, hipStream_t S) {
-   launchHaloCopyAll<false>(const_cast<Real *>(Buf), B, Jobs, NRows, K, S);
+void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch,
+                         hipStream_t S) {
+   launchHaloCopyAll<false>(const_cast<Real *>(Buf), B, Jobs, NRows, K, Pitch, S);
 }
 
 // ---------------------------------------------------------------------------------------
 // ManufacturedSolution (CustomTendencyTerms.cpp): one thread per (element, level); the source term
 // is level independent, so it is evaluated once per element row and added to every level.
-__global__ void manufacturedThicknessKernel(int N, int K, Real *Tend, const Real *XCell, const Real *YCell,
+__global__ void manufacturedThicknessKernel(int N, int K, int Pitch, Real *Tend, const Real *XCell, const Real *YCell,
                                             ManufacturedParams P, Real T) {
    const int I = blockIdx.x * blockDim.y + threadIdx.y;
    if (I >= N)
@@ -523,9 +488,9 @@ __global__ void manufacturedThicknessKernel(int N, int K, Real *Tend, const Real
    const Real Src   = P.Eta0 * (-P.H0 * (P.Kx + P.Ky) * sin(Phase) - P.AngFreq * cos(Phase) +
                               P.Eta0 * (P.Kx + P.Ky) * cos(2.0 * Phase)); // :139-142
    for (int Kl = threadIdx.x; Kl < K; Kl += blockDim.x)
-      Tend[(size_t)I * K + Kl] += Src;
+      Tend[(size_t)I * Pitch + Kl] += Src;
 }
-__global__ void manufacturedVelocityKernel(int N, int K, Real *Tend, const Real *XEdge, const Real *YEdge,
+__global__ void manufacturedVelocityKernel(int N, int K, int Pitch, Real *Tend, const Real *XEdge, const Real *YEdge,
                                            const Real *FEdge, const Real *AngleEdge, ManufacturedParams P, Real T) {
    const int I = blockIdx.x * blockDim.y + threadIdx.y;
    if (I >= N)
@@ -545,7 +510,7 @@ __global__ void manufacturedVelocityKernel(int N, int K, Real *Tend, const Real 
    }
    const Real Src = cos(AngleEdge[I]) * U + sin(AngleEdge[I]) * V;
    for (int Kl = threadIdx.x; Kl < K; Kl += blockDim.x)
-      Tend[(size_t)I * K + Kl] += Src;
+      Tend[(size_t)I * Pitch + Kl] += Src;
 }
 static dim3 rowBlock(int K) {
    int TX = 1;
@@ -558,7 +523,7 @@ void launchManufacturedThickness(int N, int K, Real *Tend, const Real *XCell, co
    if (N <= 0)
       return;
    const dim3 B = rowBlock(K);
-   hipLaunchKernelGGL(manufacturedThicknessKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, Tend, XCell, YCell, P, T);
+   hipLaunchKernelGGL(manufacturedThicknessKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, levelPitch(K), Tend, XCell, YCell, P, T);
    HIP_CHECK(hipGetLastError());
 }
 void launchManufacturedVelocity(int N, int K, Real *Tend, const Real *XEdge, const Real *YEdge, const Real *FEdge,
@@ -566,7 +531,7 @@ void launchManufacturedVelocity(int N, int K, Real *Tend, const Real *XEdge, con
    if (N <= 0)
       return;
    const dim3 B = rowBlock(K);
-   hipLaunchKernelGGL(manufacturedVelocityKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, Tend, XEdge, YEdge, FEdge,
+   hipLaunchKernelGGL(manufacturedVelocityKernel, dim3((N + B.y - 1) / B.y), B, 0, S, N, K, levelPitch(K), Tend, XEdge, YEdge, FEdge,
                       AngleEdge, P, T);
    HIP_CHECK(hipGetLastError());
 }
@@ -620,12 +585,13 @@ __global__ void __launch_bounds__(256) sumDDKernel(const Real *A, const Real *B,
       Partial[blockIdx.x] = R;
 }
 __global__ void __launch_bounds__(256) weightedSumDDKernel(const Real *W, const Real *A, const Real *B, int NRows, int K,
-                                                           DD *Partial) {
+                                                           int Pitch, DD *Partial) {
    DD Acc{0.0, 0.0};
    const size_t N = (size_t)NRows * K;
    for (size_t I = (size_t)blockIdx.x * 256 + threadIdx.x; I < N; I += (size_t)gridDim.x * 256) {
-      const double V = B ? A[I] * B[I] : A[I];
-      Acc            = ddAddScalar(Acc, W[I / K] * V);
+      const size_t R = I / K, J = R * Pitch + (I - R * K);
+      const double V = B ? A[J] * B[J] : A[J];
+      Acc            = ddAddScalar(Acc, W[R] * V);
    }
    const DD R = blockReduceDD(Acc);
    if (threadIdx.x == 0)
@@ -649,12 +615,13 @@ void localSumDD(const Real *A, const Real *B, size_t N, hipStream_t S, double Hi
    HIP_CHECK(hipGetLastError());
    finishDD(PartialD, NB, S, HiLo);
 }
-void localWeightedSumDD(const Real *W, const Real *A, const Real *B, int NRows, int K, hipStream_t S, double HiLo[2]) {
+void localWeightedSumDD(const Real *W, const Real *A, const Real *B, int NRows, int K, int Pitch, hipStream_t S,
+                        double HiLo[2]) {
    const size_t N = (size_t)NRows * K;
    const int NB   = (int)std::min<size_t>(1024, (N + 255) / 256 ? (N + 255) / 256 : 1);
    DD *PartialD   = nullptr;
    HIP_CHECK(hipMalloc(&PartialD, NB * sizeof(DD)));
-   hipLaunchKernelGGL(weightedSumDDKernel, dim3(NB), dim3(256), 0, S, W, A, B, NRows, K, PartialD);
+   hipLaunchKernelGGL(weightedSumDDKernel, dim3(NB), dim3(256), 0, S, W, A, B, NRows, K, Pitch, PartialD);
    HIP_CHECK(hipGetLastError());
    finishDD(PartialD, NB, S, HiLo);
 }

@@ -64,13 +64,15 @@ def test_rk4_conserves_volume_and_tracer_content_in_double_double():
     P = Problem(planar_hex(48, 40, 30.0e3), 20, 2, oracle=False)
     m = P.mesh
     nc, K = m.NCellsOwned, 20
+    KP = oa.level_pitch(K)      # the library's own arrays pad 20 levels to 32 (whole cache lines)
+    assert KP == 32
     area = oa.DeviceBuffer(m.get_array("AreaCell"))
 
     def content():
         hp = P.state.device_ptr(0, 0)
-        vol = oa.local_weighted_sum_dd(area.ptr, hp, nc, K)[0]
-        trs = [oa.local_weighted_sum_dd(area.ptr, hp, nc, K, P.tracers.device_ptr(0) + 8 * l * m.NCellsSize * K)[0]
-               for l in range(2)]
+        vol = oa.local_weighted_sum_dd(area.ptr, hp, nc, K, row_pitch=KP)[0]
+        trs = [oa.local_weighted_sum_dd(area.ptr, hp, nc, K, P.tracers.device_ptr(0) + 8 * l * m.NCellsSize * KP,
+                                        row_pitch=KP)[0] for l in range(2)]
         return vol, trs
     v0, t0 = content()
     h0, _ = P.state.copy_to_host(0)

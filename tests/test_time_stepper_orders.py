@@ -70,8 +70,8 @@ def test_hip_time_steppers_converge_at_their_order(kind, okind, order):
     oa.device_init(0)
     P = Problem(planar_hex(8, 8, 30e3), 1, 1, config=ALL_OFF)
 
-    def decay(tend, h, u, nall, nsize, k, t, stream):   # NormalVelTend(IEdge, K) -= Coeff * NormalVelEdge(IEdge, K)
-        oa.update_by_tend(tend, tend, u, -COEFF, nall, k, stream)
+    def decay(tend, h, u, nall, nsize, k, pitch, t, stream):   # NormalVelTend(IEdge, K) -= Coeff * NormalVelEdge(IEdge, K)
+        oa.update_by_tend(tend, tend, u, -COEFF, nall, pitch, stream)     # rows of `pitch` values (padding swept too)
     P.tend.set_custom_tendency(1, decay)
     errs = []
     for dt0 in (BASE_DT, BASE_DT / 2):
