@@ -258,6 +258,13 @@ int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t 
 int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out);
 int omg_tend_destroy(omg_tend *t);
 int omg_tend_set_fused(omg_tend *t, int use_fused_rhs);
+/* HIP-graph replay of launch-bound sequences (default on): the fused RHS (omg_tend_compute_all) and, on one rank, the
+ * stage-fused RK4 step (omg_stepper_do_step; option "UseGraphs") are captured the second time they are called with
+ * the same arrays on the same NON-default stream and replayed afterwards with one host call.  Kernel timing and
+ * custom tendencies switch it off.  *_graph_stats: graphs captured / replays so far. */
+int omg_tend_set_graphs(omg_tend *t, int use_graphs);
+int omg_tend_graph_stats(const omg_tend *t, int64_t *captures, int64_t *replays);
+int omg_stepper_graph_stats(const omg_stepper *st, int64_t *captures, int64_t *replays);
 int omg_tend_compute_all(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr, int tracer_time_level,
                          int thick_time_level, int vel_time_level, void *stream);
 int omg_tend_compute_thickness(omg_tend *t, const omg_state *s, omg_aux *a, int thick_time_level,
@@ -319,7 +326,7 @@ int omg_stepper_get_time(const omg_stepper *st, double *seconds);
  * epilogue of the RHS kernels, same arithmetic) and "StoreStageTendencies" (default 0: with fused stages the
  * Tendencies arrays are not written), "OverlapHaloExchange" (default 1: with fused stages and neighbours, each
  * exchange starts when the band of cells whose values travel is final and runs on a communication stream
- * while the stage's interior cells are computed).  0 / 1. */
+ * while the stage's interior cells are computed), "UseGraphs" (default 1, see omg_tend_set_graphs).  0 / 1. */
 int omg_stepper_set_option(omg_stepper *st, const char *name, int value);
 /* TimeStepper::changeTimeStep (O/src/timeStepping/TimeStepper.h:141-143) */
 int omg_stepper_change_time_step(omg_stepper *st, double time_step_seconds);

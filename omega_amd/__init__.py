@@ -745,6 +745,14 @@ class Tendencies:
     def set_fused(self, on: bool):
         _chk(lib().omg_tend_set_fused(self.h, int(on)))
 
+    def set_graphs(self, on: bool):
+        _chk(lib().omg_tend_set_graphs(self.h, int(on)))
+
+    def graph_stats(self):
+        c, r = C.c_int64(), C.c_int64()
+        _chk(lib().omg_tend_graph_stats(self.h, C.byref(c), C.byref(r)))
+        return {"captures": c.value, "replays": r.value}
+
     def compute_all_tendencies(self, state, aux, tracers, tracer_tl=0, thick_tl=0, vel_tl=0, stream=None):
         _chk(lib().omg_tend_compute_all(self.h, state.h, aux.h, tracers.h, tracer_tl, thick_tl, vel_tl, _sh(stream)))
 
@@ -849,6 +857,11 @@ class TimeStepper:
         v = C.c_double()
         _chk(lib().omg_stepper_get_time(self.h, C.byref(v)))
         return v.value
+
+    def graph_stats(self):
+        c, r = C.c_int64(), C.c_int64()
+        _chk(lib().omg_stepper_graph_stats(self.h, C.byref(c), C.byref(r)))
+        return {"captures": c.value, "replays": r.value}
 
     def change_time_step(self, dt: float):
         _chk(lib().omg_stepper_change_time_step(self.h, C.c_double(dt)))

@@ -236,6 +236,7 @@ void HorzMesh::buildCoefficientTables() {
          VortC(V, J) = InvAreaTriangle * DcEdgeH(E) * EdgeSignOnVertexH(V, J);  // VorticityAuxVars.h:44-45
       }
    }
+   HostKiteC = KiteC, HostVortC = VortC;
    HostArrayReal IDc(NEdgesSize, 1, 1, 0.0), IDv(NEdgesSize, 1, 1, 0.0), IDv2(NEdgesSize, 1, 1, 0.0);
    HostArrayI4 PVS(NEdgesSize, ME2, 4, 0);
    for (int E = 0; E < NEdgesSize; ++E)
@@ -384,10 +385,11 @@ void HorzMesh::buildCoefficientTables() {
    HostChW = ChW;
    buildCellPV();
    buildDel2Tables();
+   buildCellL1Tables();
    buildBandLists((I4)NCellsHaloH.size());
    // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
    if (const char *Fg = getenv("OMEGA_FORCE_GENERIC"); Fg && atoi(Fg) == 1)
-      W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = 0;
+      W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = W.CellL1OK = 0;
 }
 
 // Band / interior split of the local cells for overlapping a halo exchange with interior work
@@ -519,6 +521,7 @@ void HorzMesh::buildDel2Tables() {
          IDcV(V, J)  = 1. / DcEdgeH(E);
          CurlV(V, J) = -SV * InvDv2(E);
       }
+   HostVertRing         = Ring;
    VertRingOnCell       = createDeviceMirrorCopy<I4, 2>("VertRingOnCell", Ring);
    Del2GradMaskSOnCell  = createDeviceMirrorCopy<Real, 2>("Del2GradMaskSOnCell", GradS);
    InvDcOnCell          = createDeviceMirrorCopy<Real, 2>("InvDcOnCell", IDcC);
@@ -534,6 +537,84 @@ void HorzMesh::buildDel2Tables() {
    W.NbrVertOnVertex = NbrVertOnVertex.Ptr, W.Del2SelOnVertex = Del2SelOnVertex.Ptr;
    W.Del2MaskOnVertex = Del2MaskOnVertex.Ptr, W.InvDcOnVertex = InvDcOnVertex.Ptr;
    W.Del2CurlCoefOnVertex = Del2CurlCoefOnVertex.Ptr;
+}
+
+// Vertex quantities from the cell side (see HorzMesh.h: CellL1OK).
+void HorzMesh::buildCellL1Tables() {
+   const int ME = MaxEdges, VD = VertexDegree;
+   MeshView &W = View;
+   HostArrayI4 Spoke(NCellsSize, ME, 1, NEdgesAll), Sel(NCellsSize, ME, 1, 0x3f | (0x3f << 6));
+   HostArrayReal KC(NCellsSize, ME, 3, 0.0), VC(NCellsSize, ME, 3, 0.0);
+   bool OK = W.Del2RingOK != 0 && VD == 3;
+   std::vector<I4> Owner(NVerticesAll, -1), OwnerSlot(NVerticesAll, -1), NOwned(NCellsAll, 0);
+   for (int C = 0; C < NCellsAll && OK; ++C) {
+      const int N = NEdgesOnCellH(C);
+      for (int R = 0; R < N && OK; ++R) {
+         const int V  = HostVertRing(C, R);
+         const int E0 = EdgesOnCellH(C, R), E1 = EdgesOnCellH(C, (R + 1) % N);
+         const int N0 = HostNbrF(C, R) & 0x3fffffff, N1 = HostNbrF(C, (R + 1) % N) & 0x3fffffff;
+         int Code = 0, Sp = NEdgesAll;
+         for (int J = 0; J < 3 && OK; ++J) {
+            const int Cv = CellsOnVertexH(V, J), Ev = EdgesOnVertexH(V, J);
+            int Sc, Se;
+            if (Cv == C)
+               Sc = 0;
+            else if (Cv < NCellsAll && Cv == N0)
+               Sc = 1;
+            else if (Cv < NCellsAll && Cv == N1)
+               Sc = 2;
+            else if (Cv >= NCellsAll)
+               Sc = 3; // no such cell here: the vertex kernel reads the zero sentinel row
+            else {
+               OK = false;
+               break;
+            }
+            if (Ev == E0)
+               Se = 0;
+            else if (Ev == E1)
+               Se = 1;
+            else if (Ev >= NEdgesAll)
+               Se = 3;
+            else if (Sp == NEdgesAll || Sp == Ev)
+               Se = 2, Sp = Ev;
+            else {
+               OK = false;
+               break;
+            }
+            Code |= (Sc << (2 * J)) | (Se << (6 + 2 * J));
+            KC.V[((size_t)C * ME + R) * 3 + J] = HostKiteC(V, J);
+            VC.V[((size_t)C * ME + R) * 3 + J] = HostVortC(V, J);
+         }
+         // the spoke must really be the edge between the two neighbours (or absent)
+         Spoke(C, R) = Sp;
+         Sel(C, R)   = Code;
+         // ownership: the cell with the fewest stores so far among those that see the vertex
+         if (Owner[V] < 0 || NOwned[C] < NOwned[Owner[V]] - 1) {
+            if (Owner[V] >= 0)
+               --NOwned[Owner[V]];
+            Owner[V] = C, OwnerSlot[V] = R;
+            ++NOwned[C];
+         }
+      }
+   }
+   for (int V = 0; V < NVerticesAll && OK; ++V) {
+      if (Owner[V] < 0)
+         OK = false; // a local vertex no local cell has in its ring
+      else
+         Sel(Owner[V], OwnerSlot[V]) |= 1 << 12;
+   }
+   SpokeOnCell    = createDeviceMirrorCopy<I4, 2>("SpokeOnCell", Spoke);
+   VortSelOnCell  = createDeviceMirrorCopy<I4, 2>("VortSelOnCell", Sel);
+   KiteCoefOnCell = createDeviceMirrorCopy<Real, 3>("KiteCoefOnCell", KC);
+   VortCoefOnCell = createDeviceMirrorCopy<Real, 3>("VortCoefOnCell", VC);
+   W.SpokeOnCell = SpokeOnCell.Ptr, W.VortSelOnCell = VortSelOnCell.Ptr;
+   W.KiteCoefOnCell = KiteCoefOnCell.Ptr, W.VortCoefOnCell = VortCoefOnCell.Ptr;
+   // the PV tables number the ring the same way (they are only filled for cells that own regular edges)
+   for (int C = 0; C < NCellsAll && OK; ++C)
+      for (int R = 0; R < NEdgesOnCellH(C); ++R)
+         if (HostPVRole(C, R) != 0 && HostPVRing(C, R) != HostVertRing(C, R))
+            OK = false;
+   W.CellL1OK = OK && W.CellPVOK ? 1 : 0;
 }
 
 // Cell-centric PV tables (see HorzMesh.h).
@@ -606,6 +687,7 @@ void HorzMesh::buildCellPV() {
    }
    RingSignOnCell = createDeviceMirrorCopy<Real, 2>("RingSignOnCell", RSign);
    W.RingSignOnCell = RingSignOnCell.Ptr, W.CellPVFinalOK = FinalOK ? 1 : 0;
+   HostPVRing = Ring, HostPVRole = Role;
    RingVertOnCell = createDeviceMirrorCopy<I4, 2>("RingVertOnCell", Ring);
    PVRoleOnCell   = createDeviceMirrorCopy<I4, 2>("PVRoleOnCell", Role);
    PVWeightOnCell = createDeviceMirrorCopy<Real, 3>("PVWeightOnCell", Wt);

@@ -93,6 +93,20 @@ struct MeshView {
    // cells of the rarer valences that own regular edges: the ring kernels run once more over each list
    I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges (no list: full sweep), MaxEdges-1, MaxEdges-2
    const I4 *RingCellsM1, *RingCellsM2;
+   // ---- vertex quantities evaluated from the cell side (valid when CellL1OK; HorzMesh::buildCellL1Tables) ----
+   // Ring vertex r of cell c (shared by edge slots r and r+1) touches the cells {c, across slot r, across slot r+1}
+   // and the edges {slot r, slot r+1, "spoke" = the edge between the two neighbours}.  A thread that already holds
+   // h at the cell and its neighbours and u on its edges therefore only gathers the spokes to evaluate
+   // VorticityAuxVars::computeVarsOnVertex at all its ring vertices -- with the vertex's own coefficients and in
+   // the vertex's own slot order (selectors below), so the bits equal the vertex kernel's.  Every vertex is
+   // stored by exactly one of its cells (own bit).
+   I4 CellL1OK;
+   const I4 *SpokeOnCell;          // [C][ME] third edge of ring vertex r (sentinel row if it has none here)
+   const I4 *VortSelOnCell;        // [C][ME] bits 2j..2j+1: which register holds CellsOnVertex(v,j): 0 self, 1 nbr r,
+                                   //   2 nbr r+1, 3 none (zero row); bits 6+2j..7+2j: EdgesOnVertex(v,j): 0 slot r,
+                                   //   1 slot r+1, 2 spoke, 3 none; bit 12: this cell stores vertex v
+   const Real *KiteCoefOnCell;     // [C][ME][3] KiteCoefOnVertex(v, 0..2)
+   const Real *VortCoefOnCell;     // [C][ME][3] VortCoefOnVertex(v, 0..2)
    // ---- overlap of halo exchanges with interior work (HorzMesh::buildBandLists) ----
    // BandCells: every halo cell and every owned cell within HaloWidth+1 cells of one (a superset of the cells
    // that own anything a neighbour receives); InteriorCells: the other owned cells.  Ascending order.
@@ -165,6 +179,11 @@ class HorzMesh {
    Array3DReal PVChainWeight;
    void buildCellPV();
    void buildDel2Tables();
+   void buildCellL1Tables();
+   HostArrayI4 HostVertRing, HostPVRing, HostPVRole;
+   HostArrayReal HostKiteC, HostVortC;
+   Array2DI4 SpokeOnCell, VortSelOnCell;
+   Array3DReal KiteCoefOnCell, VortCoefOnCell;
    Array2DI4 RingVertOnCell, PVRoleOnCell;
    Array3DReal PVWeightOnCell;
    Array1DI4 EdgeRegular, IrregularEdges;

@@ -135,9 +135,21 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
             HIP_CHECK(hipEventCreate(&E));
          Ev = TimingEvents.back().data();
       }
-      launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
-                     NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
-                     EdgeScratch.Ptr);
+      const TendParams P = paramsFor(Aux);
+      auto Launch        = [&]() {
+         launchFusedRHS(Mesh->view(), NVertLayers, NTracers, P, Aux->ptrs(), LayerThicknessTend.Ptr,
+                        NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
+                        EdgeScratch.Ptr);
+      };
+      // wind forcing reads the stress arrays through a non-tile kernel too, still plain launches: capturable
+      if (UseGraphs && !Ev && !CustomThicknessTend && !CustomVelocityTend) {
+         GraphCache::Key Key;
+         GraphCache::add(Key, LayerThick.Ptr), GraphCache::add(Key, NormVel.Ptr), GraphCache::add(Key, TracerArray.Ptr);
+         GraphCache::add(Key, Aux), GraphCache::add(Key, P), GraphCache::add(Key, S);
+         Graphs.run(Key, S, Launch);
+      } else {
+         Launch();
+      }
       if (CustomThicknessTend)
          CustomThicknessTend(LayerThicknessTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
       if (CustomVelocityTend)

@@ -8,6 +8,7 @@
 
 #include "AuxiliaryState.h"
 #include "Base.h"
+#include "GraphCache.h"
 #include "kernels/Kernels.h"
 
 #include <functional>
@@ -26,6 +27,10 @@ class Tendencies {
    /// Fused RHS for computeAllTendencies (default on); off = the reference's launch
    /// structure (every AuxiliaryState array materialised).
    bool UseFusedRHS = true;
+   /// Replay the fused RHS as a HIP graph when it is called again with the same arrays on a non-default stream
+   /// (GraphCache.h): one host call instead of 7 launches.  Off while kernel timing or custom tendencies are on.
+   bool UseGraphs = true;
+   GraphCache Graphs;
 
    /// Custom tendencies (Tendencies.h:51-53, 182-183): called at the end of the thickness / velocity
    /// group with the tendency array, the state / aux state, the two time levels and the model time

@@ -310,6 +310,8 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
    const bool Exchanges  = MeshHalo && MeshHalo->NNghbr > 0;
    const bool Overlap    = Exchanges && OverlapHaloExchange;
    ExchangeJob Job{this, S, {}, {}, nullptr, NT};
+   bool FirstStageOk = true;
+   auto RunStages    = [&]() {
    for (int Stage = 0; Stage < NStages; ++Stage) {
       StageUpdate Su;
       Su.CB        = coeff(RKB[Stage]);
@@ -335,8 +337,10 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
       bool Ok;
       if (Stage == 0) {
          Ok = Tend->computeAllTendenciesStage(State, AuxState, CurTr, CurLevel, CurLevel, Su, S);
-         if (!Ok)
-            return false; // nothing has been touched: the caller runs the plain sequence
+         if (!Ok) {
+            FirstStageOk = false; // nothing has been touched: the caller runs the plain sequence
+            return;
+         }
       } else {
          OceanState *In = Prov[(Stage - 1) % 2];
          if (Stage == 2 && Exchanges) { // depends on the halo width (:107-113)
@@ -353,6 +357,25 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
          OMEGA_REQUIRE(Ok, "RungeKutta4: stage-fused RHS became unavailable mid-step");
       }
    }
+   };
+   if (!Exchanges && UseGraphs && StageFusedKnownGood && !Tend->CustomThicknessTend && !Tend->CustomVelocityTend) {
+      // one rank: nothing but kernel launches on S -- replay them as a graph (keyed by everything that enters them)
+      GraphCache::Key Key;
+      GraphCache::add(Key, State), GraphCache::add(Key, CurH.Ptr), GraphCache::add(Key, NextH.Ptr);
+      GraphCache::add(Key, CurU.Ptr), GraphCache::add(Key, NextU.Ptr), GraphCache::add(Key, CurTr.Ptr);
+      GraphCache::add(Key, NextTr.Ptr), GraphCache::add(Key, TimeStep), GraphCache::add(Key, (int)StoreStageTendencies);
+      GraphCache::add(Key, Tend), GraphCache::add(Key, AuxState), GraphCache::add(Key, Tend->Params), GraphCache::add(Key, S);
+      GraphCache::add(Key, (int)Tend->UseFusedRHS);
+      GraphCache::add(Key, (int)AuxState->LayerThicknessAux.FluxThickEdgeChoice);
+      GraphCache::add(Key, (int)AuxState->TracerAux.TracersOnEdgeChoice);
+      GraphCache::add(Key, (int)AuxState->WindForcingAux.InterpChoice);
+      Graphs.run(Key, S, RunStages);
+   } else {
+      RunStages();
+   }
+   if (!FirstStageOk)
+      return false;
+   StageFusedKnownGood = true;
    if (Overlap) { // the end-of-step exchange was started by the last stage: wait for it, then rotate
       joinExchange(S);
       State->rotateTimeLevels();

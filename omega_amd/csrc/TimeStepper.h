@@ -9,6 +9,7 @@
 #define OMEGA_AMD_TIMESTEPPER_H
 
 #include "AuxiliaryState.h"
+#include "GraphCache.h"
 #include "Halo.h"
 #include "OceanState.h"
 #include "Tendencies.h"
@@ -114,6 +115,10 @@ class RungeKutta4Stepper : public TimeStepper {
    /// travel is final and let it run on a communication stream while the stage's interior cells are still
    /// being computed (kernels/Kernels.h: StageUpdate::AfterBand); the next consumer waits on an event.
    bool OverlapHaloExchange   = true;
+   /// Without neighbours (one rank) the 28 launches of a stage-fused step are replayed as one HIP graph per
+   /// time-level parity when the step runs on a non-default stream (GraphCache.h).
+   bool UseGraphs             = true;
+   GraphCache Graphs;
    ~RungeKutta4Stepper() override;
 
  protected:
@@ -121,6 +126,7 @@ class RungeKutta4Stepper : public TimeStepper {
    std::unique_ptr<OceanState> ProvisState2;
    Array3DReal ProvisTracers2;
    bool doStepFused(OceanState *State, hipStream_t S);
+   bool StageFusedKnownGood = false; ///< a direct (un-captured) stage-fused step has succeeded on this configuration
    // overlapped exchange: communication stream, "band is final" and "halo is in place" events
    hipStream_t CommStream = nullptr;
    hipEvent_t EvBand = nullptr, EvDone = nullptr;

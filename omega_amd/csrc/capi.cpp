@@ -547,6 +547,7 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
       const MeshView &W = M.view();
       const std::map<std::string, I4> D{{"PVChainOK", W.PVChainOK},
                                         {"CellPVOK", W.CellPVOK},
+                                        {"CellL1OK", W.CellL1OK},
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
                                         {"Del2RingOK", W.Del2RingOK},
@@ -928,6 +929,31 @@ int omg_tend_set_fused(omg_tend *t, int use_fused_rhs) {
    t->T->UseFusedRHS = use_fused_rhs != 0;
    OMG_CATCH
 }
+int omg_tend_set_graphs(omg_tend *t, int use_graphs) {
+   OMG_TRY
+   OMG_ARG(t);
+   t->T->UseGraphs = use_graphs != 0;
+   OMG_CATCH
+}
+int omg_tend_graph_stats(const omg_tend *t, int64_t *captures, int64_t *replays) {
+   OMG_TRY
+   OMG_ARG(t);
+   if (captures)
+      *captures = t->T->Graphs.NCaptures;
+   if (replays)
+      *replays = t->T->Graphs.NReplays;
+   OMG_CATCH
+}
+int omg_stepper_graph_stats(const omg_stepper *st, int64_t *captures, int64_t *replays) {
+   OMG_TRY
+   OMG_ARG(st);
+   auto *Rk4 = dynamic_cast<RungeKutta4Stepper *>(st->St.get());
+   if (captures)
+      *captures = Rk4 ? Rk4->Graphs.NCaptures : 0;
+   if (replays)
+      *replays = Rk4 ? Rk4->Graphs.NReplays : 0;
+   OMG_CATCH
+}
 int omg_tend_compute_all(omg_tend *t, const omg_state *s, omg_aux *a, const omg_tracers *tr, int trtl, int ttl,
                          int vtl, void *stream) {
    OMG_TRY
@@ -1132,6 +1158,8 @@ int omg_stepper_set_option(omg_stepper *st, const char *name, int value) {
       Rk4->StoreStageTendencies = value != 0;
    else if (Rk4 && N == "OverlapHaloExchange")
       Rk4->OverlapHaloExchange = value != 0;
+   else if (Rk4 && N == "UseGraphs")
+      Rk4->UseGraphs = value != 0;
    else
       OMEGA_ABORT("TimeStepper: no option named " + N + " for this scheme");
    OMG_CATCH

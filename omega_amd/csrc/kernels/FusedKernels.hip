@@ -231,6 +231,211 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
 };
 
 // ---------------------------------------------------------------------------------------
+// L1 cell pass with the vertex pass and the side-0 PV sums folded in (HorzMesh.h: CellL1OK).
+//
+// The thread of (cell, levels) already holds h at the cell and its neighbours and u on its edges.  With u on the
+// TME "spoke" edges (the edges between consecutive neighbours) it evaluates VorticityAuxVars::computeVarsOnVertex
+// (VorticityAuxVars.h:24-59) at ALL its ring vertices -- the vertex's own coefficients, added in the vertex's own
+// slot order, so each value has the bits the vertex kernel produces, whichever of the three cells around the
+// vertex computes it -- stores the vertices it owns (RelVort, 1/LayerThickVertex), and goes straight on to the
+// side-0 half of PotentialVortHAdvOnEdge (CellPVBody<.., 0>) with the normalised vorticities still in registers.
+// Against VortVertexBody + FusedCell1Body + CellPVBody<side 0> this reads h and u once instead of three times and
+// never re-reads the two vertex arrays: 96 B per cell-level less HBM traffic and two launches less.
+template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
+   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int MaxW     = OMEGA_CELL_MAXW;
+   static constexpr int TM1      = TME - 1;
+   MeshView M;
+   int K, NT;
+   TendParams P;
+   int DoDel2Tr;
+   const Real *H, *U, *Tr;
+   Real *KE, *Div, *HTend, *Del2Tr, *RelVortV, *InvThickV, *Partial;
+   StageEpi E{}; // thickness stage update (EPI)
+   struct Lds {
+      Real *KEC, *DivC, *DvS, *D2T, *InvA, *Wt, *FV, *KC, *VC;
+      int *Edge, *NbrF, *Spoke, *Sel, *Ring, *Role, *N;
+   };
+   size_t ldsBytes(int Tile) const {
+      return ldsRound8(sizeof(Real) * Tile * TME) * 5 + ldsRound8(sizeof(Real) * Tile) +
+             ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME * 3) * 2 +
+             ldsRound8(sizeof(int) * Tile * TME) * 6 + ldsRound8(sizeof(int) * Tile);
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.KEC   = C.take<Real>(Tile * TME);
+      L.DivC  = C.take<Real>(Tile * TME);
+      L.DvS   = C.take<Real>(Tile * TME);
+      L.D2T   = C.take<Real>(Tile * TME);
+      L.FV    = C.take<Real>(Tile * TME);
+      L.InvA  = C.take<Real>(Tile);
+      L.Wt    = C.take<Real>(Tile * TME * TM1);
+      L.KC    = C.take<Real>(Tile * TME * 3);
+      L.VC    = C.take<Real>(Tile * TME * 3);
+      L.Edge  = C.take<int>(Tile * TME);
+      L.NbrF  = C.take<int>(Tile * TME);
+      L.Spoke = C.take<int>(Tile * TME);
+      L.Sel   = C.take<int>(Tile * TME);
+      L.Ring  = C.take<int>(Tile * TME);
+      L.Role  = C.take<int>(Tile * TME);
+      L.N     = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const size_t G = (size_t)First * TME + I;
+         L.KEC[I]       = M.KECoefOnCell[G];
+         L.DivC[I]      = M.DivCoefOnCell[G];
+         L.DvS[I]       = M.DvSignOnCell[G];
+         L.D2T[I]       = Fast ? M.Del2TrCoefSOnCell[G] : M.Del2TrCoefOnCell[G];
+         L.Edge[I]      = M.EdgesOnCell[G];
+         L.NbrF[I]      = M.NbrFlagOnCell[G];
+         L.Spoke[I]     = M.SpokeOnCell[G];
+         L.Sel[I]       = M.VortSelOnCell[G];
+         L.Ring[I]      = M.VertRingOnCell[G];
+         L.FV[I]        = M.FVertex[M.VertRingOnCell[G]];
+         L.Role[I]      = M.PVRoleOnCell[G];
+      }
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
+         L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
+      for (int I = Tid; I < Cnt * TME * 3; I += NThr) {
+         L.KC[I] = M.KiteCoefOnCell[(size_t)First * TME * 3 + I];
+         L.VC[I] = M.VortCoefOnCell[(size_t)First * TME * 3 + I];
+      }
+      for (int I = Tid; I < Cnt; I += NThr) {
+         L.InvA[I] = M.InvAreaCell[First + I];
+         L.N[I]    = M.NEdgesOnCell[First + I];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+      const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
+      const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
+      const Real InvA       = L.InvA[Le];
+      const int N           = L.N[Le];
+      const unsigned OffS   = rowOff<T>(ICell, K, Kv);
+      unsigned OffN[TME], OffE[TME];
+      bool IsC0[TME];
+      T Ue[TME], Hn[TME], Usp[TME];
+#pragma unroll
+      for (int J = 0; J < TME; ++J) {
+         const int F = L.NbrF[Le * TME + J];
+         OffN[J]     = rowOff<T>(F & 0x3fffffff, K, Kv);
+         IsC0[J]     = (F >> 30) != 0;
+         OffE[J]     = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
+         Ue[J]       = ldo<T>(U, OffE[J]);
+         Hn[J]       = ldo<T>(H, OffN[J]);
+         Usp[J]      = ldo<T>(U, rowOff<T>(L.Spoke[Le * TME + J], K, Kv));
+      }
+      const T Hs = ldo<T>(H, OffS);
+      // ---- KineticAuxVars / ThicknessFluxDivOnCell: exactly FusedCell1Body ----
+      T HMeanJ[TME], Flux[TME];
+      {
+         T KETmp = splat<T>(0.0), DivTmp = splat<T>(0.0), HDivTmp = splat<T>(0.0);
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            const T Mean = 0.5 * (Hs + Hn[J]); // 0.5*(h(c0)+h(c1)): a+b == b+a
+            HMeanJ[J]    = Mean;
+            Flux[J]      = Mean;
+            if (FluxUpwind)
+               Flux[J] = upwind(Ue[J], pick(IsC0[J], Hs, Hn[J]), pick(IsC0[J], Hn[J], Hs));
+            KETmp += L.KEC[Le * TME + J] * Ue[J] * Ue[J];
+            DivTmp -= L.DivC[Le * TME + J] * Ue[J];
+            HDivTmp -= L.DvS[Le * TME + J] * Flux[J] * Ue[J] * InvA;
+         }
+         stnt<T>(KE, OffS, KETmp);
+         stnt<T>(Div, OffS, DivTmp);
+         T HT = splat<T>(0.0);
+         if (ThickOn)
+            HT -= HDivTmp;
+         if (!EPI || E.StoreTend)
+            stnt<T>(HTend, OffS, HT);
+         if (EPI)
+            stageUpdate<T, true>(E, OffS, HT, Hs);
+      }
+      // ---- VorticityAuxVars::computeVarsOnVertex at every ring vertex (VorticityAuxVars.h:24-59) ----
+      T QR[TME], QF[TME];
+      {
+         const T Zero = splat<T>(0.0);
+#pragma unroll
+         for (int R = 0; R < TME; ++R) {
+            // the slot after R in this cell's own cyclic order (cells of fewer than TME edges wrap earlier)
+            const bool Wrap = (R + 1 >= TME) || (R + 1 >= N);
+            const T HnN = pick(Wrap, Hn[0], Hn[(R + 1) % TME]);
+            const T UeN = pick(Wrap, Ue[0], Ue[(R + 1) % TME]);
+            const int Sel = L.Sel[Le * TME + R];
+            T LayerThickVertex = splat<T>(0.0), RelVortTmp = splat<T>(0.0);
+#pragma unroll
+            for (int J = 0; J < 3; ++J) {
+               const int Sc = (Sel >> (2 * J)) & 3, Se = (Sel >> (6 + 2 * J)) & 3;
+               const T Hc = pick(Sc == 0, Hs, pick(Sc == 1, Hn[R], pick(Sc == 2, HnN, Zero)));
+               const T Uv = pick(Se == 0, Ue[R], pick(Se == 1, UeN, pick(Se == 2, Usp[R], Zero)));
+               LayerThickVertex += L.KC[(Le * TME + R) * 3 + J] * Hc;
+               RelVortTmp += L.VC[(Le * TME + R) * 3 + J] * Uv;
+            }
+            const T Inv = 1. / LayerThickVertex;
+            if ((Sel >> 12) & 1) { // this cell stores the vertex
+               const unsigned OffV = rowOff<T>(L.Ring[Le * TME + R], K, Kv);
+               sto<T>(RelVortV, OffV, RelVortTmp);
+               sto<T>(InvThickV, OffV, Inv);
+            }
+            QR[R] = RelVortTmp * Inv;       // NormRelVortVertex   (:50-51)
+            QF[R] = L.FV[Le * TME + R] * Inv; // NormPlanetVortVertex (:52-53)
+         }
+      }
+      // ---- side-0 half of PotentialVortHAdvOnEdge: exactly CellPVBody<TME, Fast, 0> ----
+      if (N == TME) {
+         bool Any = false;
+#pragma unroll
+         for (int J = 0; J < TME; ++J)
+            Any |= L.Role[Le * TME + J] == 1;
+         if (Any) {
+            T QRe[TME], QFe[TME];
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const int Jm = (J + TME - 1) % TME;
+               QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
+               QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
+            }
+#pragma unroll
+            for (int I = 0; I < TME; ++I) {
+               if (L.Role[Le * TME + I] != 1)
+                  continue;
+               T Acc = splat<T>(0.0);
+#pragma unroll
+               for (int J = 1; J < TME; ++J) {
+                  const int Kk     = (I + J) % TME;
+                  const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
+                  Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Ue[Kk] * NormVort;
+               }
+               sto<T>(Partial, OffE[I], Acc);
+            }
+         }
+      }
+      // ---- TracerAuxVars::computeVarsOnCells: exactly FusedCell1Body ----
+      if (DoDel2Tr) {
+         const size_t CStride = (size_t)M.NCellsSize * K;
+#pragma nounroll
+         for (int Lt = 0; Lt < NT; ++Lt) {
+            const Real *TrL = uniformPtr(Tr + Lt * CStride);
+            T Tn[TME];
+#pragma unroll
+            for (int J = 0; J < TME; ++J)
+               Tn[J] = ldo<T>(TrL, OffN[J]);
+            const T Ts = ldo<T>(TrL, OffS);
+            T Tmp      = splat<T>(0.0);
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const T Grad = Fast ? T(Tn[J] - Ts) : T(pick(IsC0[J], Tn[J], Ts) - pick(IsC0[J], Ts, Tn[J]));
+               Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
+            }
+            stnt<T>(uniformPtr(Del2Tr + Lt * CStride), OffS, Tmp * InvA);
+         }
+      }
+   }
+};
+
+// ---------------------------------------------------------------------------------------
 // L2 cell pass: VelocityDel2AuxVars::computeVarsOnCell (VelocityDel2AuxVars.h:47-67) with
 // Del2Edge (computeVarsOnEdge, :21-45) evaluated inline at each edge of the cell.
 struct FusedDel2CellBody {
@@ -1341,7 +1546,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
 };
 
 
-const char *FusedKernelNames[FusedNumKernels] = {"VortVertexBody", "FusedCell1Body", "", "", "", "", ""};
+const char *FusedKernelNames[FusedNumKernels] = {"", "", "", "", "", "", ""};
 
 /// Default.yml term set: every flag folds at compile time (see `Fast` above)
 static bool isDefaultTermSet(const TendParams &P) {
@@ -1383,12 +1588,37 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // them where they are consumed; without the cell-centric tables the edge kernels read the reference's arrays
    static const int EdgeModeV = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
    const bool CellCentric     = EdgeModeV == 0 && M.CellPVOK && EdgeScratch;
-   launchVertexAuxState1(M, K, A, H, U, S, /*StoreNorm*/ !CellCentric, /*StoreInv*/ CellCentric);
+   // vertex pass and side-0 PV sums inside the L1 cell kernel (OMEGA_MERGE_L1=0: the three separate kernels)
+   static const int MergeL1Env = getenv("OMEGA_MERGE_L1") ? atoi(getenv("OMEGA_MERGE_L1")) : 1;
+   const bool MergeL1 = CellCentric && M.CellL1OK && P.PVTendencyEnable && MergeL1Env != 0 &&
+                        (Fast || TME <= 7); // (8 edge slots with run-time option flags would spill registers)
+   FusedKernelNames[0]        = MergeL1 ? "" : "VortVertexBody";
+   FusedKernelNames[1]        = MergeL1 ? "FusedCellL1PVBody" : "FusedCell1Body";
+   if (!MergeL1)
+      launchVertexAuxState1(M, K, A, H, U, S, /*StoreNorm*/ !CellCentric, /*StoreInv*/ CellCentric);
    Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    bool Cell1Done = false;
+   if (MergeL1) {
+      auto LaunchL1 = [&](auto Epi) {
+         constexpr bool EP = decltype(Epi)::value;
+         FusedCellL1PVBody<TME, Fast, EP> B{M,  K,  NT,    P,      DoDel2Tr,        H,
+                                            U,  Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
+                                            A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
+         launchTile(B, M.NCellsAll, K, S);
+      };
+      if constexpr (Fast) {
+         if (Stage)
+            LaunchL1(std::true_type{});
+         else
+            LaunchL1(std::false_type{});
+      } else {
+         LaunchL1(std::false_type{});
+      }
+      Cell1Done = true;
+   }
    if constexpr (Fast) {
-      if (Stage) {
+      if (Stage && !Cell1Done) {
          FusedCell1Body<TME, true, true> B{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell,
                                            HTend, A.Del2TracersCell, EH};
          launchTile(B, M.NCellsAll, K, S);
@@ -1442,9 +1672,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          // maxEdges = 6 or 7) run the same ring code, instantiated for their size, over cell lists
          constexpr int NM1 = TME - 1, NM2 = TME >= 6 ? TME - 2 : TME - 1;
          CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
-         if (M.NRingCellsM0 > 0)
+         if (M.NRingCellsM0 > 0 && !MergeL1) // (merged: done by the L1 kernel; only the rarer valences remain)
             launchTile(B0, M.NCellsAll, K, S);
-         FusedKernelNames[4] = "CellPVBody<side 0>";
+         FusedKernelNames[4] = (!MergeL1 || M.NRingCellsM1 > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVBody<side 0>" : "";
          if (M.NRingCellsM1 > 0) {
             CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                              M.RingCellsM1};

@@ -378,3 +378,46 @@ def test_bench_shaped_problem_against_the_oracle():
     check("h", h, ost["h"][0], m.NCellsOwned)
     check("u", u, ost["u"][0], m.NEdgesOwned)
     check("tr", P.tracers.copy_to_host(0), ost["tr"][0], m.NCellsOwned)
+
+
+def test_hip_graph_replay_matches_the_oracle():
+    """On a non-default stream the fused RHS and the one-rank stage-fused RK4 step are captured into HIP graphs the
+    second time they run with the same arrays and replayed afterwards (GraphCache.h).  Replays must see new DATA in
+    the same arrays, both time-level parities of the stepper need their own graph, and everything stays bit-equal
+    to the oracle."""
+    P = _mk((20, 24, 30e3, 12, 3, {}))
+    m, st = P.mesh, oa.Stream()
+    for rep in range(4):
+        if rep == 3:    # same arrays, new contents
+            P.h[:-1] *= 1.25
+            P.tr[:, :-1] += 0.5
+            P.state.copy_to_device(P.h, P.u, 0)
+            P.tracers.copy_to_device(P.tr, 0)
+        P.tend.compute_all_tendencies(P.state, P.aux, P.tracers, stream=st)
+    st.synchronize()
+    gs = P.tend.graph_stats()
+    assert gs["captures"] == 1 and gs["replays"] == 3, gs
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+    check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+    check("trTend", P.tend.get(2), trT, m.NCellsOwned)
+    stepper = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    for step in range(8):
+        stepper.do_step(P.state, stream=st)
+        P.oracle.step("rk4", ost, 600.0)
+    st.synchronize()
+    gs = stepper.graph_stats()
+    assert gs["captures"] == 2 and gs["replays"] >= 4, gs      # one graph per time-level parity, then replays
+    h, u = P.state.copy_to_host(0)
+    check("h", h, ost["h"][0], m.NCellsOwned)
+    check("u", u, ost["u"][0], m.NEdgesOwned)
+    check("tr", P.tracers.copy_to_host(0), ost["tr"][0], m.NCellsOwned)
+    # switching replay off mid-run changes nothing
+    stepper.set_option("UseGraphs", False)
+    stepper.do_step(P.state, stream=st)
+    P.oracle.step("rk4", ost, 600.0)
+    st.synchronize()
+    h, u = P.state.copy_to_host(0)
+    check("h", h, ost["h"][0], m.NCellsOwned)
+    check("u", u, ost["u"][0], m.NEdgesOwned)
