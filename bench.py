@@ -54,6 +54,8 @@ def algorithmic_bytes_per_cell_level(nt, kernel=None):
     per_kernel = {
         "VortVertexBody": 8 * (1 + 3 + 2 * 2),                 # h, u -> RelVort, 1/LayerThickVertex
         "FusedCell1Body": 8 * (3 + 1 + nt + 3 + nt),            # u, h, tr -> KE, Div, hTend, Del2Tr
+        # vertex pass + side-0 PV sums folded in: + RelVort, 1/LayerThickVertex (2 vertex arrays) and the PV sums
+        "FusedCellL1PVBody": 8 * (3 + 1 + nt + 3 + nt + 2 * 2 + 3),
         "Del2CellRingBody": 8 * (1 + 2 + 1),                    # Div, RelVort -> Del2Div
         "Del2VertexSelBody": 8 * (1 + 2 + 2),                   # Div, RelVort -> Del2RelVort
         "CellPVBody<side 0>": 8 * (3 + 1 + 2 * 2 + 3),          # u, h, RelVort, InvThick -> running PV sums
@@ -79,7 +81,12 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("OMEGA_BENCH_WORKLOAD", "qu30"), choices=sorted(WORKLOADS))
     ap.add_argument("--rk4-steps", type=int, default=-1, help="RK4 steps for SYPD (default: max(2, steps//4))")
     ap.add_argument("--dt", type=float, default=600.0, help="time step [s] (Default.yml TimeStep 10 min)")
-    ap.add_argument("--block", type=int, default=0, help="cell ordering of the synthetic mesh: 0 = Morton curve (default), -1 = Hilbert curve, 1 = row-major, n > 1 = n x n blocks")
+    ap.add_argument("--block", type=int, default=1,
+                    help="cell numbering of the synthetic INPUT mesh (what a mesh file would hold): 1 = row-major (default), "
+                         "0 = Morton curve, -1 = Hilbert curve, n > 1 = n x n blocks")
+    ap.add_argument("--local-order", default="curve", choices=["curve", "global"],
+                    help="local numbering chosen by Decomp: curve = along a Morton curve through the cell centres "
+                         "(default: the library owns data locality), global = the reference's global-id order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the reference-structured launch sequence instead")
     ap.add_argument("--no-overlap", action="store_true",
@@ -132,7 +139,7 @@ def main():
     elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
     gm = oa.GlobalMesh(g)
-    decomp = oa.Decomp(gm, N, rank, halo_width)
+    decomp = oa.Decomp(gm, N, rank, halo_width, local_order=args.local_order)
     mesh = oa.HorzMesh(decomp, K)
     halo = oa.Halo(decomp) if N > 1 else None
     cell_id, edge_id = decomp.get_array("CellID"), decomp.get_array("EdgeID")
@@ -305,7 +312,9 @@ def main():
                           "halo_wire": "none (1 rank)" if N == 1 else
                           ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
                            "host-staged gloo (rehearsal)"),
-                          "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "hilbert" if args.block < 0 else "morton" if args.block == 0 else f"blocked{args.block}",
+                          "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
+                                                   "row-major" if args.block == 1 else f"blocked{args.block}")
+                                        + ", local numbering by Decomp: " + args.local_order,
                           "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1),
                           "hip_graph": graph_stats},
                "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,

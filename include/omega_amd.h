@@ -132,6 +132,12 @@ int omg_restart_read_rows(const omg_restart_file *f, const char *var, int plane,
  *      alive until meshes / halos built from the decomp have been created. ---- */
 int omg_decomp_create(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
                       const int32_t *cell_task, omg_decomp **out);
+/* local_order: 0 = the reference's numbering (owned cells in global-id order, every halo layer sorted by global id,
+ * O/src/base/Decomp.cpp:1000-1080); 1 = every group ordered along a Morton curve through the cell centres, so that
+ * consecutive local elements are spatial neighbours whatever order the mesh file uses (edges / vertices follow the
+ * cells in both cases).  Per global id the results of every computation are identical. */
+int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
+                              const int32_t *cell_task, int local_order, omg_decomp **out);
 int omg_decomp_destroy(omg_decomp *d);
 /* scalar members by reference name: "NCellsOwned", "NCellsAll", "NCellsSize", "NCellsGlobal",
  * "NEdges...", "NVertices...", "MaxEdges", "VertexDegree", "HaloWidth" */
@@ -258,7 +264,8 @@ int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t 
 int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out);
 int omg_tend_destroy(omg_tend *t);
 int omg_tend_set_fused(omg_tend *t, int use_fused_rhs);
-/* HIP-graph replay of launch-bound sequences (default on): the fused RHS (omg_tend_compute_all) and, on one rank, the
+/* HIP-graph replay of launch-bound sequences (default off: measured without gain on MI355X; OMEGA_GRAPHS=1 or these
+ * switches turn it on): the fused RHS (omg_tend_compute_all) and, on one rank, the
  * stage-fused RK4 step (omg_stepper_do_step; option "UseGraphs") are captured the second time they are called with
  * the same arrays on the same NON-default stream and replayed afterwards with one host call.  Kernel timing and
  * custom tendencies switch it off.  *_graph_stats: graphs captured / replays so far. */
@@ -326,7 +333,7 @@ int omg_stepper_get_time(const omg_stepper *st, double *seconds);
  * epilogue of the RHS kernels, same arithmetic) and "StoreStageTendencies" (default 0: with fused stages the
  * Tendencies arrays are not written), "OverlapHaloExchange" (default 1: with fused stages and neighbours, each
  * exchange starts when the band of cells whose values travel is final and runs on a communication stream
- * while the stage's interior cells are computed), "UseGraphs" (default 1, see omg_tend_set_graphs).  0 / 1. */
+ * while the stage's interior cells are computed), "UseGraphs" (default 0, see omg_tend_set_graphs).  0 / 1. */
 int omg_stepper_set_option(omg_stepper *st, const char *name, int value);
 /* TimeStepper::changeTimeStep (O/src/timeStepping/TimeStepper.h:141-143) */
 int omg_stepper_change_time_step(omg_stepper *st, double time_step_seconds);

@@ -372,11 +372,15 @@ def read_partition_file(path: str) -> np.ndarray:
 
 
 class Decomp:
-    def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None):
+    def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None,
+                 local_order: str = "global"):
+        """local_order: "global" (the reference's numbering by global id) or "curve" (Morton curve through the cell
+        centres: spatially compact local numbering whatever the file's order)."""
         self.gm = gm
         h = C.c_void_p()
         ct = None if cell_task is None else np.ascontiguousarray(cell_task, dtype=np.int32)
-        _chk(lib().omg_decomp_create(C.byref(gm.s), nparts, mytask, halo_width, _pi(ct), C.byref(h)))
+        _chk(lib().omg_decomp_create_ordered(C.byref(gm.s), nparts, mytask, halo_width, _pi(ct),
+                                             {"global": 0, "curve": 1}[local_order], C.byref(h)))
         self.h = h
 
     def get_int(self, name: str) -> int:

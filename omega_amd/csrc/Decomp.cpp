@@ -56,11 +56,55 @@ void Decomp::partitionRCB() {
    rcbSplit(G, Idx, 0, Idx.size(), 0, NumTasks, CellTask);
 }
 
+// The sequence that numbers cells inside every group: global id, or a Morton curve through the cell centres
+// (21 bits per coordinate, interleaved; planar meshes have a constant z and reduce to the 2-D curve).
+void Decomp::buildCellOrder() {
+   CellSeq.resize(NCellsGlobal);
+   std::iota(CellSeq.begin(), CellSeq.end(), 0);
+   if (Order == LocalOrder::Curve) {
+      OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: curve ordering needs cell coordinates");
+      const R8 *C[3] = {G.XCell, G.YCell, G.ZCell};
+      R8 Mn[3] = {0, 0, 0}, Sc[3] = {0, 0, 0};
+      for (int A = 0; A < 3; ++A) {
+         if (!C[A])
+            continue;
+         R8 Lo = 1e300, Hi = -1e300;
+         for (I4 I = 0; I < NCellsGlobal; ++I)
+            Lo = std::min(Lo, C[A][I]), Hi = std::max(Hi, C[A][I]);
+         Mn[A] = Lo;
+         Sc[A] = Hi > Lo ? 2097151.0 / (Hi - Lo) : 0.0;
+      }
+      // isotropic quantisation (the longest axis uses the 21 bits): keeps the curve's cells square
+      const R8 S = std::min({Sc[0] > 0 ? Sc[0] : 1e300, Sc[1] > 0 ? Sc[1] : 1e300, Sc[2] > 0 ? Sc[2] : 1e300});
+      auto Spread = [](unsigned long long V) { // 21 bits -> every third bit
+         V &= 0x1fffffULL;
+         V = (V | V << 32) & 0x1f00000000ffffULL;
+         V = (V | V << 16) & 0x1f0000ff0000ffULL;
+         V = (V | V << 8) & 0x100f00f00f00f00fULL;
+         V = (V | V << 4) & 0x10c30c30c30c30c3ULL;
+         V = (V | V << 2) & 0x1249249249249249ULL;
+         return V;
+      };
+      std::vector<unsigned long long> Key(NCellsGlobal);
+      for (I4 I = 0; I < NCellsGlobal; ++I) {
+         unsigned long long K = 0;
+         for (int A = 0; A < 3; ++A)
+            if (C[A] && Sc[A] > 0)
+               K |= Spread((unsigned long long)((C[A][I] - Mn[A]) * S)) << A;
+         Key[I] = K;
+      }
+      std::sort(CellSeq.begin(), CellSeq.end(), [&](I4 A, I4 B) { return Key[A] < Key[B] || (Key[A] == Key[B] && A < B); });
+   }
+   CellRank.resize(NCellsGlobal);
+   for (I4 I = 0; I < NCellsGlobal; ++I)
+      CellRank[CellSeq[I]] = I;
+}
+
 // Owner task and local address on the owner for every global cell/edge/vertex.
 void Decomp::computeOwnership() {
    std::vector<I4> Count(NumTasks, 0);
    CellLocAll.assign(NCellsGlobal, 0);
-   for (I4 C = 0; C < NCellsGlobal; ++C) // owned cells keep global-id order (:1000-1015)
+   for (I4 C : CellSeq) // owned cells keep the numbering sequence (global-id order in the reference, :1000-1015)
       CellLocAll[C] = Count[CellTask[C]]++;
 
    // edge owner = task of the first valid cell in CellsOnEdge (:1476-1486)
@@ -87,7 +131,7 @@ void Decomp::computeOwnership() {
    EdgeLocAll.assign(NEdgesGlobal, -1);
    VertexLocAll.assign(NVerticesGlobal, -1);
    std::vector<I4> ECount(NumTasks, 0), VCount(NumTasks, 0);
-   for (I4 C = 0; C < NCellsGlobal; ++C) {
+   for (I4 C : CellSeq) {
       const I4 T = CellTask[C];
       for (int J = 0; J < MaxEdges; ++J) {
          I4 E = G.EdgesOnCell[(size_t)C * MaxEdges + J];
@@ -104,7 +148,7 @@ LocalSets Decomp::computeLocalSets(I4 Task) const {
    LocalSets S;
    // ---- cells: owned in global order, then HaloWidth BFS layers, each sorted ----
    std::vector<char> InList(NCellsGlobal, 0);
-   for (I4 C = 0; C < NCellsGlobal; ++C)
+   for (I4 C : CellSeq)
       if (CellTask[C] == Task) {
          S.CellID.push_back(C);
          InList[C] = 1;
@@ -126,7 +170,7 @@ LocalSets Decomp::computeLocalSets(I4 Task) const {
             }
          }
       }
-      std::sort(Layer.begin(), Layer.end());
+      std::sort(Layer.begin(), Layer.end(), [&](I4 A, I4 B) { return CellRank[A] < CellRank[B]; });
       S.CellID.insert(S.CellID.end(), Layer.begin(), Layer.end());
       S.NCellsHalo[Halo] = (I4)S.CellID.size();
       Start              = End;
@@ -265,8 +309,9 @@ void Decomp::buildLocalConnectivity(const LocalSets &S) {
    }
 }
 
-Decomp::Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask_, I4 HaloWidth_, const I4 *UserCellTask)
-    : HaloWidth(HaloWidth_), NumTasks(NParts), MyTask(MyTask_), G(Mesh) {
+Decomp::Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask_, I4 HaloWidth_, const I4 *UserCellTask,
+               LocalOrder Order_)
+    : HaloWidth(HaloWidth_), NumTasks(NParts), MyTask(MyTask_), Order(Order_), G(Mesh) {
    OMEGA_REQUIRE(NParts >= 1 && MyTask_ >= 0 && MyTask_ < NParts, "Decomp: bad task / part count");
    OMEGA_REQUIRE(HaloWidth_ >= 1, "Decomp: HaloWidth must be >= 1");
    OMEGA_REQUIRE(G.NCells > 0 && G.CellsOnCell && G.EdgesOnCell && G.VerticesOnCell && G.CellsOnEdge &&
@@ -287,6 +332,7 @@ Decomp::Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask_, I4 HaloWidth_,
    } else if (NParts > 1) {
       partitionRCB();
    }
+   buildCellOrder();
    computeOwnership();
 
    LocalSets S    = computeLocalSets(MyTask);

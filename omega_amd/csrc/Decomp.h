@@ -40,6 +40,14 @@ struct GlobalMeshDesc {
 
 enum PartMethod { PartMethodRCB, PartMethodUser };
 
+/// Order of a rank's cells inside each group (owned, halo layer 1, 2, ...).  GlobalID is the reference's
+/// (Decomp.cpp:1000-1080: owned cells in global-id order, every halo layer sorted by global id); Curve orders
+/// each group along a space-filling (Morton) curve through the cell centres, so that consecutive local cells --
+/// a kernel's tile, an XCD's share of the sweep -- are spatial neighbours whatever numbering the mesh file came
+/// with.  Edges and vertices follow the cells (order of encounter) in both cases.  Results per global id are
+/// identical; only the local numbering differs.
+enum class LocalOrder { GlobalID = 0, Curve = 1 };
+
 /// Ordered local element lists of one rank (global 0-based ids) with layer bounds.
 struct LocalSets {
    std::vector<I4> CellID, EdgeID, VertexID;
@@ -50,11 +58,12 @@ struct LocalSets {
 class Decomp {
  public:
    Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask, I4 HaloWidth,
-          const I4 *UserCellTask /* nullable */);
+          const I4 *UserCellTask /* nullable */, LocalOrder Order = LocalOrder::GlobalID);
 
    // ---- public data, names as in the reference (host side; "H" arrays) ----
    I4 HaloWidth;
    I4 NumTasks, MyTask;
+   LocalOrder Order;
 
    I4 NCellsGlobal, NCellsOwned, NCellsAll, NCellsSize, MaxEdges;
    HostArrayI4 NCellsHaloH; ///< [HaloWidth] owned+halo count through layer i
@@ -83,6 +92,9 @@ class Decomp {
 
  private:
    GlobalMeshDesc G;
+   std::vector<I4> CellSeq;  ///< cells in the order that numbers them (identity, or along the curve)
+   std::vector<I4> CellRank; ///< position of each cell in CellSeq
+   void buildCellOrder();
    void partitionRCB();
    void computeOwnership();
    void buildLocalConnectivity(const LocalSets &S);

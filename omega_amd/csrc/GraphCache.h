@@ -6,7 +6,10 @@
 // seen the sequence runs directly (lazy allocations happen here), the second time it is captured from the stream
 // into a graph, afterwards the instantiated graph is launched: one host call per sequence.
 // Only sequences that consist of kernel launches on ONE non-default stream qualify (no host callbacks, no
-// synchronisation, no allocation) -- the callers check that.  OMEGA_GRAPHS=0 disables replay.
+// synchronisation, no allocation) -- the callers check that.
+// Measured on MI355X: replay does not shorten even the smallest workload (QU240-sized:
+// 86 us direct, 91 us replayed) -- the sequences are bound by the GPU's per-kernel latency, not by the host -- so
+// replay is OFF unless asked for (Tendencies::UseGraphs / RungeKutta4Stepper::UseGraphs, or OMEGA_GRAPHS=1).
 #ifndef OMEGA_AMD_GRAPHCACHE_H
 #define OMEGA_AMD_GRAPHCACHE_H
 
@@ -28,9 +31,14 @@ class GraphCache {
             (void)hipGraphExecDestroy(E.Exec);
       Entries.clear();
    }
-   static bool enabled() {
-      static const bool On = !(getenv("OMEGA_GRAPHS") && atoi(getenv("OMEGA_GRAPHS")) == 0);
+   /// environment default of the UseGraphs switches (OMEGA_GRAPHS=1), and the global veto (OMEGA_GRAPHS=0)
+   static bool defaultOn() {
+      static const bool On = getenv("OMEGA_GRAPHS") && atoi(getenv("OMEGA_GRAPHS")) != 0;
       return On;
+   }
+   static bool enabled() {
+      static const bool Off = getenv("OMEGA_GRAPHS") && atoi(getenv("OMEGA_GRAPHS")) == 0;
+      return !Off;
    }
    template <class T> static void add(Key &K, const T &V) {
       unsigned long long W[(sizeof(T) + 7) / 8] = {};

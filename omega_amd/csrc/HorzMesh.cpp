@@ -543,7 +543,7 @@ void HorzMesh::buildDel2Tables() {
 void HorzMesh::buildCellL1Tables() {
    const int ME = MaxEdges, VD = VertexDegree;
    MeshView &W = View;
-   HostArrayI4 Spoke(NCellsSize, ME, 1, NEdgesAll), Sel(NCellsSize, ME, 1, 0x3f | (0x3f << 6));
+   HostArrayI4 Spoke(NCellsSize, ME, 1, NEdgesAll), Sel(NCellsSize, ME, 1, 0);
    HostArrayReal KC(NCellsSize, ME, 3, 0.0), VC(NCellsSize, ME, 3, 0.0);
    bool OK = W.Del2RingOK != 0 && VD == 3;
    std::vector<I4> Owner(NVerticesAll, -1), OwnerSlot(NVerticesAll, -1), NOwned(NCellsAll, 0);
@@ -553,41 +553,38 @@ void HorzMesh::buildCellL1Tables() {
          const int V  = HostVertRing(C, R);
          const int E0 = EdgesOnCellH(C, R), E1 = EdgesOnCellH(C, (R + 1) % N);
          const int N0 = HostNbrF(C, R) & 0x3fffffff, N1 = HostNbrF(C, (R + 1) % N) & 0x3fffffff;
-         int Code = 0, Sp = NEdgesAll;
+         // Roles: cells A = this cell, B = across slot R, C = across slot R+1; edges A = slot R, B = slot R+1,
+         // C = the spoke.  The vertex kernel adds its three terms in the vertex's slot order, ((0 + t0) + t1) + t2;
+         // t0 + t1 commutes, so all the cell side needs is each role's coefficient and WHICH ROLE IS LAST.
+         int Sp = NEdgesAll, LastC = -1, LastE = -1;
+         bool SeenC[3] = {false, false, false}, SeenE[3] = {false, false, false};
          for (int J = 0; J < 3 && OK; ++J) {
             const int Cv = CellsOnVertexH(V, J), Ev = EdgesOnVertexH(V, J);
-            int Sc, Se;
-            if (Cv == C)
-               Sc = 0;
-            else if (Cv < NCellsAll && Cv == N0)
-               Sc = 1;
-            else if (Cv < NCellsAll && Cv == N1)
-               Sc = 2;
-            else if (Cv >= NCellsAll)
-               Sc = 3; // no such cell here: the vertex kernel reads the zero sentinel row
-            else {
+            int Rc = -1, Re = -1;
+            if (Cv == C && !SeenC[0])
+               Rc = 0;
+            else if (Cv == N0 && !SeenC[1]) // (a missing cell is the sentinel on both sides: the zero row either way)
+               Rc = 1;
+            else if (Cv == N1 && !SeenC[2])
+               Rc = 2;
+            if (Ev == E0 && !SeenE[0])
+               Re = 0;
+            else if (Ev == E1 && !SeenE[1])
+               Re = 1;
+            else if (!SeenE[2] && (Ev >= NEdgesAll || (Ev != E0 && Ev != E1)))
+               Re = 2, Sp = Ev; // the spoke, or no third edge here (sentinel row)
+            if (Rc < 0 || Re < 0) {
                OK = false;
                break;
             }
-            if (Ev == E0)
-               Se = 0;
-            else if (Ev == E1)
-               Se = 1;
-            else if (Ev >= NEdgesAll)
-               Se = 3;
-            else if (Sp == NEdgesAll || Sp == Ev)
-               Se = 2, Sp = Ev;
-            else {
-               OK = false;
-               break;
-            }
-            Code |= (Sc << (2 * J)) | (Se << (6 + 2 * J));
-            KC.V[((size_t)C * ME + R) * 3 + J] = HostKiteC(V, J);
-            VC.V[((size_t)C * ME + R) * 3 + J] = HostVortC(V, J);
+            SeenC[Rc] = SeenE[Re] = true;
+            KC.V[((size_t)C * ME + R) * 3 + Rc] = HostKiteC(V, J);
+            VC.V[((size_t)C * ME + R) * 3 + Re] = HostVortC(V, J);
+            if (J == 2)
+               LastC = Rc, LastE = Re;
          }
-         // the spoke must really be the edge between the two neighbours (or absent)
          Spoke(C, R) = Sp;
-         Sel(C, R)   = Code;
+         Sel(C, R)   = LastC | (LastE << 2);
          // ownership: the cell with the fewest stores so far among those that see the vertex
          if (Owner[V] < 0 || NOwned[C] < NOwned[Owner[V]] - 1) {
             if (Owner[V] >= 0)
@@ -601,7 +598,7 @@ void HorzMesh::buildCellL1Tables() {
       if (Owner[V] < 0)
          OK = false; // a local vertex no local cell has in its ring
       else
-         Sel(Owner[V], OwnerSlot[V]) |= 1 << 12;
+         Sel(Owner[V], OwnerSlot[V]) |= 1 << 4;
    }
    SpokeOnCell    = createDeviceMirrorCopy<I4, 2>("SpokeOnCell", Spoke);
    VortSelOnCell  = createDeviceMirrorCopy<I4, 2>("VortSelOnCell", Sel);

@@ -102,11 +102,12 @@ struct MeshView {
    // stored by exactly one of its cells (own bit).
    I4 CellL1OK;
    const I4 *SpokeOnCell;          // [C][ME] third edge of ring vertex r (sentinel row if it has none here)
-   const I4 *VortSelOnCell;        // [C][ME] bits 2j..2j+1: which register holds CellsOnVertex(v,j): 0 self, 1 nbr r,
-                                   //   2 nbr r+1, 3 none (zero row); bits 6+2j..7+2j: EdgesOnVertex(v,j): 0 slot r,
-                                   //   1 slot r+1, 2 spoke, 3 none; bit 12: this cell stores vertex v
-   const Real *KiteCoefOnCell;     // [C][ME][3] KiteCoefOnVertex(v, 0..2)
-   const Real *VortCoefOnCell;     // [C][ME][3] VortCoefOnVertex(v, 0..2)
+   const I4 *VortSelOnCell;        // [C][ME] bits 0-1: which of the cells {0 self, 1 across slot r, 2 across slot r+1} sits
+                                   //   in the vertex's LAST slot (its term is added last; the first two commute);
+                                   //   bits 2-3: the same for the edges {0 slot r, 1 slot r+1, 2 spoke}; bit 4: this
+                                   //   cell stores vertex v
+   const Real *KiteCoefOnCell;     // [C][ME][3] KiteCoefOnVertex of the vertex's slot holding {self, across r, across r+1}
+   const Real *VortCoefOnCell;     // [C][ME][3] VortCoefOnVertex of the vertex's slot holding {slot r, slot r+1, spoke}
    // ---- overlap of halo exchanges with interior work (HorzMesh::buildBandLists) ----
    // BandCells: every halo cell and every owned cell within HaloWidth+1 cells of one (a superset of the cells
    // that own anything a neighbour receives); InteriorCells: the other owned cells.  Ascending order.

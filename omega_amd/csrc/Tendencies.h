@@ -28,8 +28,9 @@ class Tendencies {
    /// structure (every AuxiliaryState array materialised).
    bool UseFusedRHS = true;
    /// Replay the fused RHS as a HIP graph when it is called again with the same arrays on a non-default stream
-   /// (GraphCache.h): one host call instead of 7 launches.  Off while kernel timing or custom tendencies are on.
-   bool UseGraphs = true;
+   /// (GraphCache.h): one host call instead of 7 launches.  Default off (no gain measured); never used while
+   /// kernel timing or custom tendencies are on.
+   bool UseGraphs = GraphCache::defaultOn();
    GraphCache Graphs;
 
    /// Custom tendencies (Tendencies.h:51-53, 182-183): called at the end of the thickness / velocity

@@ -117,7 +117,7 @@ class RungeKutta4Stepper : public TimeStepper {
    bool OverlapHaloExchange   = true;
    /// Without neighbours (one rank) the 28 launches of a stage-fused step are replayed as one HIP graph per
    /// time-level parity when the step runs on a non-default stream (GraphCache.h).
-   bool UseGraphs             = true;
+   bool UseGraphs             = GraphCache::defaultOn();
    GraphCache Graphs;
    ~RungeKutta4Stepper() override;
 

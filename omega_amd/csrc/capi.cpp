@@ -318,10 +318,8 @@ int omg_restart_read_rows(const omg_restart_file *f, const char *var, int plane,
 }
 
 // ---------------------------------------------------------------- Decomp
-int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo_width, const int32_t *cell_task,
-                      omg_decomp **out) {
-   OMG_TRY
-   OMG_ARG(m && out);
+static GlobalMeshDesc toDesc(const omg_global_mesh &M) {
+   const omg_global_mesh *m = &M;
    GlobalMeshDesc G;
    G.NCells = m->nCells, G.NEdges = m->nEdges, G.NVertices = m->nVertices, G.MaxEdges = m->maxEdges;
    G.VertexDegree = m->vertexDegree;
@@ -335,9 +333,21 @@ int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo
    G.AreaCell = m->areaCell, G.AreaTriangle = m->areaTriangle, G.KiteAreasOnVertex = m->kiteAreasOnVertex;
    G.DcEdge = m->dcEdge, G.DvEdge = m->dvEdge, G.AngleEdge = m->angleEdge, G.WeightsOnEdge = m->weightsOnEdge;
    G.FCell = m->fCell, G.FEdge = m->fEdge, G.FVertex = m->fVertex, G.BottomDepth = m->bottomDepth;
+   return G;
+}
+int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
+                              const int32_t *cell_task, int local_order, omg_decomp **out);
+int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo_width, const int32_t *cell_task,
+                      omg_decomp **out) {
+   return omg_decomp_create_ordered(m, nparts, mytask, halo_width, cell_task, 0, out);
+}
+int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
+                              const int32_t *cell_task, int local_order, omg_decomp **out) {
+   OMG_TRY
+   OMG_ARG(mesh && out && (local_order == 0 || local_order == 1));
    auto *R = new omg_decomp;
    try {
-      R->D.reset(new Decomp(G, nparts, mytask, halo_width, cell_task));
+      R->D.reset(new Decomp(toDesc(*mesh), nparts, mytask, halo_width, cell_task, (LocalOrder)local_order));
    } catch (...) {
       delete R;
       throw;

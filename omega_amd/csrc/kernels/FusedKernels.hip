@@ -241,8 +241,11 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
 // side-0 half of PotentialVortHAdvOnEdge (CellPVBody<.., 0>) with the normalised vorticities still in registers.
 // Against VortVertexBody + FusedCell1Body + CellPVBody<side 0> this reads h and u once instead of three times and
 // never re-reads the two vertex arrays: 96 B per cell-level less HBM traffic and two launches less.
+#ifndef OMEGA_L1PV_MINW
+#define OMEGA_L1PV_MINW OMEGA_CELL_MINW
+#endif
 template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
-   static constexpr int MinWaves = OMEGA_CELL_MINW;
+   static constexpr int MinWaves = OMEGA_L1PV_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
@@ -289,8 +292,12 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.DvS[I]       = M.DvSignOnCell[G];
          L.D2T[I]       = Fast ? M.Del2TrCoefSOnCell[G] : M.Del2TrCoefOnCell[G];
-         L.Edge[I]      = M.EdgesOnCell[G];
-         L.NbrF[I]      = M.NbrFlagOnCell[G];
+         // slot N of a cell with N < TME edges repeats slot 0 (its coefficients are zero, so it adds exact zeros to the
+         // cell sums) -- the ring code below then finds "the slot after N-1" without a wrap-around select
+         const int Cl   = I / TME, Jl = I - Cl * TME;
+         const size_t G0 = (Jl == M.NEdgesOnCell[First + Cl]) ? (size_t)(First + Cl) * TME : G;
+         L.Edge[I]      = M.EdgesOnCell[G0];
+         L.NbrF[I]      = M.NbrFlagOnCell[G0];
          L.Spoke[I]     = M.SpokeOnCell[G];
          L.Sel[I]       = M.VortSelOnCell[G];
          L.Ring[I]      = M.VertRingOnCell[G];
@@ -354,32 +361,32 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
             stageUpdate<T, true>(E, OffS, HT, Hs);
       }
       // ---- VorticityAuxVars::computeVarsOnVertex at every ring vertex (VorticityAuxVars.h:24-59) ----
+      // ((0 + t0) + t1) + t2 in the vertex's slot order: t0 + t1 commutes, so with the coefficients staged per
+      // role only the role of the last slot has to be selected.  Slot N of a cell with N < TME edges repeats slot 0
+      // (stage()), so "slot R+1" needs no wrap-around select.
       T QR[TME], QF[TME];
       {
          const T Zero = splat<T>(0.0);
 #pragma unroll
          for (int R = 0; R < TME; ++R) {
-            // the slot after R in this cell's own cyclic order (cells of fewer than TME edges wrap earlier)
-            const bool Wrap = (R + 1 >= TME) || (R + 1 >= N);
-            const T HnN = pick(Wrap, Hn[0], Hn[(R + 1) % TME]);
-            const T UeN = pick(Wrap, Ue[0], Ue[(R + 1) % TME]);
+            const int R1  = (R + 1) % TME;
             const int Sel = L.Sel[Le * TME + R];
-            T LayerThickVertex = splat<T>(0.0), RelVortTmp = splat<T>(0.0);
-#pragma unroll
-            for (int J = 0; J < 3; ++J) {
-               const int Sc = (Sel >> (2 * J)) & 3, Se = (Sel >> (6 + 2 * J)) & 3;
-               const T Hc = pick(Sc == 0, Hs, pick(Sc == 1, Hn[R], pick(Sc == 2, HnN, Zero)));
-               const T Uv = pick(Se == 0, Ue[R], pick(Se == 1, UeN, pick(Se == 2, Usp[R], Zero)));
-               LayerThickVertex += L.KC[(Le * TME + R) * 3 + J] * Hc;
-               RelVortTmp += L.VC[(Le * TME + R) * 3 + J] * Uv;
-            }
-            const T Inv = 1. / LayerThickVertex;
-            if ((Sel >> 12) & 1) { // this cell stores the vertex
+            const int Lc = Sel & 3, Lu = (Sel >> 2) & 3;
+            const T PA = L.KC[(Le * TME + R) * 3 + 0] * Hs, PB = L.KC[(Le * TME + R) * 3 + 1] * Hn[R],
+                    PC = L.KC[(Le * TME + R) * 3 + 2] * Hn[R1];
+            const T X  = pick(Lc == 0, PB, PA), Y = pick(Lc == 2, PB, PC), Z = pick(Lc == 0, PA, pick(Lc == 1, PB, PC));
+            const T LayerThickVertex = ((Zero + X) + Y) + Z;
+            const T UA = L.VC[(Le * TME + R) * 3 + 0] * Ue[R], UB = L.VC[(Le * TME + R) * 3 + 1] * Ue[R1],
+                    UC = L.VC[(Le * TME + R) * 3 + 2] * Usp[R];
+            const T Xu = pick(Lu == 0, UB, UA), Yu = pick(Lu == 2, UB, UC), Zu = pick(Lu == 0, UA, pick(Lu == 1, UB, UC));
+            const T RelVortTmp = ((Zero + Xu) + Yu) + Zu;
+            const T Inv        = 1. / LayerThickVertex;
+            if ((Sel >> 4) & 1) { // this cell stores the vertex
                const unsigned OffV = rowOff<T>(L.Ring[Le * TME + R], K, Kv);
                sto<T>(RelVortV, OffV, RelVortTmp);
                sto<T>(InvThickV, OffV, Inv);
             }
-            QR[R] = RelVortTmp * Inv;       // NormRelVortVertex   (:50-51)
+            QR[R] = RelVortTmp * Inv;         // NormRelVortVertex   (:50-51)
             QF[R] = L.FV[Le * TME + R] * Inv; // NormPlanetVortVertex (:52-53)
          }
       }

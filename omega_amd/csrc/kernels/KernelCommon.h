@@ -140,7 +140,20 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0) {
    if (G.Tile > 256)
       G.Tile = 256;
    int NTiles = (N + G.Tile - 1) / G.Tile;
-   G.Grid     = dim3(NTiles > 0 ? NTiles : 1, 1, 1);
+   // Small sweeps (QU240-sized meshes, the per-GPU share of a partitioned mesh): a workgroup walking its level
+   // chunks one after the other is a chain of dependent memory round trips with too few workgroups in flight to
+   // hide it, so the chunks go to separate workgroups (gridDim.y) -- more, shorter workgroups; each stages its own
+   // copy of the tile's tables.
+   int NChunks = (G.KV + TX - 1) / TX, Split = 1;
+   static const int EnvSplit = getenv("OMEGA_CHUNK_SPLIT") ? atoi(getenv("OMEGA_CHUNK_SPLIT")) : -1;
+   if (EnvSplit >= 0)
+      Split = EnvSplit > 0 ? (EnvSplit < NChunks ? EnvSplit : NChunks) : 1;
+   else
+      while (Split < NChunks && (long)NTiles * Split < 2048)
+         Split *= 2;
+   if (Split > NChunks)
+      Split = NChunks;
+   G.Grid = dim3(NTiles > 0 ? NTiles : 1, Split > 0 ? Split : 1, 1);
    return G;
 }
 
@@ -178,7 +191,7 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
       B.stage(L, First, Cnt, Tid, NThr);
    __syncthreads();
    for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-      for (int Kv = threadIdx.x; Kv < KV; Kv += blockDim.x)
+      for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
 {
 #ifdef OMEGA_KV_BARRIER
             __asm__ volatile("" ::: "memory");

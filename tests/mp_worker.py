@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="RK4 (gpu mode): exchange after the stage instead of overlapped")
     ap.add_argument("--user-stream", action="store_true",
                     help="gpu mode: step on a non-blocking stream created with omg_stream_create instead of the default stream")
+    ap.add_argument("--local-order", default="global", choices=["global", "curve"],
+                    help="Decomp local numbering: the reference's (global id) or along a Morton curve")
     ap.add_argument("--rtol", type=float, default=0.0,
                     help="0 = owned elements must equal the single-rank run bit for bit; > 0 = the partitioned run may "
                          "deviate by at most this (relative to the field's max), and MUST deviate (the setting is known "
@@ -63,7 +65,8 @@ def main():
     if gpu:
         oa.device_init(0)
     cfg = {"VelHyperDiffTendencyEnable": 0, "TracerHyperDiffTendencyEnable": 0} if a.no_del4 else {}
-    P = Problem(g, K, NT, nparts=a.world, rank=a.rank, device=gpu, config=cfg, halo_width=a.halo_width)
+    P = Problem(g, K, NT, nparts=a.world, rank=a.rank, device=gpu, config=cfg, halo_width=a.halo_width,
+                local_order=a.local_order)
     m = P.mesh
     halo = P.halo if gpu else oa.Halo(P.decomp)
     nbrs = halo.neighbors

@@ -18,10 +18,10 @@ class Problem:
     """One rank's view of a global mesh: product objects (if a GPU is present) + oracle."""
 
     def __init__(self, g, K, NT, nparts=1, rank=0, device=True, config=None, seed=20251003, halo_width=3,
-                 oracle=True):
+                 oracle=True, local_order="global"):
         self.g, self.K, self.NT = g, K, NT
         self.gm = oa.GlobalMesh(g)
-        self.decomp = oa.Decomp(self.gm, nparts, rank, halo_width)
+        self.decomp = oa.Decomp(self.gm, nparts, rank, halo_width, local_order=local_order)
         self.mesh = oa.HorzMesh(self.decomp, K, host_only=not device)
         self.cell_id = self.decomp.get_array("CellID")
         self.edge_id = self.decomp.get_array("EdgeID")

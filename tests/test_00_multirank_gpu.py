@@ -27,6 +27,7 @@ pytestmark = pytest.mark.gpu
     ["--halo-width", 4, "--nx", 72, "--ny", 12, "--levels", 3, "--steps", 3],
     ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4, "--tracers", 0],   # no tracer kernel: exchange starts after the u band
     ["--no-del4", "--mesh", "ico3", "--levels", 4],                          # sphere, pentagon ring launches, 2 ranks
+    ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 6, "--local-order", "curve"],   # Morton-ordered local numbering
     ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 20],     # 20 levels: device rows padded to 32 (pack / unpack with a pitch)
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream"],               # non-blocking user stream,
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream", "--no-overlap"],  # overlapped and sequential

@@ -387,6 +387,7 @@ def test_hip_graph_replay_matches_the_oracle():
     to the oracle."""
     P = _mk((20, 24, 30e3, 12, 3, {}))
     m, st = P.mesh, oa.Stream()
+    P.tend.set_graphs(True)
     for rep in range(4):
         if rep == 3:    # same arrays, new contents
             P.h[:-1] *= 1.25
@@ -402,6 +403,7 @@ def test_hip_graph_replay_matches_the_oracle():
     check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
     check("trTend", P.tend.get(2), trT, m.NCellsOwned)
     stepper = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    stepper.set_option("UseGraphs", True)
     ost = P.oracle.make_state(P.h, P.u, P.tr)
     for step in range(8):
         stepper.do_step(P.state, stream=st)
@@ -418,6 +420,38 @@ def test_hip_graph_replay_matches_the_oracle():
     stepper.do_step(P.state, stream=st)
     P.oracle.step("rk4", ost, 600.0)
     st.synchronize()
+    h, u = P.state.copy_to_host(0)
+    check("h", h, ost["h"][0], m.NCellsOwned)
+    check("u", u, ost["u"][0], m.NEdgesOwned)
+
+
+@pytest.mark.parametrize("mesh", ["hex", "ico3"])
+def test_curve_ordered_local_numbering(mesh):
+    """Decomp with LocalOrder::Curve on a row-major (unordered) input mesh: another local numbering, the same results
+    per global id -- fused RHS and an RK4 step against the oracle running on the product's own local arrays."""
+    g = planar_hex(40, 24, 30e3) if mesh == "hex" else sphere("ico3")
+    P = Problem(g, 12, 2, local_order="curve")
+    assert not np.array_equal(P.cell_id[:-1], np.arange(1, g["nCells"] + 1))
+    m = P.mesh
+    assert m.get_int("CellL1OK") == 1 and m.get_int("CellPVFinalOK") == 1
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+    check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+    check("trTend", P.tend.get(2), trT, m.NCellsOwned)
+    # and the same numbers as the reference numbering, element by element through the global ids
+    Q = Problem(g, 12, 2)
+    Q.tend.compute_all_tendencies(Q.state, Q.aux, Q.tracers)
+    oa.device_synchronize()
+    a, b = np.zeros((g["nCells"], 12)), np.zeros((g["nCells"], 12))
+    a[P.cell_id[:-1] - 1], b[Q.cell_id[:-1] - 1] = P.tend.get(0)[:-1], Q.tend.get(0)[:-1]
+    assert np.array_equal(a, b)
+    st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    st.do_step(P.state)
+    oa.device_synchronize()
+    P.oracle.step("rk4", ost, 600.0)
     h, u = P.state.copy_to_host(0)
     check("h", h, ost["h"][0], m.NCellsOwned)
     check("u", u, ost["u"][0], m.NEdgesOwned)

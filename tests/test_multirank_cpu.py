@@ -58,6 +58,7 @@ def run_ranks(mode, world, extra=(), timeout=600):
     (3, ["--no-del4", "--nx", 18, "--ny", 18, "--stepper", "Forward-Backward", "--levels", 3]),
     (3, ["--no-del4", "--mesh", "ico3", "--levels", 3]),                # sphere, 12 pentagons, RCB in 3-D
     (2, ["--halo-width", 5, "--mesh", "fib700", "--levels", 3, "--steps", 1]),  # pentagons + heptagons, del4 on
+    (3, ["--halo-width", 4, "--nx", 24, "--ny", 24, "--local-order", "curve"]),  # local numbering along a Morton curve
 ])
 def test_partitioned_oracle_matches_single_rank(world, extra):
     outs = run_ranks("cpu", world, extra)
@@ -104,6 +105,35 @@ def test_decomp_every_element_owned_once(nparts):
             lo = hi
         loc = d.get_array("CellLoc")
         assert np.all(loc[:no, 0] == r) and np.array_equal(loc[:no, 1], np.arange(no))
+    n = np.array([g["nCells"], g["nEdges"], g["nVertices"]], dtype=np.int64)
+    assert np.array_equal(tot, n * (n + 1) // 2)
+
+
+@pytest.mark.parametrize("nparts", [1, 3, 8])
+def test_curve_ordered_decomp_owns_every_element_once_and_is_compact(nparts):
+    """LocalOrder::Curve: same element sets per rank and layer as the reference numbering, ordered along a Morton
+    curve -- consecutive owned cells of a row-major mesh are then near each other (the reference numbering keeps
+    the file's row-major order, whose rows are nx cells apart)."""
+    nx, ny = 32, 24
+    g = planar_hex(nx, ny, 1.0)
+    gm = oa.GlobalMesh(g)
+    tot = np.zeros(3, dtype=np.int64)
+    for r in range(nparts):
+        d, d0 = oa.Decomp(gm, nparts, r, 3, local_order="curve"), oa.Decomp(gm, nparts, r, 3)
+        for i, (arr, n) in enumerate((("CellID", "NCellsOwned"), ("EdgeID", "NEdgesOwned"), ("VertexID", "NVerticesOwned"))):
+            tot[i] += d.get_array(arr)[: d.get_int(n)].astype(np.int64).sum()
+        cid, cid0 = d.get_array("CellID"), d0.get_array("CellID")
+        lo = 0
+        for hi in [d.get_int("NCellsOwned")] + list(d.get_array("NCellsHalo")):   # same sets, group by group
+            assert np.array_equal(np.sort(cid[lo:hi]), np.sort(cid0[lo:hi]))
+            lo = hi
+        assert np.array_equal(d.get_array("NCellsHalo"), d0.get_array("NCellsHalo"))
+        assert np.array_equal(d.get_array("NEdgesHalo"), d0.get_array("NEdgesHalo"))
+        if nparts == 1:     # mean index distance of consecutive cells: ~nx/2.. for row-major, small along the curve
+            own = cid[: d.get_int("NCellsOwned")] - 1
+            x, y = own % nx, own // nx
+            step = np.abs(np.diff(x)) + np.abs(np.diff(y))
+            assert np.median(step) <= 2 and step.mean() < 4.0
     n = np.array([g["nCells"], g["nEdges"], g["nVertices"]], dtype=np.int64)
     assert np.array_equal(tot, n * (n + 1) // 2)
 
