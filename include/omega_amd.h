@@ -126,6 +126,18 @@ int omg_restart_write_rows(omg_restart_file *f, const char *var, int plane, cons
 int omg_restart_read_rows(const omg_restart_file *f, const char *var, int plane, const int32_t *global_id, int64_t n,
                           double *rows);
 
+/* ---- History output (the "History" IOStream, O/configs/Default.yml:115-127: `Contents` lists fields and field groups;
+ *      field names, long names and units as registered by the registerFields of O/src/ocn/auxiliaryVars/ (one .cpp per group) and
+ *      O/src/ocn/OceanState.cpp:190-234).  contents: comma-separated field names ("SshCell", "KineticEnergyCell", ...)
+ *      and groups ("State" = LayerThickness + NormalVelocity, "Tracers", "AuxiliaryState" = every auxiliary field).
+ *      One CDF-5 file per dump (dimensions NCells / NEdges / NVertices / NVertLayers / NTracers); every rank writes
+ *      the rows of its owned elements by global id.  create_file != 0 on exactly one rank (first, then a barrier of
+ *      the caller's).  The whole AuxiliaryState is recomputed from the state / tracers at `time_level` before anything
+ *      is copied (the fused RHS does not materialise most auxiliary arrays), on `stream`, which is synchronised. ---- */
+int omg_history_write(const char *path, const omg_decomp *d, const omg_state *s, const omg_tracers *t, omg_aux *a,
+                      const char *contents, double simulation_time, int time_level, int create_file, void *stream,
+                      int *n_variables_written);
+
 /* ---- Decomp (O/src/base/Decomp.cpp:444-745 constructor; Decomp.h:189-260 members).
  *      cell_task: optional [nCells] owner task of each cell (e.g. a METIS part file);
  *      NULL = built-in recursive coordinate bisection.  The global mesh arrays must stay

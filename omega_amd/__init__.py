@@ -208,6 +208,16 @@ def write_restart(path, decomp, state, tracers, K, NT, simulation_time, steps_do
         barrier()
 
 
+def write_history(path, decomp, state, tracers, aux, contents="State,Tracers,AuxiliaryState", simulation_time=0.0,
+                  time_level=0, create_file=True, stream=None) -> int:
+    """One history dump (omg_history_write): field names / groups as in the reference's History stream Contents."""
+    n = C.c_int()
+    _chk(lib().omg_history_write(os.fsencode(path), decomp.h, state.h, tracers.h if tracers is not None else None, aux.h,
+                                 contents.encode(), C.c_double(simulation_time), time_level, int(create_file), _sh(stream),
+                                 C.byref(n)))
+    return n.value
+
+
 def read_restart(path, decomp, mesh, state, tracers, K, NT):
     """Restart load: every rank reads the rows of ALL its local cells / edges (owned and halo, by global
     id) into time level 0, so no halo exchange is needed afterwards.  Returns (simulation_time, steps_done)."""

@@ -38,7 +38,7 @@ struct TracerAuxVars {
    FluxTracerEdgeOption TracersOnEdgeChoice = FluxTracerEdgeOption::Center;
 };
 
-class AuxiliaryState {
+class AuxiliaryState : public Registry<AuxiliaryState> {
  public:
    AuxiliaryState(const std::string &Name, const HorzMesh *Mesh, Halo *MeshHalo, int NVertLayers, int NTracers);
 

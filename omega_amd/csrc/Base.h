@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -144,6 +145,40 @@ template <class T> struct HostArray {
 };
 using HostArrayI4   = HostArray<I4>;
 using HostArrayReal = HostArray<Real>;
+
+/// The reference's object registries (e.g. Tendencies::create / get / getDefault / erase / clear,
+/// components/omega/src/ocn/Tendencies.h:105-144; the same pattern in OceanState.h:100-149, AuxiliaryState.h:49-65,
+/// Halo.h:258-279, HorzMesh.h, Decomp.h, TimeStepper.h:87-139): objects are created by name, owned by a static
+/// map<string, unique_ptr<T>>, looked up by name, and the one called "Default" is what getDefault() returns.
+/// create() forwards its arguments after the name to the constructor T(Name, ...); a second create with the
+/// same name fails (returns nullptr, as the reference logs an error and returns nullptr); get() of a missing name
+/// returns nullptr.  `init()` of the reference builds the default object from the YAML configuration, which is out
+/// of scope here: the host code creates "Default" itself.
+template <class T> class Registry {
+ public:
+   template <class... A> static T *create(const std::string &Name, A &&...Args) {
+      auto &M = all();
+      if (M.find(Name) != M.end())
+         return nullptr;
+      T *Obj = new T(Name, std::forward<A>(Args)...);
+      M[Name].reset(Obj);
+      return Obj;
+   }
+   static T *get(const std::string &Name) {
+      auto &M  = all();
+      auto It = M.find(Name);
+      return It == M.end() ? nullptr : It->second.get();
+   }
+   static T *getDefault() { return get("Default"); }
+   static void erase(const std::string &Name) { all().erase(Name); }
+   static void clear() { all().clear(); }
+
+ private:
+   static std::map<std::string, std::unique_ptr<T>> &all() {
+      static std::map<std::string, std::unique_ptr<T>> M;
+      return M;
+   }
+};
 
 // ---- device helpers (Device.cpp) ----
 void deviceInit(int DeviceId);                 ///< hipSetDevice + sanity check (gfx950)

@@ -55,10 +55,16 @@ struct LocalSets {
    std::vector<I4> NCellsHalo, NEdgesHalo, NVerticesHalo; ///< HaloWidth entries each
 };
 
-class Decomp {
+class Decomp : public Registry<Decomp> {
  public:
    Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask, I4 HaloWidth,
           const I4 *UserCellTask /* nullable */, LocalOrder Order = LocalOrder::GlobalID);
+   /// named form for Decomp::create(Name, ...) (Decomp.h:262-275)
+   Decomp(const std::string &Name, const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask, I4 HaloWidth,
+          const I4 *UserCellTask = nullptr, LocalOrder Order = LocalOrder::GlobalID)
+       : Decomp(Mesh, NParts, MyTask, HaloWidth, UserCellTask, Order) {
+      (void)Name;
+   }
 
    // ---- public data, names as in the reference (host side; "H" arrays) ----
    I4 HaloWidth;

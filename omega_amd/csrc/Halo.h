@@ -33,7 +33,7 @@ typedef int (*HaloTransportFn)(void *Ctx, int NNghbr, const int *Tasks, void *co
                                const size_t *SendBytes, void *const *RecvPtrs, const size_t *RecvBytes,
                                void *Stream);
 
-class Halo {
+class Halo : public Registry<Halo> {
  public:
    Halo(const std::string &Name, const Decomp *InDecomp);
    ~Halo();

@@ -115,7 +115,7 @@ struct MeshView {
    const I4 *BandCells, *InteriorCells;
 };
 
-class HorzMesh {
+class HorzMesh : public Registry<HorzMesh> {
  public:
    HorzMesh(const std::string &Name, const Decomp *MeshDecomp, I4 NVertLayers, bool HostOnly = false);
    bool HostOnly; ///< host arrays only (no device mirrors): compute calls are rejected

@@ -13,7 +13,7 @@ namespace OMEGA {
 
 class Halo;
 
-class OceanState {
+class OceanState : public Registry<OceanState> {
  public:
    OceanState(const std::string &Name, const HorzMesh *Mesh, Halo *MeshHalo, int NVertLayers, int NTimeLevels);
 

@@ -15,7 +15,7 @@
 
 namespace OMEGA {
 
-class Tendencies {
+class Tendencies : public Registry<Tendencies> {
  public:
    Tendencies(const std::string &Name, const HorzMesh *Mesh, int NVertLayers, int NTracers, const TendParams &Options);
 

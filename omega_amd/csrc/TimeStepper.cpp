@@ -114,7 +114,31 @@ TimeStepperType TimeStepper::getFromStr(const std::string &In) {
    return TimeStepperType::Invalid;
 }
 
-TimeStepper *TimeStepper::create(const std::string &Name, TimeStepperType Type, R8 Dt) {
+namespace {
+std::map<std::string, std::unique_ptr<TimeStepper>> &allSteppers() {
+   static std::map<std::string, std::unique_ptr<TimeStepper>> M;
+   return M;
+}
+} // namespace
+TimeStepper *TimeStepper::create(const std::string &Name, TimeStepperType Type, R8 Dt, Tendencies *T, AuxiliaryState *A,
+                                 const HorzMesh *M, Halo *H, Tracers *Tr) {
+   auto &All = allSteppers();
+   if (All.find(Name) != All.end())
+      return nullptr;
+   TimeStepper *St = make(Name, Type, Dt);
+   All[Name].reset(St);
+   St->attachData(T, A, M, H, Tr);
+   St->finalizeInit();
+   return St;
+}
+TimeStepper *TimeStepper::get(const std::string &Name) {
+   auto It = allSteppers().find(Name);
+   return It == allSteppers().end() ? nullptr : It->second.get();
+}
+void TimeStepper::erase(const std::string &Name) { allSteppers().erase(Name); }
+void TimeStepper::clear() { allSteppers().clear(); }
+
+TimeStepper *TimeStepper::make(const std::string &Name, TimeStepperType Type, R8 Dt) {
    switch (Type) {
    case TimeStepperType::ForwardBackward:
       return new ForwardBackwardStepper(Name, Dt);
@@ -123,7 +147,7 @@ TimeStepper *TimeStepper::create(const std::string &Name, TimeStepperType Type, 
    case TimeStepperType::RungeKutta2:
       return new RungeKutta2Stepper(Name, Dt);
    default:
-      OMEGA_ABORT("TimeStepper::create: unknown time stepper type");
+      OMEGA_ABORT("TimeStepper::make: unknown time stepper type");
    }
 }
 

@@ -23,8 +23,16 @@ class TimeStepper {
    TimeStepper(const std::string &Name, TimeStepperType Type, int NTimeLevels, R8 TimeStepSeconds);
    virtual ~TimeStepper() = default;
 
-   /// factory (TimeStepper::create, TimeStepper.h:96-107)
-   static TimeStepper *create(const std::string &Name, TimeStepperType Type, R8 TimeStepSeconds);
+   /// plain factory: the caller owns the object
+   static TimeStepper *make(const std::string &Name, TimeStepperType Type, R8 TimeStepSeconds);
+   /// the reference's registry (TimeStepper::create / get / getDefault / erase / clear, TimeStepper.h:87-139):
+   /// create makes the scheme, attaches the data and finalises it; the registry owns it
+   static TimeStepper *create(const std::string &Name, TimeStepperType Type, R8 TimeStepSeconds, Tendencies *Tend,
+                              AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, Tracers *Trc);
+   static TimeStepper *get(const std::string &Name);
+   static TimeStepper *getDefault() { return get("Default"); }
+   static void erase(const std::string &Name);
+   static void clear();
    static TimeStepperType getFromStr(const std::string &In); ///< TimeStepper.h:64-75
 
    /// attach the objects the scheme works on (TimeStepper::attachData)

@@ -10,6 +10,7 @@
 #include "Tendencies.h"
 #include "CustomTendencyTerms.h"
 #include "MeshIO.h"
+#include "History.h"
 #include "Rccl.h"
 #include "TimeStepper.h"
 
@@ -457,6 +458,17 @@ int omg_halo_required_bytes(const omg_halo *h, int i, size_t pc, size_t pe, size
    OMG_TRY
    OMG_ARG(h && bytes && i >= 0 && i < h->H->NNghbr);
    *bytes = h->H->requiredBytes(i, pc, pe, pv);
+   OMG_CATCH
+}
+int omg_history_write(const char *path, const omg_decomp *d, const omg_state *s, const omg_tracers *t, omg_aux *a,
+                      const char *contents, double simulation_time, int time_level, int create_file, void *stream,
+                      int *n_variables_written) {
+   OMG_TRY
+   OMG_ARG(path && d && s && a && contents);
+   const int N = writeHistory(path, d->D.get(), s->S.get(), t ? t->T.get() : nullptr, a->A.get(), contents,
+                              simulation_time, time_level, create_file != 0, (hipStream_t)stream);
+   if (n_variables_written)
+      *n_variables_written = N;
    OMG_CATCH
 }
 int omg_rccl_get_unique_id(char *id) {
@@ -1113,7 +1125,7 @@ int omg_stepper_create(const char *type, double dt, omg_tend *t, omg_aux *a, con
       OMEGA_ABORT(std::string("TimeStepper: unknown type ") + type);
    auto *R = new omg_stepper;
    try {
-      R->St.reset(TimeStepper::create("Default", Ty, dt));
+      R->St.reset(TimeStepper::make("Default", Ty, dt));
       R->St->attachData(t->T.get(), a->A.get(), m->M.get(), halo ? halo->H.get() : nullptr, tr->T.get());
       R->St->finalizeInit();
    } catch (...) {

@@ -149,8 +149,8 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0) {
    if (EnvSplit >= 0)
       Split = EnvSplit > 0 ? (EnvSplit < NChunks ? EnvSplit : NChunks) : 1;
    else
-      while (Split < NChunks && (long)NTiles * Split < 2048)
-         Split *= 2;
+      while (Split < NChunks && (long)NTiles * Split < 1200) // measured: QU240-sized (882 tiles) 77 -> 64 us at 2,
+         Split *= 2;                                         // 74 us at 4; an eighth of QU30 (7225 tiles) loses at any
    if (Split > NChunks)
       Split = NChunks;
    G.Grid = dim3(NTiles > 0 ? NTiles : 1, Split > 0 ? Split : 1, 1);

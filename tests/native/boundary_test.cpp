@@ -1,0 +1,241 @@
+// boundary_test.cpp -- a consumer of the C++ boundary (omega_amd/csrc/*.h): compiled with hipcc against the
+// library's headers, linked with libomega_amd.so, driving the path by the reference's class and method names
+// (Decomp / Halo / HorzMesh / OceanState / AuxiliaryState / Tendencies / TimeStepper registries: create, get,
+// getDefault, erase, clear; Tendencies::computeAllTendencies; RungeKutta4Stepper::doStep through TimeStepper;
+// Halo::exchangeFullArrayHalo; DivergenceOnCell; custom tendencies as std::function with a HIP kernel defined
+// HERE).  Checks:
+//   1. fused RHS and one RK4 step against golden vectors (raw little-endian doubles written by the pytest wrapper
+//      from tests/golden/*.npz), bit for bit, on a mesh read from an MPAS file through MeshFile;
+//   2. the reference's time-stepper known answer (test/timeStepping/TimeStepperTest.cpp:375-388): du/dt = -0.5 u as
+//      the custom velocity tendency, T = 1, dt = 0.2 and 0.1, L-inf error orders 4 / 1 / 2 +- 0.1.
+// usage: boundary_test <mesh.nc> <golden_dir> <K> <NT>
+#include "AuxiliaryState.h"
+#include "Decomp.h"
+#include "Halo.h"
+#include "HorzMesh.h"
+#include "HorzOperators.h"
+#include "MeshIO.h"
+#include "OceanState.h"
+#include "Tendencies.h"
+#include "TimeStepper.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+using namespace OMEGA;
+
+static int Failures = 0;
+#define CHECK(cond, what)                                                                                          \
+   do {                                                                                                            \
+      if (!(cond)) {                                                                                               \
+         std::printf("FAIL: %s (%s:%d)\n", what, __FILE__, __LINE__);                                              \
+         ++Failures;                                                                                               \
+      }                                                                                                            \
+   } while (0)
+
+static std::vector<double> readBin(const std::string &Path) {
+   std::ifstream F(Path, std::ios::binary | std::ios::ate);
+   if (!F)
+      throw std::runtime_error("cannot open " + Path);
+   const size_t N = (size_t)F.tellg() / sizeof(double);
+   std::vector<double> V(N);
+   F.seekg(0);
+   F.read(reinterpret_cast<char *>(V.data()), (std::streamsize)(N * sizeof(double)));
+   return V;
+}
+
+// global [nGlobal][K] -> local [rowsSize][K] through 1-based ids (sentinel row zero)
+static std::vector<double> toLocal(const std::vector<double> &G, const HostArrayI4 &ID, int RowsSize, int K, int NT = 1,
+                                   size_t NGlobal = 0) {
+   std::vector<double> L((size_t)NT * RowsSize * K, 0.0);
+   for (int T = 0; T < NT; ++T)
+      for (int R = 0; R + 1 < RowsSize; ++R)
+         std::memcpy(&L[((size_t)T * RowsSize + R) * K], &G[((size_t)T * NGlobal + (ID(R) - 1)) * K], K * sizeof(double));
+   return L;
+}
+static bool sameRows(const std::vector<double> &Local, const std::vector<double> &Glob, const HostArrayI4 &ID, int NOwned,
+                     int RowsSize, int K, int NT = 1, size_t NGlobal = 0) {
+   for (int T = 0; T < NT; ++T)
+      for (int R = 0; R < NOwned; ++R)
+         if (std::memcmp(&Local[((size_t)T * RowsSize + R) * K], &Glob[((size_t)T * NGlobal + (ID(R) - 1)) * K],
+                         K * sizeof(double)) != 0)
+            return false;
+   return true;
+}
+
+// DecayVelocityTendency of the reference test (TimeStepperTest.cpp:49-73) as this program's own HIP kernel
+__global__ void decayKernel(double *Tend, const double *U, int NRows, int K, int Pitch, double Coeff) {
+   const int I = blockIdx.x * blockDim.x + threadIdx.x;
+   if (I < NRows * K) {
+      const int R = I / K, L = I - R * K;
+      Tend[(size_t)R * Pitch + L] -= Coeff * U[(size_t)R * Pitch + L];
+   }
+}
+
+int main(int argc, char **argv) {
+   if (argc < 5) {
+      std::printf("usage: %s mesh.nc golden_dir K NT\n", argv[0]);
+      return 2;
+   }
+   try {
+      const std::string Dir = argv[2];
+      const int K = std::atoi(argv[3]), NT = std::atoi(argv[4]);
+      deviceInit(0);
+      MeshFile File(argv[1]);
+
+      // ---- objects through the registries, by the reference's names ----
+      Decomp *DefDecomp = Decomp::create("Default", File.desc(), 1, 0, 3);
+      CHECK(DefDecomp && Decomp::getDefault() == DefDecomp, "Decomp::create / getDefault");
+      CHECK(Decomp::create("Default", File.desc(), 1, 0, 3) == nullptr, "second create with the same name must fail");
+      Halo *DefHalo     = Halo::create("Default", DefDecomp);
+      HorzMesh *DefMesh = HorzMesh::create("Default", DefDecomp, K);
+      OceanState *State = OceanState::create("Default", DefMesh, DefHalo, K, 2);
+      AuxiliaryState *Aux = AuxiliaryState::create("Default", DefMesh, DefHalo, K, NT);
+      Tendencies *Tend    = Tendencies::create("Default", DefMesh, K, NT, TendParams{});
+      Tracers Trc(DefMesh, DefHalo, K, NT, 2);
+      CHECK(HorzMesh::get("Default") == DefMesh && Tendencies::get("nope") == nullptr, "get by name");
+      const size_t NCg = File.desc().NCells, NEg = File.desc().NEdges;
+
+      // ---- 1. golden vectors ----
+      const auto Hg = readBin(Dir + "/h.bin"), Ug = readBin(Dir + "/u.bin"), Trg = readBin(Dir + "/tr.bin");
+      const auto Hl = toLocal(Hg, DefDecomp->CellIDH, DefMesh->NCellsSize, K);
+      const auto Ul = toLocal(Ug, DefDecomp->EdgeIDH, DefMesh->NEdgesSize, K);
+      const auto Tl = toLocal(Trg, DefDecomp->CellIDH, DefMesh->NCellsSize, K, NT, NCg);
+      State->copyToDevice(Hl.data(), Ul.data(), 0);
+      Trc.copyToDevice(Tl.data(), 0);
+      hipStream_t S;
+      HIP_CHECK(hipStreamCreate(&S));
+      Array3DReal TracerArray;
+      Trc.getAll(TracerArray, 0);
+      Tendencies::getDefault()->computeAllTendencies(State, Aux, TracerArray, 0, 0, S);
+      HIP_CHECK(hipStreamSynchronize(S));
+      std::vector<double> HT((size_t)DefMesh->NCellsSize * K), UT((size_t)DefMesh->NEdgesSize * K),
+          TT((size_t)NT * DefMesh->NCellsSize * K);
+      copyToHost(HT.data(), Tend->LayerThicknessTend);
+      copyToHost(UT.data(), Tend->NormalVelocityTend);
+      copyToHost(TT.data(), Tend->TracerTend);
+      CHECK(sameRows(HT, readBin(Dir + "/hTend.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K),
+            "LayerThicknessTend equals the golden vector");
+      CHECK(sameRows(UT, readBin(Dir + "/uTend.bin"), DefDecomp->EdgeIDH, DefMesh->NEdgesOwned, DefMesh->NEdgesSize, K),
+            "NormalVelocityTend equals the golden vector");
+      CHECK(sameRows(TT, readBin(Dir + "/trTend.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K, NT,
+                     NCg),
+            "TracerTend equals the golden vector");
+
+      TimeStepper *Stepper = TimeStepper::create("Default", TimeStepper::getFromStr("RungeKutta4"), 600.0, Tend, Aux,
+                                                 DefMesh, DefHalo, &Trc);
+      CHECK(Stepper && TimeStepper::getDefault() == Stepper, "TimeStepper::create / getDefault");
+      Stepper->doStep(State, S);
+      HIP_CHECK(hipStreamSynchronize(S));
+      std::vector<double> H1(HT.size()), U1(UT.size()), T1(TT.size());
+      State->copyToHost(H1.data(), U1.data(), 0);
+      Trc.copyToHost(T1.data(), 0);
+      CHECK(sameRows(H1, readBin(Dir + "/rk4_h.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K),
+            "RK4 layer thickness equals the golden vector");
+      CHECK(sameRows(U1, readBin(Dir + "/rk4_u.bin"), DefDecomp->EdgeIDH, DefMesh->NEdgesOwned, DefMesh->NEdgesSize, K),
+            "RK4 normal velocity equals the golden vector");
+      CHECK(sameRows(T1, readBin(Dir + "/rk4_tr.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K, NT,
+                     NCg),
+            "RK4 tracers equal the golden vector");
+
+      // Halo::exchangeFullArrayHalo by its reference name (one rank: nothing to move, must return 0)
+      Array2DReal Hc;
+      State->getLayerThickness(Hc, 0);
+      CHECK(DefHalo->exchangeFullArrayHalo(Hc, OnCell, S) == 0 && State->exchangeHalo(0, S) == 0, "exchangeFullArrayHalo");
+
+      // HorzOperators functor object
+      {
+         Array2DReal Div = Array2DReal::levels("Div", DefMesh->NCellsSize, K), Un;
+         State->getNormalVelocity(Un, 0);
+         DivergenceOnCell DivOp(DefMesh);
+         DivOp(Div, Un, S);
+         Aux->computeMomAux(State, 0, 0, S);
+         HIP_CHECK(hipStreamSynchronize(S));
+         std::vector<double> A((size_t)DefMesh->NCellsSize * K), B(A.size());
+         copyToHost(A.data(), Div);
+         copyToHost(B.data(), Aux->KineticAux.VelocityDivCell);
+         // VelocityDivCell uses the (Dv*InvArea*Sign)*u product order, DivergenceOnCell (Dv*Sign)*u*InvArea: equal
+         // to rounding, not bitwise
+         double MaxRel = 0, Mx = 0;
+         for (size_t I = 0; I < A.size(); ++I)
+            Mx = std::fmax(Mx, std::fabs(B[I]));
+         for (size_t I = 0; I < (size_t)DefMesh->NCellsOwned * K; ++I)
+            MaxRel = std::fmax(MaxRel, std::fabs(A[I] - B[I]) / Mx);
+         CHECK(Mx > 0 && MaxRel < 1e-14, "DivergenceOnCell agrees with KineticAuxVars' divergence");
+      }
+
+      // ---- 2. TimeStepperTest: orders 4 / 1 / 2 with du/dt = -0.5 u ----
+      {
+         const int K1 = 1;
+         OceanState *TestState = OceanState::create("TestState", DefMesh, DefHalo, K1, 2);
+         AuxiliaryState *TestAux = AuxiliaryState::create("TestAuxState", DefMesh, DefHalo, K1, NT);
+         TendParams Off;
+         Off.ThicknessFluxTendencyEnable = Off.PVTendencyEnable = Off.KETendencyEnable = Off.SSHTendencyEnable = 0;
+         Off.VelDiffTendencyEnable = Off.VelHyperDiffTendencyEnable = Off.TracerHorzAdvTendencyEnable = 0;
+         Off.TracerDiffTendencyEnable = Off.TracerHyperDiffTendencyEnable = 0;
+         Tendencies *TestTend = Tendencies::create("TestTendencies", DefMesh, K1, NT, Off);
+         const double Coeff   = 0.5;
+         TestTend->CustomVelocityTend = [Coeff, DefMesh](const Array2DReal &NormalVelTend, const OceanState *St,
+                                                         const AuxiliaryState *, int, int VelLvl, R8, hipStream_t Str) {
+            Array2DReal NormalVelEdge;
+            St->getNormalVelocity(NormalVelEdge, VelLvl);
+            const int N = DefMesh->NEdgesAll * NormalVelTend.Ext[1];
+            hipLaunchKernelGGL(decayKernel, dim3((N + 255) / 256), dim3(256), 0, Str, NormalVelTend.Ptr, NormalVelEdge.Ptr,
+                               DefMesh->NEdgesAll, NormalVelTend.Ext[1], NormalVelTend.Pitch, Coeff);
+         };
+         Tracers TestTrc(DefMesh, DefHalo, K1, NT, 2);
+         const double TimeEnd = 1.0, Exact = std::exp(-Coeff * TimeEnd);
+         const struct {
+            const char *Name;
+            double Order;
+         } Schemes[3] = {{"RungeKutta4", 4.0}, {"Forward-Backward", 1.0}, {"RungeKutta2", 2.0}};
+         for (const auto &Sch : Schemes) {
+            double Err[2];
+            double Dt = 0.2;
+            for (int Ref = 0; Ref < 2; ++Ref, Dt /= 2) {
+               const int NSteps = (int)std::ceil(TimeEnd / Dt);
+               TimeStepper *St  = TimeStepper::create("TestTimeStepper", TimeStepper::getFromStr(Sch.Name), TimeEnd / NSteps,
+                                                      TestTend, TestAux, DefMesh, DefHalo, &TestTrc);
+               std::vector<double> One1((size_t)DefMesh->NCellsSize * K1, 1.0), OneE((size_t)DefMesh->NEdgesSize * K1, 1.0),
+                   OneT((size_t)NT * DefMesh->NCellsSize * K1, 1.0);
+               TestState->copyToDevice(One1.data(), OneE.data(), 0);
+               TestTrc.copyToDevice(OneT.data(), 0);
+               for (int I = 0; I < NSteps; ++I)
+                  St->doStep(TestState, S);
+               HIP_CHECK(hipStreamSynchronize(S));
+               TestState->copyToHost(One1.data(), OneE.data(), 0);
+               double E = 0;
+               for (int R = 0; R < DefMesh->NEdgesOwned; ++R)
+                  E = std::fmax(E, std::fabs(OneE[R] - Exact));
+               Err[Ref] = E;
+               TimeStepper::erase("TestTimeStepper");
+            }
+            const double Rate = std::log2(Err[0] / Err[1]);
+            std::printf("%-17s errors %.3e %.3e  order %.3f (expected %.0f)\n", Sch.Name, Err[0], Err[1], Rate, Sch.Order);
+            CHECK(std::fabs(Rate - Sch.Order) <= 0.1, "time stepper convergence order");
+         }
+         Tendencies::erase("TestTendencies");
+         CHECK(Tendencies::get("TestTendencies") == nullptr, "erase");
+      }
+      HIP_CHECK(hipStreamDestroy(S));
+      // reference shutdown order (TimeStepperTest.cpp finalizeTimeStepperTest)
+      TimeStepper::clear();
+      Tendencies::clear();
+      AuxiliaryState::clear();
+      OceanState::clear();
+      HorzMesh::clear();
+      Halo::clear();
+      Decomp::clear();
+      CHECK(Decomp::getDefault() == nullptr, "clear");
+   } catch (const std::exception &E) {
+      std::printf("FAIL: exception: %s\n", E.what());
+      return 1;
+   }
+   if (Failures == 0)
+      std::printf("boundary_test OK\n");
+   return Failures == 0 ? 0 : 1;
+}
