@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--block", type=int, default=1,
                     help="cell numbering of the synthetic INPUT mesh (what a mesh file would hold): 1 = row-major (default), "
                          "0 = Morton curve, -1 = Hilbert curve, n > 1 = n x n blocks")
+    ap.add_argument("--partition", default="graph", choices=["graph", "rcb"],
+                    help="N > 1: built-in partitioner of the cell graph (graph = recursive graph bisection + FM / k-way "
+                         "refinement, the stand-in for the reference's METIS k-way; rcb = coordinate bisection)")
     ap.add_argument("--local-order", default="curve", choices=["curve", "global"],
                     help="local numbering chosen by Decomp: curve = along a Morton curve through the cell centres "
                          "(default: the library owns data locality), global = the reference's global-id order")
@@ -139,7 +142,8 @@ def main():
     elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
     gm = oa.GlobalMesh(g)
-    decomp = oa.Decomp(gm, N, rank, halo_width, local_order=args.local_order)
+    cell_task, edge_cut = (oa.partition_cells(gm, N, args.partition) if N > 1 else (None, 0))
+    decomp = oa.Decomp(gm, N, rank, halo_width, cell_task=cell_task, local_order=args.local_order)
     mesh = oa.HorzMesh(decomp, K)
     halo = oa.Halo(decomp) if N > 1 else None
     cell_id, edge_id = decomp.get_array("CellID"), decomp.get_array("EdgeID")
@@ -308,7 +312,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
-                          "partition": f"rcb{N}", "halo_width": halo_width,
+                          "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else
                           ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
                            "host-staged gloo (rehearsal)"),

@@ -150,6 +150,14 @@ int omg_decomp_create(const omg_global_mesh *mesh, int nparts, int mytask, int h
  * cells in both cases).  Per global id the results of every computation are identical. */
 int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
                               const int32_t *cell_task, int local_order, omg_decomp **out);
+/* Built-in partitioners of the cell graph (the reference calls METIS_PartGraphKway, O/src/base/Decomp.cpp:868-1000):
+ * method "rcb" = recursive coordinate bisection of the cell centres (what omg_decomp_create uses when cell_task is
+ * NULL), "graph" = recursive graph bisection with Fiduccia-Mattheyses refinement + greedy k-way refinement on
+ * CellsOnCell (no coordinates needed; minimises the edge cut = halo size within a 3 % imbalance tolerance).
+ * cell_task_out[nCells] receives the owner task of every cell -- hand it to omg_decomp_create* as cell_task.
+ * edge_cut (optional): number of cell-graph edges between different parts. */
+int omg_partition_cells(const omg_global_mesh *mesh, int nparts, const char *method, int32_t *cell_task_out,
+                        int64_t *edge_cut);
 int omg_decomp_destroy(omg_decomp *d);
 /* scalar members by reference name: "NCellsOwned", "NCellsAll", "NCellsSize", "NCellsGlobal",
  * "NEdges...", "NVertices...", "MaxEdges", "VertexDegree", "HaloWidth" */

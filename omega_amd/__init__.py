@@ -381,6 +381,14 @@ def read_partition_file(path: str) -> np.ndarray:
     return np.loadtxt(path, dtype=np.int32, ndmin=1)
 
 
+def partition_cells(gm: GlobalMesh, nparts: int, method: str = "graph"):
+    """(cell_task[nCells], edge_cut) of the built-in partitioners: "rcb" or "graph" (omg_partition_cells)."""
+    out = np.zeros(gm.s.nCells, dtype=np.int32)
+    cut = C.c_int64()
+    _chk(lib().omg_partition_cells(C.byref(gm.s), nparts, method.encode(), _pi(out), C.byref(cut)))
+    return out, cut.value
+
+
 class Decomp:
     def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None,
                  local_order: str = "global"):

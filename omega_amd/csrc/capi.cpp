@@ -10,6 +10,7 @@
 #include "Tendencies.h"
 #include "CustomTendencyTerms.h"
 #include "MeshIO.h"
+#include "Partition.h"
 #include "History.h"
 #include "Rccl.h"
 #include "TimeStepper.h"
@@ -354,6 +355,26 @@ int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytas
       throw;
    }
    *out = R;
+   OMG_CATCH
+}
+int omg_partition_cells(const omg_global_mesh *mesh, int nparts, const char *method, int32_t *cell_task_out,
+                        int64_t *edge_cut) {
+   OMG_TRY
+   OMG_ARG(mesh && method && cell_task_out && nparts >= 1);
+   const GlobalMeshDesc G = toDesc(*mesh);
+   std::vector<I4> T;
+   const std::string M(method);
+   if (M == "graph") {
+      partitionGraph(G, nparts, T);
+   } else if (M == "rcb") {
+      Decomp D(G, nparts, 0, 1, nullptr);
+      T = D.CellTask;
+   } else {
+      OMEGA_ABORT("omg_partition_cells: method must be \"rcb\" or \"graph\"");
+   }
+   std::memcpy(cell_task_out, T.data(), T.size() * sizeof(I4));
+   if (edge_cut)
+      *edge_cut = edgeCut(G, T);
    OMG_CATCH
 }
 int omg_decomp_destroy(omg_decomp *d) {

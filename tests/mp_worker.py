@@ -37,6 +37,7 @@ def main():
                     help="gpu mode: step on a non-blocking stream created with omg_stream_create instead of the default stream")
     ap.add_argument("--local-order", default="global", choices=["global", "curve"],
                     help="Decomp local numbering: the reference's (global id) or along a Morton curve")
+    ap.add_argument("--partition", default="rcb", choices=["rcb", "graph"], help="built-in partitioner (omg_partition_cells)")
     ap.add_argument("--rtol", type=float, default=0.0,
                     help="0 = owned elements must equal the single-rank run bit for bit; > 0 = the partitioned run may "
                          "deviate by at most this (relative to the field's max), and MUST deviate (the setting is known "
@@ -66,7 +67,7 @@ def main():
         oa.device_init(0)
     cfg = {"VelHyperDiffTendencyEnable": 0, "TracerHyperDiffTendencyEnable": 0} if a.no_del4 else {}
     P = Problem(g, K, NT, nparts=a.world, rank=a.rank, device=gpu, config=cfg, halo_width=a.halo_width,
-                local_order=a.local_order)
+                local_order=a.local_order, partition=a.partition)
     m = P.mesh
     halo = P.halo if gpu else oa.Halo(P.decomp)
     nbrs = halo.neighbors

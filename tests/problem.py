@@ -18,10 +18,11 @@ class Problem:
     """One rank's view of a global mesh: product objects (if a GPU is present) + oracle."""
 
     def __init__(self, g, K, NT, nparts=1, rank=0, device=True, config=None, seed=20251003, halo_width=3,
-                 oracle=True, local_order="global"):
+                 oracle=True, local_order="global", partition="rcb"):
         self.g, self.K, self.NT = g, K, NT
         self.gm = oa.GlobalMesh(g)
-        self.decomp = oa.Decomp(self.gm, nparts, rank, halo_width, local_order=local_order)
+        cell_task = oa.partition_cells(self.gm, nparts, "graph")[0] if (partition == "graph" and nparts > 1) else None
+        self.decomp = oa.Decomp(self.gm, nparts, rank, halo_width, cell_task=cell_task, local_order=local_order)
         self.mesh = oa.HorzMesh(self.decomp, K, host_only=not device)
         self.cell_id = self.decomp.get_array("CellID")
         self.edge_id = self.decomp.get_array("EdgeID")

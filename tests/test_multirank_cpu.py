@@ -59,6 +59,7 @@ def run_ranks(mode, world, extra=(), timeout=600):
     (3, ["--no-del4", "--mesh", "ico3", "--levels", 3]),                # sphere, 12 pentagons, RCB in 3-D
     (2, ["--halo-width", 5, "--mesh", "fib700", "--levels", 3, "--steps", 1]),  # pentagons + heptagons, del4 on
     (3, ["--halo-width", 4, "--nx", 24, "--ny", 24, "--local-order", "curve"]),  # local numbering along a Morton curve
+    (3, ["--no-del4", "--mesh", "ico3", "--levels", 3, "--partition", "graph"]),   # built-in graph partitioner
 ])
 def test_partitioned_oracle_matches_single_rank(world, extra):
     outs = run_ranks("cpu", world, extra)
@@ -158,3 +159,50 @@ def test_single_rank_local_mesh_equals_identity_numbering_up_to_permutation():
     assert np.array_equal(uT[:-1], uTi[P.edge_id[:-1] - 1])
     assert np.array_equal(trT[:, :-1], trTi[:, P.cell_id[:-1] - 1])
     assert not np.array_equal(P.edge_id[:-1], np.arange(1, g["nEdges"] + 1)), "expected a non-trivial edge renumbering"
+
+
+def _variable_resolution_sphere(n=2500, seed=3):
+    """Voronoi mesh of points whose density grows towards one pole (cells ~4x smaller there)."""
+    from omega_amd.meshgen import spherical_voronoi
+    rng = np.random.default_rng(seed)
+    u = rng.random(6 * n)
+    z = 1.0 - 2.0 * u ** 1.8                     # more points near z = +1
+    keep = rng.random(6 * n) < 0.5
+    z = z[keep][:n]
+    phi = rng.random(z.size) * 2 * np.pi
+    r = np.sqrt(1 - z * z)
+    pts = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
+    return spherical_voronoi(points=pts, lloyd=3)
+
+
+@pytest.mark.parametrize("mesh", ["hex", "ico4", "variable"])
+@pytest.mark.parametrize("nparts", [2, 5, 8])
+def test_graph_partitioner_balance_cut_and_determinism(mesh, nparts):
+    """omg_partition_cells("graph") (the stand-in for METIS_PartGraphKway, Decomp.cpp:968): every part within 3 % of the
+    mean size (+-1 cell), connected parts on these meshes, an edge cut no worse than 1.3 x the coordinate bisection's
+    (and lower on the sphere, where RCB's planes cut obliquely), the same answer every time."""
+    from omega_amd.meshgen import icosahedral_points, spherical_voronoi
+    g = (planar_hex(48, 40, 1.0) if mesh == "hex" else
+         spherical_voronoi(points=icosahedral_points(4), lloyd=1) if mesh == "ico4" else _variable_resolution_sphere())
+    gm = oa.GlobalMesh(g)
+    t, cut = oa.partition_cells(gm, nparts, "graph")
+    t2, cut2 = oa.partition_cells(gm, nparts, "graph")
+    assert np.array_equal(t, t2) and cut == cut2
+    sizes = np.bincount(t, minlength=nparts)
+    mean = g["nCells"] / nparts
+    assert sizes.min() > 0 and sizes.max() <= 1.03 * mean + 2 and sizes.min() >= 0.97 * mean - 2, sizes
+    _, cut_rcb = oa.partition_cells(gm, nparts, "rcb")
+    assert cut <= 1.3 * cut_rcb, (cut, cut_rcb)
+    if mesh != "hex":
+        assert cut <= 1.05 * cut_rcb, (cut, cut_rcb)
+    # the cut it reports is the cut of the vector it returns
+    coc = np.asarray(g["cellsOnCell"])
+    valid = coc >= 0
+    mine = np.repeat(t[:, None], coc.shape[1], axis=1)
+    assert cut == int((valid & (t[np.where(valid, coc, 0)] != mine)).sum() // 2)
+    # every rank's Decomp built from it owns each element once
+    tot = 0
+    for r in range(nparts):
+        d = oa.Decomp(gm, nparts, r, 2, cell_task=t)
+        tot += d.get_int("NCellsOwned")
+    assert tot == g["nCells"]
