@@ -15,10 +15,10 @@ mkdir -p $OUT
 ARGS="--steps 8 --warmup 2 --rk4-steps 2 --no-cpu-baseline $*"
 python3 bench.py --steps 20 --warmup 3 $* > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "[profile] bench done"
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t -- python3 bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 echo "[profile] kernel trace done"
-rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o f -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
 echo "[profile] FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/${TAG}_pmc_write -o w -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1
 echo "[profile] WRITE_SIZE pass done"
 python3 tools/summarise_profile.py $TAG $*
