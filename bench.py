@@ -58,7 +58,6 @@ def algorithmic_bytes_per_cell_level(nt, kernel=None):
         "FusedCellL1PVBody": 8 * (3 + 1 + nt + 3 + nt + 2 * 2 + 3),
         "Del2CellRingBody": 8 * (1 + 2 + 1),                    # Div, RelVort -> Del2Div
         "Del2VertexSelBody": 8 * (1 + 2 + 2),                   # Div, RelVort -> Del2RelVort
-        "Del2CellVertBody": 8 * (1 + 2 + 1 + 2),                # Div, RelVort -> Del2Div, Del2RelVort (one pass)
         "CellPVBody<side 0>": 8 * (3 + 1 + 2 * 2 + 3),          # u, h, RelVort, InvThick -> running PV sums
         "CellPVFinalBody": 8 * (3 + 1 + 2 * 2 + 3 + 3 + 2 + 3),  # + sums, KE, Div, Del2Div, Del2RV -> uTend
         "FusedCell3Body": 8 * (nt + nt + 1 + 3 + nt),           # tr, Del2Tr, h, u -> trTend

@@ -389,7 +389,7 @@ void HorzMesh::buildCoefficientTables() {
    buildBandLists((I4)NCellsHaloH.size());
    // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
    if (const char *Fg = getenv("OMEGA_FORCE_GENERIC"); Fg && atoi(Fg) == 1)
-      W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = W.CellL1OK = W.CellL2OK = 0;
+      W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = W.CellL1OK = 0;
 }
 
 // Band / interior split of the local cells for overlapping a halo exchange with interior work
@@ -522,7 +522,6 @@ void HorzMesh::buildDel2Tables() {
          CurlV(V, J) = -SV * InvDv2(E);
       }
    HostVertRing         = Ring;
-   HostCurlV = CurlV, HostMaskV = MaskV, HostIDcV = IDcV;
    VertRingOnCell       = createDeviceMirrorCopy<I4, 2>("VertRingOnCell", Ring);
    Del2GradMaskSOnCell  = createDeviceMirrorCopy<Real, 2>("Del2GradMaskSOnCell", GradS);
    InvDcOnCell          = createDeviceMirrorCopy<Real, 2>("InvDcOnCell", IDcC);
@@ -613,62 +612,6 @@ void HorzMesh::buildCellL1Tables() {
          if (HostPVRole(C, R) != 0 && HostPVRing(C, R) != HostVertRing(C, R))
             OK = false;
    W.CellL1OK = OK && W.CellPVOK ? 1 : 0;
-   HostSpoke = Spoke, HostVortSel = Sel;
-
-   // ---- the del2 of the relative vorticity at the vertices a cell stores (HorzMesh.h: CellL2OK) ----
-   HostArrayI4 Outer(NCellsSize, ME, 1, NVerticesAll), Last(NCellsSize, ME, 1, 0);
-   HostArrayReal Cf(NCellsSize, ME, 12, 0.0);
-   bool OK2 = OK && W.Del2VertOK != 0;
-   for (int C = 0; C < NCellsAll && OK2; ++C) {
-      const int N = NEdgesOnCellH(C);
-      for (int R = 0; R < N && OK2; ++R) {
-         if (!((Sel(C, R) >> 4) & 1))
-            continue;
-         const int V  = HostVertRing(C, R);
-         const int E0 = EdgesOnCellH(C, R), E1 = EdgesOnCellH(C, (R + 1) % N);
-         const int N0 = HostNbrF(C, R) & 0x3fffffff;
-         bool Seen[3] = {false, false, false};
-         for (int J = 0; J < 3 && OK2; ++J) {
-            const int E = EdgesOnVertexH(V, J);
-            int Role;
-            if (E == E0 && !Seen[0])
-               Role = 0;
-            else if (E == E1 && !Seen[1])
-               Role = 1;
-            else if (!Seen[2])
-               Role = 2;
-            else {
-               OK2 = false;
-               break;
-            }
-            Seen[Role] = true;
-            Real Orient = 0.0;
-            if (E < NEdgesAll) {
-               // cell-side difference: role 0 Div(across r) - Div(c), role 1 Div(across r+1) - Div(c),
-               // role 2 Div(across r+1) - Div(across r); the vertex kernel takes Div(CellsOnEdge(e,1)) - Div(CellsOnEdge(e,0))
-               const int Lo = Role == 2 ? N0 : C;
-               Orient       = CellsOnEdgeH(E, 0) == Lo ? 1.0 : -1.0;
-               if (Role == 2) {
-                  const int Vo = VerticesOnEdgeH(E, 0) == V ? VerticesOnEdgeH(E, 1) : VerticesOnEdgeH(E, 0);
-                  Outer(C, R)  = Vo;
-               }
-            }
-            Real *P = &Cf.V[(((size_t)C * ME + R) * 3 + Role) * 4];
-            P[0]    = HostVortC(V, J);
-            P[1]    = HostMaskV(V, J) * Orient;
-            P[2]    = HostIDcV(V, J);
-            P[3]    = HostCurlV(V, J);
-            if (J == 2)
-               Last(C, R) = Role;
-         }
-      }
-   }
-   OuterVertOnCell    = createDeviceMirrorCopy<I4, 2>("OuterVertOnCell", Outer);
-   Del2LastOnCell     = createDeviceMirrorCopy<I4, 2>("Del2LastOnCell", Last);
-   Del2VertCoefOnCell = createDeviceMirrorCopy<Real, 3>("Del2VertCoefOnCell", Cf);
-   W.OuterVertOnCell = OuterVertOnCell.Ptr, W.Del2LastOnCell = Del2LastOnCell.Ptr;
-   W.Del2VertCoefOnCell = Del2VertCoefOnCell.Ptr;
-   W.CellL2OK = OK2 && W.CellL1OK && W.Del2RingOK ? 1 : 0;
 }
 
 // Cell-centric PV tables (see HorzMesh.h).

@@ -108,14 +108,6 @@ struct MeshView {
                                    //   cell stores vertex v
    const Real *KiteCoefOnCell;     // [C][ME][3] KiteCoefOnVertex of the vertex's slot holding {self, across r, across r+1}
    const Real *VortCoefOnCell;     // [C][ME][3] VortCoefOnVertex of the vertex's slot holding {slot r, slot r+1, spoke}
-   // VelocityDel2AuxVars::computeVarsOnVertex from the cell side, for the vertices a cell stores (own bit of
-   // VortSelOnCell): per ring vertex r and per edge ROLE (0 = slot r, 1 = slot r+1, 2 = spoke) the vertex slot's
-   // coefficients, with the orientation of the cell-side difference folded into the mask; the outer vertex (other
-   // end of the spoke); which role sits in the vertex's last slot.  Valid when CellL2OK.
-   I4 CellL2OK;
-   const I4 *OuterVertOnCell;      // [C][ME] other end of the spoke of ring vertex r (sentinel row if none)
-   const I4 *Del2LastOnCell;       // [C][ME] role (0..2) of the edge in the vertex's last slot
-   const Real *Del2VertCoefOnCell; // [C][ME][3 roles][4]: VortCoefOnVertex, EdgeMask x orientation, 1/DcEdge, curl coefficient
    // ---- overlap of halo exchanges with interior work (HorzMesh::buildBandLists) ----
    // BandCells: every halo cell and every owned cell within HaloWidth+1 cells of one (a superset of the cells
    // that own anything a neighbour receives); InteriorCells: the other owned cells.  Ascending order.
@@ -191,10 +183,7 @@ class HorzMesh : public Registry<HorzMesh> {
    void buildCellL1Tables();
    HostArrayI4 HostVertRing, HostPVRing, HostPVRole;
    HostArrayReal HostKiteC, HostVortC;
-   Array2DI4 SpokeOnCell, VortSelOnCell, OuterVertOnCell, Del2LastOnCell;
-   DeviceArray<Real, 3> Del2VertCoefOnCell;
-   HostArrayI4 HostSpoke, HostVortSel;
-   HostArrayReal HostCurlV, HostMaskV, HostIDcV;
+   Array2DI4 SpokeOnCell, VortSelOnCell;
    Array3DReal KiteCoefOnCell, VortCoefOnCell;
    Array2DI4 RingVertOnCell, PVRoleOnCell;
    Array3DReal PVWeightOnCell;

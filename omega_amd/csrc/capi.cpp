@@ -591,7 +591,6 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
       const std::map<std::string, I4> D{{"PVChainOK", W.PVChainOK},
                                         {"CellPVOK", W.CellPVOK},
                                         {"CellL1OK", W.CellL1OK},
-                                        {"CellL2OK", W.CellL2OK},
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
                                         {"Del2RingOK", W.Del2RingOK},

@@ -620,106 +620,6 @@ template <int TME> struct Del2CellRingBody {
    }
 };
 
-// L2 cell pass with the vertex pass folded in (HorzMesh.h: CellL2OK): Del2CellRingBody, plus
-// VelocityDel2AuxVars::computeVarsOnVertex (VelocityDel2AuxVars.h:69-89) at the ring vertices this cell stores.
-// Such a vertex needs Div at its three cells -- this cell and the two neighbours across slots r, r+1, all in
-// registers -- and RelVort at itself, at ring vertices r-1 and r+1 (in registers) and at the outer end of its
-// spoke (the one extra gather).  Its three terms are formed per edge role with the vertex slot's own
-// coefficients and added with the last slot's term last (the first two commute), so the bits are the vertex
-// kernel's.  Div and RelVort are read once instead of twice, one launch less.
-template <int TME> struct Del2CellVertBody {
-   MeshView M;
-   int K;
-   const Real *Div, *RelVort;
-   Real *Del2Div, *Del2RelVort;
-   struct Lds {
-      Real *DivC, *InvDc, *GradS, *CurlC, *VCf;
-      int *Nbr, *Ring, *Outer, *Flag, *N;
-   };
-   size_t ldsBytes(int Tile) const {
-      return ldsRound8(sizeof(Real) * Tile * TME) * 4 + ldsRound8(sizeof(Real) * Tile * TME * 12) +
-             ldsRound8(sizeof(int) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile);
-   }
-   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
-      LdsCarver C{Ptr};
-      Lds L;
-      L.DivC  = C.take<Real>(Tile * TME);
-      L.InvDc = C.take<Real>(Tile * TME);
-      L.GradS = C.take<Real>(Tile * TME);
-      L.CurlC = C.take<Real>(Tile * TME);
-      L.VCf   = C.take<Real>(Tile * TME * 12);
-      L.Nbr   = C.take<int>(Tile * TME);
-      L.Ring  = C.take<int>(Tile * TME);
-      L.Outer = C.take<int>(Tile * TME);
-      L.Flag  = C.take<int>(Tile * TME);
-      L.N     = C.take<int>(Tile);
-      return L;
-   }
-   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
-      for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
-         L.DivC[I]      = M.DivCoefOnCell[G];
-         L.InvDc[I]     = M.InvDcOnCell[G];
-         L.GradS[I]     = M.Del2GradMaskSOnCell[G];
-         L.CurlC[I]     = M.Del2CurlCoefOnCell[G];
-         L.Nbr[I]       = M.NbrFlagOnCell[G] & 0x3fffffff;
-         L.Ring[I]      = M.VertRingOnCell[G];
-         L.Outer[I]     = M.OuterVertOnCell[G];
-         L.Flag[I]      = ((M.VortSelOnCell[G] >> 4) & 1) | (M.Del2LastOnCell[G] << 1); // bit 0 own, bits 1-2 last role
-      }
-      for (int I = Tid; I < Cnt * TME * 12; I += NThr)
-         L.VCf[I] = M.Del2VertCoefOnCell[(size_t)First * TME * 12 + I];
-      for (int I = Tid; I < Cnt; I += NThr)
-         L.N[I] = M.NEdgesOnCell[First + I];
-   }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
-      T Dn[TME], Rv[TME];
-#pragma unroll
-      for (int J = 0; J < TME; ++J) {
-         Dn[J] = ldo<T>(Div, rowOff<T>(L.Nbr[Le * TME + J], K, Kv));
-         Rv[J] = ldo<T>(RelVort, rowOff<T>(L.Ring[Le * TME + J], K, Kv));
-      }
-      const unsigned OffS = rowOff<T>(ICell, K, Kv);
-      const T Ds          = ldo<T>(Div, OffS);
-      {
-         T Tmp = splat<T>(0.0);
-#pragma unroll
-         for (int J = 0; J < TME; ++J) { // exactly Del2CellRingBody
-            const int I      = Le * TME + J;
-            const int Jm     = (J + TME - 1) % TME;
-            const T GradDiv  = (Dn[J] - Ds) * L.InvDc[I];
-            const T CurlVort = (Rv[J] - Rv[Jm]) * L.CurlC[I];
-            const T Del2E    = L.GradS[I] * GradDiv + CurlVort;
-            Tmp -= L.DivC[I] * Del2E;
-         }
-         stnt<T>(Del2Div, OffS, Tmp);
-      }
-      const int N  = L.N[Le];
-      const T Zero = splat<T>(0.0);
-#pragma unroll
-      for (int R = 0; R < TME; ++R) {
-         const int Flag = L.Flag[Le * TME + R];
-         if (!(Flag & 1))
-            continue; // another cell stores this vertex
-         const bool Wrap = (R + 1 >= TME) || (R + 1 >= N); // slot after R in this cell's own cyclic order
-         const T Dn1 = pick(Wrap, Dn[0], Dn[(R + 1) % TME]), Rv1 = pick(Wrap, Rv[0], Rv[(R + 1) % TME]);
-         const T Rvm = Rv[(R + TME - 1) % TME]; // (padded slots repeat the last ring vertex: slot 0 finds N-1 at TME-1)
-         const T Rs  = Rv[R];
-         const T Ro  = ldo<T>(RelVort, rowOff<T>(L.Outer[Le * TME + R], K, Kv));
-         const Real *Cf = &L.VCf[(Le * TME + R) * 12];
-         // role 0: edge slot R (cells: this, across R; other vertex: ring R-1)
-         const T TA = Cf[0] * (Cf[1] * ((Dn[R] - Ds) * Cf[2]) + (Rvm - Rs) * Cf[3]);
-         // role 1: edge slot R+1 (cells: this, across R+1; other vertex: ring R+1)
-         const T TB = Cf[4] * (Cf[5] * ((Dn1 - Ds) * Cf[6]) + (Rv1 - Rs) * Cf[7]);
-         // role 2: the spoke (cells: across R, across R+1; other vertex: its outer end)
-         const T TC = Cf[8] * (Cf[9] * ((Dn1 - Dn[R]) * Cf[10]) + (Ro - Rs) * Cf[11]);
-         const int Lr = (Flag >> 1) & 3;
-         const T X = pick(Lr == 0, TB, TA), Y = pick(Lr == 2, TB, TC), Z = pick(Lr == 0, TA, pick(Lr == 1, TB, TC));
-         stnt<T>(Del2RelVort, rowOff<T>(L.Ring[Le * TME + R], K, Kv), ((Zero + X) + Y) + Z);
-      }
-   }
-};
-
 // L2 vertex pass for VertexDegree 3, each row gathered once (7 instead of 12).
 struct Del2VertexSelBody {
    MeshView M;
@@ -1741,14 +1641,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       launchEdgeAuxState1(M, A, P.WindInterpIsotropic, S);
    // L2 (only the del4 term consumes it)
    Mark(2);
-   static const int MergeL2Env = getenv("OMEGA_MERGE_L2") ? atoi(getenv("OMEGA_MERGE_L2")) : 1;
-   const bool MergeL2         = P.VelHyperDiffTendencyEnable && M.CellL2OK && MergeL2Env != 0;
-   FusedKernelNames[2] = FusedKernelNames[3] = "";
-   if (MergeL2) {
-      FusedKernelNames[2] = "Del2CellVertBody";
-      Del2CellVertBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell, A.Del2RelVortVertex};
-      launchTile(BC, M.NCellsAll, K, S);
-   } else if (P.VelHyperDiffTendencyEnable) {
+   if (P.VelHyperDiffTendencyEnable) {
       FusedKernelNames[2] = M.Del2RingOK ? "Del2CellRingBody" : "FusedDel2CellBody";
       if (M.Del2RingOK) {
          Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
@@ -1759,7 +1652,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       }
    }
    Mark(3);
-   if (P.VelHyperDiffTendencyEnable && !MergeL2) {
+   if (P.VelHyperDiffTendencyEnable) {
       FusedKernelNames[3] = M.Del2VertOK ? "Del2VertexSelBody" : "FusedDel2VertexBody";
       if (M.Del2VertOK) {
          Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
