@@ -254,6 +254,38 @@ def main():
             if N > 1 and rank != 0:
                 os._exit(3)   # the launcher tears the job down; peers must not wait for this rank
 
+    # ------------------------------------------------ N > 1: the overlapped exchange against the sequential one
+    # The one-GPU development boxes can only run the exchange logic over a host-staged wire, which synchronises the
+    # streams; here, on the real wire, two short runs from the same initial state -- exchanges overlapped with the
+    # interior work, and exchanges after the stage -- must leave the same bits (global double-double checksum of h, u
+    # and the tracers over owned elements, combined in rank order).
+    overlap_check = None
+    if N > 1 and nrk > 0 and rk4_error is None and overlap:
+        try:
+            def checksum(mode_overlap):
+                state.copy_to_device(h, u, 0)
+                tracers.copy_to_device(tr, 0)
+                st2 = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
+                st2.set_option("OverlapHaloExchange", mode_overlap)
+                for _ in range(2):
+                    st2.do_step(state, stream=stream)
+                oa.device_synchronize()
+                kp = oa.level_pitch(K)
+                parts = [oa.local_weighted_sum_dd(ones_c.ptr, state.device_ptr(0, 0), mesh.NCellsOwned, K, row_pitch=kp,
+                                                  stream=stream),
+                         oa.local_weighted_sum_dd(ones_e.ptr, state.device_ptr(1, 0), mesh.NEdgesOwned, K, row_pitch=kp,
+                                                  stream=stream)]
+                parts += [oa.local_weighted_sum_dd(ones_c.ptr, tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp,
+                                                   mesh.NCellsOwned, K, row_pitch=kp, stream=stream) for l in range(NT)]
+                return [oa.global_sum_dd(p) for p in parts]
+            ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
+            a, b = checksum(True), checksum(False)
+            overlap_check = {"overlapped_equals_sequential": a == b, "checksums_h_u_tracers": a}
+        except Exception as exc:  # noqa: BLE001
+            overlap_check = {"error": f"rank {rank}: {type(exc).__name__}: {exc}"}
+            if rank != 0:
+                os._exit(3)
+
     # ------------------------------------------------ roofline of the dominant kernel (rank 0's view)
     roofline = None
     if ktimes:
@@ -325,7 +357,7 @@ def main():
                        "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
                        "halo_exchange": "none (1 rank)" if N == 1 else
                        ("overlapped with the stage's interior cells" if overlap else "after the stage"),
-                       "error": rk4_error},
+                       "error": rk4_error, "overlap_check": overlap_check},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if N > 1:

@@ -121,6 +121,13 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
 
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
                                       int ThickLvl, int VelLvl, hipStream_t S) {
+   if (UseFusedRHS && !fusedRHSSupported(Mesh->view(), NVertLayers) && !WarnedUnfused) {
+      // (32-bit byte offsets inside an array plane: more than ~2.2 M cells x 80 levels per GPU, or MaxEdges outside 5..8)
+      std::fprintf(stderr,
+                   "[omega_amd] Tendencies: this mesh / level count is outside the fused RHS (array planes of 4 GiB or "
+                   "more, or MaxEdges outside 5..8): computeAllTendencies uses the reference-structured 23-launch path\n");
+      WarnedUnfused = true;
+   }
    if (UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)) {
       Array2DReal LayerThick, NormVel;
       OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 &&

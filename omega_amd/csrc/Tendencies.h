@@ -78,6 +78,7 @@ class Tendencies : public Registry<Tendencies> {
  private:
    Array2DReal EdgeScratch; ///< running PV sums of the fused RHS (allocated on first use)
    bool TimingOn = false;
+   bool WarnedUnfused = false;
    std::vector<std::vector<hipEvent_t>> TimingEvents;
    /// AuxiliaryState options are read by AuxiliaryState::readConfigOptions in the reference;
    /// the kernels take them through TendParams, so sync them from the AuxState in use.
