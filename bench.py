@@ -262,6 +262,8 @@ def main():
     overlap_check = None
     if N > 1 and nrk > 0 and rk4_error is None and overlap:
         try:
+            ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
+
             def checksum(mode_overlap):
                 state.copy_to_device(h, u, 0)
                 tracers.copy_to_device(tr, 0)
@@ -278,7 +280,6 @@ def main():
                 parts += [oa.local_weighted_sum_dd(ones_c.ptr, tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp,
                                                    mesh.NCellsOwned, K, row_pitch=kp, stream=stream) for l in range(NT)]
                 return [oa.global_sum_dd(p) for p in parts]
-            ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
             a, b = checksum(True), checksum(False)
             overlap_check = {"overlapped_equals_sequential": a == b, "checksums_h_u_tracers": a}
         except Exception as exc:  # noqa: BLE001
