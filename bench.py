@@ -118,6 +118,11 @@ def main():
     stream = None
     if args.backend == "nccl":
         args.backend = "rccl"
+    # stdout carries exactly ONE line, the JSON record: libraries that chat on stdout (gloo prints its connection
+    # summary there) are sent to stderr until the record is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if N > 1:
         # torch.distributed is the rendezvous / side channel only (gloo, CPU): it distributes the RCCL unique id and
         # carries the timing reductions; the halo data path is RCCL inside libomega_amd.  torch never touches the GPU.
@@ -126,6 +131,7 @@ def main():
         import torch.distributed as dist
         if args.single_device:
             local_rank = 0
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the side channel stays on the loopback device
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
     oa.device_init(local_rank)
     halo_width = args.halo_width if args.halo_width > 0 else (4 if N > 1 else 3)
@@ -360,7 +366,10 @@ def main():
                        ("overlapped with the stage's interior cells" if overlap else "after the stage"),
                        "error": rk4_error, "overlap_check": overlap_check},
                "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if N > 1:
         dist.barrier()
         dist.destroy_process_group()
