@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("OMEGA_BENCH_WORKLOAD", "qu30"), choices=sorted(WORKLOADS))
     ap.add_argument("--rk4-steps", type=int, default=-1, help="RK4 steps for SYPD (default: max(2, steps//4))")
-    ap.add_argument("--dt", type=float, default=600.0, help="time step [s] (Default.yml TimeStep 10 min)")
+    ap.add_argument("--dt", type=float, default=0.0,
+                    help="time step [s]; 0 = Default.yml's 10 minutes at 30 km cells, scaled with the workload's cell size")
     ap.add_argument("--block", type=int, default=1,
                     help="cell numbering of the synthetic INPUT mesh (what a mesh file would hold): 1 = row-major (default), "
                          "0 = Morton curve, -1 = Hilbert curve, n > 1 = n x n blocks")
@@ -114,6 +115,9 @@ def main():
     N = world
 
     nx, ny, dc, K, NT, desc = WORKLOADS[args.workload]
+    if args.dt <= 0:
+        cell = dc if dc > 0 else (4.0 * np.pi * 6371.22e3 ** 2 / (10 * 4 ** ny + 2)) ** 0.5   # icosahedral: mean spacing
+        args.dt = 600.0 * cell / 30.0e3
     dist = None
     stream = None
     if args.backend == "nccl":
