@@ -80,6 +80,15 @@ def test_halo_width_3_with_del4_is_only_approximately_partition_independent(worl
     assert all("OK" in o and "max deviation" in o for o in outs)
 
 
+def test_eight_ranks_as_the_scaling_bench_partitions_them():
+    """The driver's largest run: 8 ranks, graph partition, Morton-ordered local numbering, HaloWidth 4, every
+    Default.yml term -- Decomp / Halo lists of every rank (up to 7 neighbours each, corner halos) driving the oracle
+    over gloo must reproduce the single-rank run bit for bit."""
+    outs = run_ranks("cpu", 8, ["--halo-width", 4, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 2,
+                                "--partition", "graph", "--local-order", "curve"], timeout=900)
+    assert all("OK" in o for o in outs)
+
+
 def test_halo_width_4_with_del4_is_partition_independent():
     """The setting bench.py uses for N > 1 (HaloWidth 4, Default.yml terms incl. del4, 6 tracers): bit-exact."""
     outs = run_ranks("cpu", 4, ["--halo-width", 4, "--nx", 32, "--ny", 32, "--levels", 3, "--tracers", 6])
