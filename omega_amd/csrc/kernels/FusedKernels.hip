@@ -1641,7 +1641,16 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       launchEdgeAuxState1(M, A, P.WindInterpIsotropic, S);
    // L2 (only the del4 term consumes it)
    Mark(2);
-   if (P.VelHyperDiffTendencyEnable) {
+   // independent sweeps share a launch (KernelCommon.h: tileKernel2); OMEGA_PAIR=0 launches them one by one
+   static const int PairEnv = getenv("OMEGA_PAIR") ? atoi(getenv("OMEGA_PAIR")) : 1;
+   const bool PairL2        = PairEnv && P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.Del2VertOK;
+   FusedKernelNames[2] = FusedKernelNames[3] = "";
+   if (PairL2) {
+      FusedKernelNames[2] = "Del2CellRingBody+Del2VertexSelBody";
+      Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+      Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
+      launchTile2(BC, M.NCellsAll, BV, M.NVerticesAll, K, S);
+   } else if (P.VelHyperDiffTendencyEnable) {
       FusedKernelNames[2] = M.Del2RingOK ? "Del2CellRingBody" : "FusedDel2CellBody";
       if (M.Del2RingOK) {
          Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
@@ -1652,7 +1661,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       }
    }
    Mark(3);
-   if (P.VelHyperDiffTendencyEnable) {
+   if (P.VelHyperDiffTendencyEnable && !PairL2) {
       FusedKernelNames[3] = M.Del2VertOK ? "Del2VertexSelBody" : "FusedDel2VertexBody";
       if (M.Del2VertOK) {
          Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
@@ -1670,6 +1679,10 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // OMEGA_EDGE_MODE=1 forces the edge-centric chain kernel (the fallback of meshes without the
    // cell-centric PV tables) for A/B measurements
    static const int EdgeMode = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
+   static const int FuseFinalEnv = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
+   // the side-1 PV + velocity kernel and the tracer kernel are independent: their main sweeps share a launch
+   const bool PairL3 = PairEnv && Fast && EdgeMode == 0 && M.CellPVOK && EdgeScratch && P.PVTendencyEnable &&
+                       FuseFinalEnv && M.CellPVFinalOK && NT > 0 && M.NRingCellsM0 > 0;
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
@@ -1717,7 +1730,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 UTend,
                                                 nullptr,
                                                 EU};
-               if (M.NRingCellsM0 > 0) {
+               if (M.NRingCellsM0 > 0 && !PairL3) { // (paired: launched together with the tracer kernel below)
                   if (Overlap) {
                      B1.List = M.BandCells;
                      launchTile(B1, M.NBandCells, K, S);
@@ -1742,7 +1755,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             LaunchFinalInterior = [&, Overlap]() {
                (void)Overlap;
                if constexpr (Fast) {
-                  if (Overlap && M.NRingCellsM0 > 0 && M.NInteriorCells > 0) {
+                  if (Overlap && M.NRingCellsM0 > 0 && M.NInteriorCells > 0 && !PairL3) {
                      CellPVFinalBody<TME, TME, true> B1{M,
                                                         K,
                                                         P,
@@ -1768,7 +1781,10 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             else
                LaunchFinal(std::false_type{});
             Finished            = true;
-            FusedKernelNames[5] = "CellPVFinalBody";
+            // (paired: the main sweep runs in slot 6 together with the tracer kernel; only the list launches of the
+            // rarer valences remain here)
+            FusedKernelNames[5] = !PairL3 ? "CellPVFinalBody"
+                                          : ((M.NRingCellsM1 > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVFinalBody (rarer valences)" : "");
          } else {
             CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
             if (M.NRingCellsM0 > 0)
@@ -1855,9 +1871,46 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (!Marked5)
       Mark(5);
    Mark(6);
-   FusedKernelNames[6] = NT > 0 ? "FusedCell3Body" : "";
+   FusedKernelNames[6] = PairL3 ? "CellPVFinalBody+FusedCell3Body" : (NT > 0 ? "FusedCell3Body" : "");
    bool AfterBandCalled = false;
-   if (NT > 0) {
+   if (PairL3) {
+      if constexpr (Fast) {
+         auto Go = [&](auto Epi) {
+            constexpr bool EP = decltype(Epi)::value;
+            CellPVFinalBody<TME, TME, EP> B1{M,
+                                             K,
+                                             P,
+                                             H,
+                                             U,
+                                             A.RelVortVertex,
+                                             A.InvThickVertex,
+                                             EdgeScratch,
+                                             A.RelVortVertex,
+                                             A.KineticEnergyCell,
+                                             A.VelocityDivCell,
+                                             A.Del2DivCell,
+                                             A.Del2RelVortVertex,
+                                             UTend,
+                                             nullptr,
+                                             EU};
+            FusedCell3Body<TME, true, EP> B3{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            if (EP && Stage && Stage->AfterBand && M.NBandCells > 0) {
+               B1.List = B3.List = M.BandCells;
+               launchTile2(B1, M.NBandCells, B3, M.NBandCells, K, S);
+               Stage->AfterBand(Stage->AfterBandCtx); // u, h and the tracers of every sent element are final
+               AfterBandCalled = true;
+               B1.List = B3.List = M.InteriorCells;
+               launchTile2(B1, M.NInteriorCells, B3, M.NInteriorCells, K, S);
+            } else {
+               launchTile2(B1, M.NCellsAll, B3, M.NCellsAll, K, S);
+            }
+         };
+         if (Stage)
+            Go(std::true_type{});
+         else
+            Go(std::false_type{});
+      }
+   } else if (NT > 0) {
       bool Done = false;
       if constexpr (Fast) {
          if (Stage) {

@@ -200,6 +200,39 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
          }
 }
 
+/// Two INDEPENDENT sweeps in one launch: the first NTilesA workgroups run body A over its tiles, the others body B.
+/// Saves a launch (what small sweeps are made of) and lets the tail of one sweep overlap the ramp of the other.
+/// Each half keeps its own XCD mapping.  Register budget and LDS are the larger of the two bodies'.
+template <class BA, class BB, class T>
+__global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<BB>::V ? BodyMinWaves<BA>::V
+                                                                                       : BodyMinWaves<BB>::V))
+    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA) {
+   extern __shared__ __align__(16) unsigned char Lds[];
+   const int Tid  = threadIdx.y * blockDim.x + threadIdx.x;
+   const int NThr = blockDim.x * blockDim.y;
+   if ((int)blockIdx.x < NTilesA) {
+      const int First = xcdRemap(blockIdx.x, NTilesA) * Tile;
+      const int Cnt   = NA - First < Tile ? NA - First : Tile;
+      typename BA::Lds L = A.carve(Lds, Tile);
+      if (Cnt > 0)
+         A.stage(L, First, Cnt, Tid, NThr);
+      __syncthreads();
+      for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+            A.template compute<T>(L, Le, First + Le, Kv);
+   } else {
+      const int First = xcdRemap(blockIdx.x - NTilesA, gridDim.x - NTilesA) * Tile;
+      const int Cnt   = NB - First < Tile ? NB - First : Tile;
+      typename BB::Lds L = Bb.carve(Lds, Tile);
+      if (Cnt > 0)
+         Bb.stage(L, First, Cnt, Tid, NThr);
+      __syncthreads();
+      for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+            Bb.template compute<T>(L, Le, First + Le, Kv);
+   }
+}
+
 template <class B, class = void> struct BodyHasKLog {
    static constexpr bool V = false;
 };
@@ -227,6 +260,39 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
       }
    }
    hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+   HIP_CHECK(hipGetLastError());
+}
+
+/// launchTile for two independent sweeps of the same level count (see tileKernel2); either may be empty
+template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B0, int NB, int K, hipStream_t S) {
+   static_assert(BodyMaxW<BA>::V == BodyMaxW<BB>::V, "launchTile2: bodies must agree on the levels per thread");
+   if (NA <= 0) {
+      launchTile(B0, NB, K, S);
+      return;
+   }
+   if (NB <= 0) {
+      launchTile(A0, NA, K, S);
+      return;
+   }
+   BA A  = A0;
+   BB Bb = B0;
+   A.K = Bb.K = levelPitch(K);
+   if constexpr (BodyHasKLog<BA>::V)
+      A.KLog = K;
+   if constexpr (BodyHasKLog<BB>::V)
+      Bb.KLog = K;
+   Geom G = makeGeom(NA + NB, K, BodyMaxW<BA>::V, A.K);
+   const int NTA = (NA + G.Tile - 1) / G.Tile, NTB = (NB + G.Tile - 1) / G.Tile;
+   const size_t LA = A.ldsBytes(G.Tile), LB = Bb.ldsBytes(G.Tile), Lds = LA > LB ? LA : LB;
+   const dim3 Grid(NTA + NTB, G.Grid.y, 1);
+   if constexpr (BodyMaxW<BA>::V >= 2) {
+      if (G.W == 2) {
+         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA);
+         HIP_CHECK(hipGetLastError());
+         return;
+      }
+   }
+   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA);
    HIP_CHECK(hipGetLastError());
 }
 

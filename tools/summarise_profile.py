@@ -27,22 +27,34 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def short(name):
-    """void OMEGA::tileKernel<OMEGA::FusedCell3Body<6, true, false>, ...>(...) -> FusedCell3Body<6, true, false>"""
-    if "tileKernel<" in name:
-        s = name[name.index("tileKernel<") + len("tileKernel<"):]
-        depth, out = 0, ""
-        for ch in s:
-            if ch == "<":
-                depth += 1
-            elif ch == ">":
-                if depth == 0:
-                    break
-                depth -= 1
-            elif ch == "," and depth == 0:
+def _template_args(s):
+    """top-level template arguments of the text after an opening '<'"""
+    depth, cur, out = 0, "", []
+    for ch in s:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            if depth == 0:
                 break
-            out += ch
-        return out.replace("OMEGA::", "").strip()
+            depth -= 1
+        elif ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+            continue
+        cur += ch
+    out.append(cur.strip())
+    return out
+
+
+def short(name):
+    """void OMEGA::tileKernel<OMEGA::FusedCell3Body<6, true, false>, ...>(...) -> FusedCell3Body<6, true, false>;
+    tileKernel2<A, B, T> (two independent sweeps in one launch) -> A+B"""
+    if "tileKernel2<" in name:
+        a = _template_args(name[name.index("tileKernel2<") + len("tileKernel2<"):])
+        return "+".join(x.replace("OMEGA::", "") for x in a[:2])
+    if "tileKernel<" in name:
+        a = _template_args(name[name.index("tileKernel<") + len("tileKernel<"):])
+        return a[0].replace("OMEGA::", "")
     return name.split("(")[0].replace("OMEGA::", "").replace("void ", "").strip()
 
 
