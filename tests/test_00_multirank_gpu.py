@@ -28,6 +28,8 @@ pytestmark = pytest.mark.gpu
     ["--no-del4", "--nx", 64, "--ny", 16, "--levels", 4, "--tracers", 0],   # no tracer kernel: exchange starts after the u band
     ["--no-del4", "--mesh", "ico3", "--levels", 4],                          # sphere, pentagon ring launches, 2 ranks
     ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 6, "--local-order", "curve"],   # Morton-ordered local numbering
+    ["--halo-width", 4, "--mesh", "ico4", "--levels", 6, "--partition", "graph", "--local-order", "curve"],  # sphere: pentagon
+                                                                  # lists next to the paired launches, del4 on, overlapped
     ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 20],     # 20 levels: device rows padded to 32 (pack / unpack with a pitch)
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream"],               # non-blocking user stream,
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream", "--no-overlap"],  # overlapped and sequential

@@ -60,6 +60,7 @@ def run_ranks(mode, world, extra=(), timeout=600):
     (2, ["--halo-width", 5, "--mesh", "fib700", "--levels", 3, "--steps", 1]),  # pentagons + heptagons, del4 on
     (3, ["--halo-width", 4, "--nx", 24, "--ny", 24, "--local-order", "curve"]),  # local numbering along a Morton curve
     (3, ["--no-del4", "--mesh", "ico3", "--levels", 3, "--partition", "graph"]),   # built-in graph partitioner
+    (3, ["--halo-width", 4, "--mesh", "ico4", "--levels", 3, "--partition", "graph", "--local-order", "curve"]),
 ])
 def test_partitioned_oracle_matches_single_rank(world, extra):
     outs = run_ranks("cpu", world, extra)
