@@ -3,58 +3,14 @@
 // ownership + ordering :1476-1610, vertex ditto :1740-1880, XxOnCell compaction
 // :2030-2064, EdgesOnEdge :2187-2199, global->local translation :553-712.
 #include "Decomp.h"
+#include "Partition.h"
 
 #include <algorithm>
 #include <numeric>
 
 namespace OMEGA {
 
-namespace {
-
-// Recursive coordinate bisection: split `Idx[Lo,Hi)` into NP parts, part ids
-// starting at Part0.  Deterministic (ties broken by global id).
-void rcbSplit(const GlobalMeshDesc &G, std::vector<I4> &Idx, size_t Lo, size_t Hi, I4 Part0,
-              I4 NP, std::vector<I4> &Task) {
-   if (NP == 1) {
-      for (size_t I = Lo; I < Hi; ++I)
-         Task[Idx[I]] = Part0;
-      return;
-   }
-   const R8 *C[3] = {G.XCell, G.YCell, G.ZCell};
-   int Axis = 0;
-   R8 Best  = -1;
-   for (int A = 0; A < 3; ++A) {
-      if (!C[A])
-         continue;
-      R8 Mn = 1e300, Mx = -1e300;
-      for (size_t I = Lo; I < Hi; ++I) {
-         R8 V = C[A][Idx[I]];
-         Mn   = std::min(Mn, V);
-         Mx   = std::max(Mx, V);
-      }
-      if (Mx - Mn > Best) {
-         Best = Mx - Mn;
-         Axis = A;
-      }
-   }
-   const I4 NPLeft = NP / 2;
-   const size_t N  = Hi - Lo;
-   const size_t NLeft = (size_t)((double)N * NPLeft / NP + 0.5);
-   const R8 *X = C[Axis];
-   auto Cmp    = [X](I4 A, I4 B) { return X[A] < X[B] || (X[A] == X[B] && A < B); };
-   std::nth_element(Idx.begin() + Lo, Idx.begin() + Lo + NLeft, Idx.begin() + Hi, Cmp);
-   rcbSplit(G, Idx, Lo, Lo + NLeft, Part0, NPLeft, Task);
-   rcbSplit(G, Idx, Lo + NLeft, Hi, Part0 + NPLeft, NP - NPLeft, Task);
-}
-
-} // namespace
-
-void Decomp::partitionRCB() {
-   OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: RCB partitioner needs cell coordinates");
-   std::vector<I4> Idx(NCellsGlobal);
-   std::iota(Idx.begin(), Idx.end(), 0);
-   rcbSplit(G, Idx, 0, Idx.size(), 0, NumTasks, CellTask);
-}
+void Decomp::partitionRCB() { OMEGA::partitionRCB(G, NumTasks, CellTask); }
 
 // The sequence that numbers cells inside every group: global id, or a Morton curve through the cell centres
 // (21 bits per coordinate, interleaved; planar meshes have a constant z and reduce to the 2-D curve).

@@ -222,6 +222,56 @@ void recurse(const Graph &Gr, std::vector<I4> &Part, I4 Tag, I4 NP, I4 &NextTag,
 
 } // namespace
 
+namespace {
+// Recursive coordinate bisection: split `Idx[Lo,Hi)` into NP parts, part ids
+// starting at Part0.  Deterministic (ties broken by global id).
+void rcbSplit(const GlobalMeshDesc &G, std::vector<I4> &Idx, size_t Lo, size_t Hi, I4 Part0,
+              I4 NP, std::vector<I4> &Task) {
+   if (NP == 1) {
+      for (size_t I = Lo; I < Hi; ++I)
+         Task[Idx[I]] = Part0;
+      return;
+   }
+   const R8 *C[3] = {G.XCell, G.YCell, G.ZCell};
+   int Axis = 0;
+   R8 Best  = -1;
+   for (int A = 0; A < 3; ++A) {
+      if (!C[A])
+         continue;
+      R8 Mn = 1e300, Mx = -1e300;
+      for (size_t I = Lo; I < Hi; ++I) {
+         R8 V = C[A][Idx[I]];
+         Mn   = std::min(Mn, V);
+         Mx   = std::max(Mx, V);
+      }
+      if (Mx - Mn > Best) {
+         Best = Mx - Mn;
+         Axis = A;
+      }
+   }
+   const I4 NPLeft = NP / 2;
+   const size_t N  = Hi - Lo;
+   const size_t NLeft = (size_t)((double)N * NPLeft / NP + 0.5);
+   const R8 *X = C[Axis];
+   auto Cmp    = [X](I4 A, I4 B) { return X[A] < X[B] || (X[A] == X[B] && A < B); };
+   std::nth_element(Idx.begin() + Lo, Idx.begin() + Lo + NLeft, Idx.begin() + Hi, Cmp);
+   rcbSplit(G, Idx, Lo, Lo + NLeft, Part0, NPLeft, Task);
+   rcbSplit(G, Idx, Lo + NLeft, Hi, Part0 + NPLeft, NP - NPLeft, Task);
+}
+
+} // namespace
+
+
+void partitionRCB(const GlobalMeshDesc &G, I4 NParts, std::vector<I4> &CellTask) {
+   OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: RCB partitioner needs cell coordinates");
+   CellTask.assign(G.NCells, 0);
+   if (NParts <= 1)
+      return;
+   std::vector<I4> Idx(G.NCells);
+   std::iota(Idx.begin(), Idx.end(), 0);
+   rcbSplit(G, Idx, 0, Idx.size(), 0, NParts, CellTask);
+}
+
 I8 edgeCut(const GlobalMeshDesc &G, const std::vector<I4> &T) {
    I8 Cut = 0;
    for (I4 C = 0; C < G.NCells; ++C)

@@ -16,6 +16,8 @@
 
 namespace OMEGA {
 
+/// recursive coordinate bisection of the cell centres (ties broken by global id)
+void partitionRCB(const GlobalMeshDesc &G, I4 NParts, std::vector<I4> &CellTask);
 /// CellTask[c] in [0, NParts) for every global cell.  Deterministic.
 void partitionGraph(const GlobalMeshDesc &G, I4 NParts, std::vector<I4> &CellTask);
 /// number of cell-graph edges whose two cells lie in different parts

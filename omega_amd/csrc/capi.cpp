@@ -367,8 +367,7 @@ int omg_partition_cells(const omg_global_mesh *mesh, int nparts, const char *met
    if (M == "graph") {
       partitionGraph(G, nparts, T);
    } else if (M == "rcb") {
-      Decomp D(G, nparts, 0, 1, nullptr);
-      T = D.CellTask;
+      partitionRCB(G, nparts, T);
    } else {
       OMEGA_ABORT("omg_partition_cells: method must be \"rcb\" or \"graph\"");
    }
