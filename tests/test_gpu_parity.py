@@ -455,3 +455,41 @@ def test_curve_ordered_local_numbering(mesh):
     h, u = P.state.copy_to_host(0)
     check("h", h, ost["h"][0], m.NCellsOwned)
     check("u", u, ost["u"][0], m.NEdgesOwned)
+
+
+@pytest.mark.parametrize("name,K,NT,rk4", [("ico5", 60, 2, True), ("hex484", 60, 2, True), ("hex680", 80, 6, False)],
+                         ids=["configs1_QU240_sphere", "configs2_EC30to60_size", "configs3_QU30_size"])
+def test_baseline_configurations_at_full_size_against_the_oracle(name, K, NT, rk4):
+    """BASELINE.json configs[1..3] at their FULL sizes, element by element against the oracle (the property tests of
+    tests/test_gpu_properties.py are what remains size-independent; this is the direct comparison): a spherical
+    quasi-uniform mesh of 10 242 cells x 60 levels (QU240 itself is a download), 234 256 cells x 60
+    levels x 2 tracers, 462 400 cells x 80 levels x 6 tracers -- row-major input numbered by Decomp along the curve, as
+    bench.py runs them.  Fused RHS everywhere, one RK4 step where the oracle's step stays within seconds."""
+    import gc
+    if name == "ico5":
+        g = sphere(name)
+    else:
+        n = int(name[3:])
+        g = planar_hex(n, n, 30.0e3 if n == 680 else 45.0e3)
+    P = Problem(g, K, NT, local_order="curve")
+    m = P.mesh
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+    check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+    check("trTend", P.tend.get(2), trT, m.NCellsOwned)
+    if rk4:
+        dt = 600.0
+        st = oa.TimeStepper("RungeKutta4", dt, P.tend, P.aux, P.mesh, None, P.tracers)
+        ost = P.oracle.make_state(P.h, P.u, P.tr)
+        st.do_step(P.state)
+        oa.device_synchronize()
+        P.oracle.step("rk4", ost, dt)
+        h, u = P.state.copy_to_host(0)
+        assert np.isfinite(ost["h"][0]).all()
+        check("h", h, ost["h"][0], m.NCellsOwned)
+        check("u", u, ost["u"][0], m.NEdgesOwned)
+        check("tr", P.tracers.copy_to_host(0), ost["tr"][0], m.NCellsOwned)
+    del P
+    gc.collect()
