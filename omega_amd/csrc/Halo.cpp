@@ -74,7 +74,10 @@ Halo::Halo(const std::string &, const Decomp *D) {
    RecvPtrs.assign(NNghbr, nullptr);
 }
 
-Halo::~Halo() {}
+Halo::~Halo() {
+   if (EvLast)
+      (void)hipEventDestroy(EvLast);
+}
 
 void Halo::useRccl(RcclComm *Comm) {
    OMEGA_REQUIRE(Comm != nullptr, "Halo::useRccl: no communicator");
@@ -160,6 +163,10 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
       SendPtrs[N] = static_cast<char *>(SendBuf->Ptr) + Pl.SendOff[N];
       RecvPtrs[N] = static_cast<char *>(RecvBuf->Ptr) + Pl.RecvOff[N];
    }
+   if (!EvLast)
+      HIP_CHECK(hipEventCreateWithFlags(&EvLast, hipEventDisableTiming));
+   if (HaveLast)
+      HIP_CHECK(hipStreamWaitEvent(S, EvLast, 0)); // the shared buffers are free once the previous exchange is done
    // pack: one launch for every neighbour and array (Halo.h:324-414)
    launchHaloPackAll(static_cast<Real *>(SendBuf->Ptr), B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, Pl.Pitch, S);
    const int Err = Transport(TransportCtx, NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
@@ -168,6 +175,8 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
       return -1;
    // unpack: one launch (Halo.h:566-653)
    launchHaloUnpackAll(B, static_cast<const Real *>(RecvBuf->Ptr), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, S);
+   HIP_CHECK(hipEventRecord(EvLast, S));
+   HaveLast = true;
    return 0;
 }
 I4 Halo::exchangeFullArrayHalo(const Array2DReal &A, MeshElement E, hipStream_t S) {

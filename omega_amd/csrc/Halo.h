@@ -86,6 +86,10 @@ class Halo : public Registry<Halo> {
    void *TransportCtx        = nullptr;
    std::map<std::vector<int>, Plan> Plans; ///< keyed by (Elem, NT, RowsSize, K) of every piece
    std::shared_ptr<DeviceBuffer> SendBuf, RecvBuf;
+   /// end of the previous exchange: the message buffers are shared by all exchanges of this Halo, so an exchange
+   /// issued on another stream first waits for the previous one (a no-op on the same stream)
+   hipEvent_t EvLast = nullptr;
+   bool HaveLast     = false;
    std::vector<void *> SendPtrs, RecvPtrs;
 };
 

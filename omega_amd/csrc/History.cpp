@@ -139,6 +139,8 @@ int writeHistory(const std::string &Path, const Decomp *D, const OceanState *Sta
    OMEGA_REQUIRE(D && State && Aux, "writeHistory: missing object");
    const std::vector<HistoryField> F = expandHistoryContents(Csv);
    const int K = State->NVertLayers, NT = Trc ? Trc->NTracers : 0;
+   OMEGA_REQUIRE(Aux->NTracers == NT && Aux->NVertLayers == K,
+                 "writeHistory: the auxiliary state was created for another tracer / level count");
    const I8 NG[3] = {D->NCellsGlobal, D->NEdgesGlobal, D->NVerticesGlobal};
    // layout (every rank derives the same one)
    std::vector<I8> Begins(F.size() + 1, 0), Bytes;
