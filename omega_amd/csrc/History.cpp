@@ -5,6 +5,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sstream>
+#include <sys/mman.h>
 #include <unistd.h>
 
 namespace OMEGA {
@@ -181,6 +182,13 @@ int writeHistory(const std::string &Path, const Decomp *D, const OceanState *Sta
    const int Fd = open(Path.c_str(), O_RDWR);
    if (Fd < 0)
       OMEGA_ABORT("History: cannot open " + Path);
+   // rows land at scattered global positions (millions of 8*K-byte pieces for a QU30-sized dump): write them through
+   // a shared mapping of the file instead of one pwrite each
+   unsigned char *Map = static_cast<unsigned char *>(mmap(nullptr, (size_t)Off, PROT_READ | PROT_WRITE, MAP_SHARED, Fd, 0));
+   if (Map == MAP_FAILED) {
+      close(Fd);
+      OMEGA_ABORT("History: cannot map " + Path);
+   }
    const I4 NOwned[3]        = {D->NCellsOwned, D->NEdgesOwned, D->NVerticesOwned};
    const HostArrayI4 *IDs[3] = {&D->CellIDH, &D->EdgeIDH, &D->VertexIDH};
    int NWritten              = 0;
@@ -220,28 +228,30 @@ int writeHistory(const std::string &Path, const Decomp *D, const OceanState *Sta
          const int E  = (int)Fd_.Elem;
          const I4 No  = NOwned[E];
          std::vector<R8> Host((size_t)No * RowLen);
-         std::vector<unsigned char> Buf((size_t)RowLen * 8);
          for (int P = 0; P < Planes; ++P) {
             copyRowsToHost(Host.data(), Ptr + (size_t)P * RowsSize * Pitch, Pitch, (size_t)No, RowLen);
             for (I4 R = 0; R < No; ++R) {
-               for (int L = 0; L < RowLen; ++L) {
+               const I8 Pos = Begins[I + 1] + (((I8)P * NG[E]) + ((*IDs[E])(R) - 1)) * RowLen * 8;
+               unsigned char *Dst = Map + Pos;
+               for (int L = 0; L < RowLen; ++L) { // big-endian doubles
                   unsigned char T[8];
                   std::memcpy(T, &Host[(size_t)R * RowLen + L], 8);
                   for (int J = 0; J < 8; ++J)
-                     Buf[(size_t)L * 8 + J] = T[7 - J];
+                     Dst[(size_t)L * 8 + J] = T[7 - J];
                }
-               const I8 Pos = Begins[I + 1] + (((I8)P * NG[E]) + ((*IDs[E])(R) - 1)) * RowLen * 8;
-               if (pwrite(Fd, Buf.data(), Buf.size(), (off_t)Pos) != (ssize_t)Buf.size())
-                  OMEGA_ABORT("History: short write to " + Path);
             }
          }
          ++NWritten;
       }
    } catch (...) {
+      munmap(Map, (size_t)Off);
       close(Fd);
       throw;
    }
+   const bool Synced = msync(Map, (size_t)Off, MS_SYNC) == 0;
+   munmap(Map, (size_t)Off);
    close(Fd);
+   OMEGA_REQUIRE(Synced, "History: error flushing " + Path);
    return NWritten;
 }
 
