@@ -80,6 +80,18 @@ def test_five_ranks_graph_partition_curve_order_one_gpu():
     assert all("OK" in o for o in outs)
 
 
+def test_unmerged_unpaired_kernel_structure_in_a_child_process():
+    """OMEGA_MERGE_L1=0 OMEGA_PAIR=0: the seven separate kernels of round 1 (what meshes without the cell-side vertex
+    tables fall back to) must still equal the oracle."""
+    env = dict(os.environ, OMEGA_MERGE_L1="0", OMEGA_PAIR="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
+                        "(compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500)) or time_steppers or rk4_on_the_sphere"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert " passed" in out and "failed" not in out
+
+
 def test_four_ranks_one_gpu():
     """Four ranks (2 x 2 blocks of a 48 x 48 mesh: every rank has several neighbours, corner halos travel
     through two of them) on one GPU, overlapped exchanges."""
