@@ -43,6 +43,8 @@ WORKLOADS = {
     "orrs18to6_eighth": (680, 680, 6.0e3, 80, 37,
                          "one eighth of an oRRS18to6-sized mesh (680x680 = 462400 of 3.7M cells), 80L, 37 tracers"),
     "ico7": (0, 7, 0.0, 80, 6, "spherical icosahedral Voronoi mesh, 163842 cells (12 pentagons), 80L, 6 tracers"),
+    "ico8": (0, 8, 0.0, 80, 6, "spherical icosahedral Voronoi mesh, 655362 cells (12 pentagons), 80L, 6 tracers "
+                               "(QU30-sized on the sphere; the mesh generator needs a few minutes)"),
     "ico6": (0, 6, 0.0, 60, 2, "spherical icosahedral Voronoi mesh, 40962 cells (12 pentagons), 60L, 2 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
 }
