@@ -67,6 +67,8 @@ def algorithmic_bytes_per_cell_level(nt, kernel=None):
     # independent sweeps sharing one launch (KernelCommon.h: tileKernel2)
     per_kernel["Del2CellRingBody+Del2VertexSelBody"] = per_kernel["Del2CellRingBody"] + per_kernel["Del2VertexSelBody"]
     per_kernel["CellPVFinalBody+FusedCell3Body"] = per_kernel["CellPVFinalBody"] + per_kernel["FusedCell3Body"]
+    # both in one thread: h and u gathered once
+    per_kernel["CellPVFinalTracerBody"] = per_kernel["CellPVFinalBody"] + per_kernel["FusedCell3Body"] - 8 * (1 + 3)
     per_kernel["CellPVFinalBody (rarer valences)"] = per_kernel["CellPVFinalBody"]
     per_kernel["CellPVBody<side 0>+FusedCell3Body"] = 8 * (nt + nt + 1 + 3 + nt + 2 * 2 + 3)
     per_kernel["FusedDel2CellBody"] = per_kernel["Del2CellRingBody"]

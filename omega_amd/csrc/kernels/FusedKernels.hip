@@ -1295,6 +1295,207 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
    }
 };
 
+// CellPVFinalBody<TME, TME> and the default-term FusedCell3Body in one thread: the L3 work of a cell with one gather
+// of h and u (32 B per cell-level less than the paired launch of the two kernels; same expressions, so same bits).
+// Plain RHS only: with the stage updates in the epilogues the paired launch is the faster one.
+template <int TME> struct CellPVFinalTracerBody {
+   static constexpr int MinWaves = OMEGA_PVF_MINW;
+   static constexpr int TM1      = TME - 1;
+   MeshView M;
+   int K, NT;
+   TendParams P;
+   const Real *H, *U, *RelVortV, *InvThickV, *Partial;
+   const Real *RelVort, *KE, *Div, *Del2Div, *Del2RelVort;
+   Real *Tend;
+   const Real *Tr, *Del2Tr;
+   Real *TrTend;
+   const int *List = nullptr;
+   struct Lds {
+      Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs, *FV, *MDvS, *Df2, *Df4, *InvA;
+      int *Edge, *NbrF, *Ring, *Role, *N;
+   };
+   size_t ldsBytes(int Tile) const {
+      return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) * 9 +
+             ldsRound8(sizeof(Real) * Tile) * 2 + ldsRound8(sizeof(int) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile);
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      LdsCarver C{Ptr};
+      Lds L;
+      L.Wt     = C.take<Real>(Tile * TME * TM1);
+      L.InvDc  = C.take<Real>(Tile * TME);
+      L.InvDvS = C.take<Real>(Tile * TME);
+      L.C2     = C.take<Real>(Tile * TME);
+      L.C4     = C.take<Real>(Tile * TME);
+      L.BDn    = C.take<Real>(Tile * TME);
+      L.FV     = C.take<Real>(Tile * TME);
+      L.MDvS   = C.take<Real>(Tile * TME);
+      L.Df2    = C.take<Real>(Tile * TME);
+      L.Df4    = C.take<Real>(Tile * TME);
+      L.BDs    = C.take<Real>(Tile);
+      L.InvA   = C.take<Real>(Tile);
+      L.Edge   = C.take<int>(Tile * TME);
+      L.NbrF   = C.take<int>(Tile * TME);
+      L.Ring   = C.take<int>(Tile * TME);
+      L.Role   = C.take<int>(Tile * TME);
+      L.N      = C.take<int>(Tile);
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
+         const int Le = I / (TME * TM1);
+         const int C  = List ? List[First + Le] : First + Le;
+         L.Wt[I]      = M.PVWeightOnCell[(size_t)C * TME * TM1 + (I - Le * TME * TM1)];
+      }
+      for (int I = Tid; I < Cnt * TME; I += NThr) {
+         const int Le    = I / TME;
+         const int C     = List ? List[First + Le] : First + Le;
+         const size_t G  = (size_t)C * TME + (I - Le * TME);
+         const int Ed    = M.EdgesOnCell[G];
+         const int F     = M.NbrFlagOnCell[G];
+         const Real Mask = M.EdgeMask1D[Ed];
+         L.Edge[I]       = Ed;
+         L.NbrF[I]       = F;
+         L.Ring[I]       = M.RingVertOnCell[G];
+         L.FV[I]         = M.FVertex[M.RingVertOnCell[G]];
+         L.Role[I]       = M.PVRoleOnCell[G];
+         L.InvDc[I]      = M.InvDcEdge[Ed];
+         L.InvDvS[I]     = M.RingSignOnCell[G] * M.InvDvEdge[Ed];
+         L.C2[I]         = Mask * P.ViscDel2 * M.MeshScalingDel2[Ed];
+         L.C4[I]         = Mask * P.ViscDel4 * M.MeshScalingDel4[Ed];
+         L.BDn[I]        = M.BottomDepth[F & 0x3fffffff];
+         L.MDvS[I]       = M.MaskDvSignOnCell[G];
+         L.Df2[I]        = M.Diff2CoefSOnCell[G];
+         L.Df4[I]        = M.Diff4CoefSOnCell[G];
+      }
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int C = List ? List[First + I] : First + I;
+         L.BDs[I]    = M.BottomDepth[C];
+         L.N[I]      = M.NEdgesOnCell[C];
+         L.InvA[I]   = M.InvAreaCell[C];
+      }
+   }
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      const int ICell = List ? List[IElem] : IElem;
+      const Real Grav = 9.80665; // TendencyTerms.h:176
+      unsigned OffE[TME], OffN[TME];
+      T Uj[TME], Hn[TME];
+      const unsigned OffS = rowOff<T>(ICell, K, Kv);
+      const T Hs          = ldo<T>(H, OffS);
+#pragma unroll
+      for (int J = 0; J < TME; ++J) {
+         OffE[J] = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
+         OffN[J] = rowOff<T>(L.NbrF[Le * TME + J] & 0x3fffffff, K, Kv);
+         Uj[J]   = ldo<T>(U, OffE[J]);
+         Hn[J]   = ldo<T>(H, OffN[J]);
+      }
+      bool Any = L.N[Le] == TME;
+      if (Any) {
+         Any = false;
+#pragma unroll
+         for (int J = 0; J < TME; ++J)
+            Any |= L.Role[Le * TME + J] == 2;
+      }
+      if (Any) { // ---- CellPVFinalBody<TME, TME> ----
+         constexpr int N = TME;
+         unsigned OffV[N];
+         T Flux[N], QRe[N], QFe[N];
+         {
+            T QR[N], QF[N];
+#pragma unroll
+            for (int J = 0; J < N; ++J) {
+               OffV[J]    = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
+               const T Iv = ldo<T>(InvThickV, OffV[J]);
+               QR[J]      = ldo<T>(RelVortV, OffV[J]) * Iv;
+               QF[J]      = L.FV[Le * TME + J] * Iv;
+            }
+#pragma unroll
+            for (int J = 0; J < N; ++J) {
+               Flux[J]      = 0.5 * (Hs + Hn[J]);
+               const int Jm = (J + N - 1) % N;
+               QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
+               QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
+            }
+         }
+         T Acc[N];
+#pragma unroll
+         for (int I = 0; I < N; ++I) {
+            Acc[I] = splat<T>(0.0);
+            if (L.Role[Le * TME + I] != 2)
+               continue;
+            Acc[I] = ldo<T>(Partial, OffE[I]);
+#pragma unroll
+            for (int J = 1; J < N; ++J) {
+               const int Kk     = (I + J) % N;
+               const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
+               Acc[I] += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
+            }
+         }
+         T Rv[N], R2[N];
+#pragma unroll
+         for (int J = 0; J < N; ++J) {
+            Rv[J] = ldo<T>(RelVort, OffV[J]);
+            R2[J] = ldo<T>(Del2RelVort, OffV[J]);
+         }
+         const T KEs = ldo<T>(KE, OffS), DivS = ldo<T>(Div, OffS), D2S = ldo<T>(Del2Div, OffS);
+         const T Ssh1 = Hs - L.BDs[Le];
+#pragma unroll
+         for (int I = 0; I < N; ++I) {
+            const int Li = Le * TME + I;
+            if (L.Role[Li] != 2)
+               continue;
+            const int Im     = (I + N - 1) % N;
+            const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
+            T TendV          = splat<T>(0.0);
+            TendV += Acc[I];
+            TendV -= (KEs - ldo<T>(KE, OffN[I])) * InvDc;
+            const T Ssh0 = Hn[I] - L.BDn[Li];
+            TendV -= Grav * (Ssh1 - Ssh0) * InvDc;
+            {
+               const T Del2U = ((DivS - ldo<T>(Div, OffN[I])) * InvDc - (Rv[I] - Rv[Im]) * InvDvS);
+               TendV += L.C2[Li] * Del2U;
+            }
+            {
+               const T Del2U = (P.DivFactor * (D2S - ldo<T>(Del2Div, OffN[I])) * InvDc - (R2[I] - R2[Im]) * InvDvS);
+               TendV -= L.C4[Li] * Del2U;
+            }
+            stnt<T>(Tend, OffE[I], TendV);
+         }
+      }
+      // ---- FusedCell3Body<TME, true> ----
+      const Real InvA      = L.InvA[Le];
+      const size_t CStride = (size_t)M.NCellsSize * K;
+#pragma nounroll
+      for (int Lt = 0; Lt < NT; ++Lt) {
+         const Real *TrL = uniformPtr(Tr + Lt * CStride);
+         const Real *D2L = uniformPtr(Del2Tr + Lt * CStride);
+         T Tn[TME], Dn[TME];
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            Tn[J] = ldo<T>(TrL, OffN[J]);
+            Dn[J] = ldo<T>(D2L, OffN[J]);
+         }
+         const T Ts = ldo<T>(TrL, OffS);
+         const T Ds = ldo<T>(D2L, OffS);
+         T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
+         const T HsTs = Hs * Ts;
+#pragma unroll
+         for (int J = 0; J < TME; ++J) {
+            const int I  = Le * TME + J;
+            const T HTr  = 0.5 * (HsTs + Hn[J] * Tn[J]);
+            HAdvTmp -= L.MDvS[I] * HTr * Uj[J] * InvA;
+            const T Mean = 0.5 * (Hs + Hn[J]);
+            DiffTmp -= L.Df2[I] * Mean * (Tn[J] - Ts);
+            HypTmp -= L.Df4[I] * (Dn[J] - Ds);
+         }
+         T TendV = splat<T>(0.0);
+         TendV -= HAdvTmp;
+         TendV += P.EddyDiff2 * DiffTmp * InvA;
+         TendV -= P.EddyDiff4 * HypTmp * InvA;
+         stnt<T>(uniformPtr(TrTend + Lt * CStride), OffS, TendV);
+      }
+   }
+};
+
 // L3 edge pass after the cell-centric PV sums: the remaining velocity terms for regular edges,
 // with the finished PV sum read from `Partial`.
 template <bool Fast> struct EdgeFinalBody {
@@ -1871,7 +2072,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (!Marked5)
       Mark(5);
    Mark(6);
-   FusedKernelNames[6] = PairL3 ? "CellPVFinalBody+FusedCell3Body" : (NT > 0 ? "FusedCell3Body" : "");
+   // OMEGA_FUSE_L3=0: the plain RHS keeps the paired launch too (A/B measurements)
+   static const int FuseL3Env = getenv("OMEGA_FUSE_L3") ? atoi(getenv("OMEGA_FUSE_L3")) : 1;
+   const bool FuseL3          = PairL3 && FuseL3Env && !Stage;
+   FusedKernelNames[6]        = FuseL3   ? "CellPVFinalTracerBody"
+                                : PairL3 ? "CellPVFinalBody+FusedCell3Body"
+                                         : (NT > 0 ? "FusedCell3Body" : "");
    bool AfterBandCalled = false;
    if (PairL3) {
       if constexpr (Fast) {
@@ -1894,6 +2100,15 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                              nullptr,
                                              EU};
             FusedCell3Body<TME, true, EP> B3{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            if constexpr (!EP) {
+               if (FuseL3) { // one thread per (cell, levels) does both: h and u gathered once
+                  CellPVFinalTracerBody<TME> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
+                                                A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
+                  launchTile(BF, M.NCellsAll, K, S);
+                  return;
+               }
+            }
             if (EP && Stage && Stage->AfterBand && M.NBandCells > 0) {
                B1.List = B3.List = M.BandCells;
                launchTile2(B1, M.NBandCells, B3, M.NBandCells, K, S);
