@@ -1,0 +1,18 @@
+#!/bin/bash
+# bench.py --workload <name> --no-cpu-baseline for every configuration size -> gpurun_out/<tag>_wl_<name>.json
+#   usage (through gpurun):  bash tools/run_workloads.sh <tag> [workload ...]
+set -e -o pipefail
+TAG=${1:?tag}; shift || true
+cd "$(dirname "$0")/.."
+WL=${*:-qu30 ec30to60 qu240 qu30_eighth ico7 orrs18to6_eighth ico8}
+mkdir -p gpurun_out
+for w in $WL; do
+   extra=""
+   [ "$w" = orrs18to6_eighth ] && extra="--rk4-steps 0"
+   timeout -k 10 900 python3 bench.py --workload $w --no-cpu-baseline $extra > gpurun_out/${TAG}_wl_$w.json 2> gpurun_out/${TAG}_wl_$w.err
+   python3 - <<PY
+import json
+d = json.loads(open("gpurun_out/${TAG}_wl_$w.json").read())
+print("[workloads] $w", round(d["ms_per_step"], 4), "ms", round(d["roofline"]["rhs"]["frac"], 4), "rk4", (d.get("rk4") or {}).get("ms_per_step"), flush=True)
+PY
+done
