@@ -52,6 +52,40 @@ namespace OMEGA {
 // argument + tracer * plane size), so the compiler emits `global_load_dwordx4 v, v_off, s[base]`
 // and a gather costs one 32-bit VGPR per neighbour, shared by every array of that index space
 // (h, each tracer, each Del2Tracers plane, ...).  launchFusedRHS checks planes are < 4 GiB.
+#ifndef OMEGA_FLAT_ADDR
+// MUBUF form: the plane's base goes into a buffer resource (4 SGPRs, built from the wave-uniform pointer; no
+// stride, no bound below 4 GiB), the element offset is the instruction's 32-bit VGPR offset -- no 64-bit address
+// arithmetic and no address register pairs per access.
+typedef unsigned BufV4 __attribute__((ext_vector_type(4)));
+typedef unsigned BufV2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bufRsrc(const Real *Base) {
+   return __builtin_amdgcn_make_buffer_rsrc(const_cast<Real *>(Base), 0, 0xffffffffu, 0x00020000);
+}
+template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned ByteOff) {
+   if constexpr (sizeof(T) == 16)
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(bufRsrc(Base), ByteOff, 0, 0));
+   else
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(bufRsrc(Base), ByteOff, 0, 0));
+}
+template <class T> __device__ __forceinline__ void stAux(Real *Base, unsigned ByteOff, T V, int) {}
+template <class T> __device__ __forceinline__ void sto(Real *Base, unsigned ByteOff, T V) {
+   if constexpr (sizeof(T) == 16)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(BufV4, V), bufRsrc(Base), ByteOff, 0, 0);
+   else
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(BufV2, V), bufRsrc(Base), ByteOff, 0, 0);
+}
+/// streaming store (nt) for outputs nobody re-reads inside the same kernel
+template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned ByteOff, T V) {
+   if constexpr (sizeof(T) == 16)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(BufV4, V), bufRsrc(Base), ByteOff, 0, 2);
+   else
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(BufV2, V), bufRsrc(Base), ByteOff, 0, 2);
+}
+/// keeps loop-invariant LDS reads inside the loop (a register each otherwise): nothing after this point may be
+/// assumed unchanged in memory
+__device__ __forceinline__ void loopFence() { __asm__ volatile("" ::: "memory"); }
+#else
+__device__ __forceinline__ void loopFence() {}
 template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned ByteOff) {
    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(Base) + ByteOff);
 }
@@ -67,6 +101,7 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
    __builtin_nontemporal_store(V, reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff));
 #endif
 }
+#endif
 /// Device-side view of one variable's Runge-Kutta stage update (Kernels.h: StageUpdate)
 struct StageEpi {
    Real CB = 0, CA = 0;
@@ -211,6 +246,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
          const size_t CStride = (size_t)M.NCellsSize * K;
 #pragma nounroll
          for (int Lt = 0; Lt < NT; ++Lt) {
+            loopFence();
             const Real *TrL = uniformPtr(Tr + Lt * CStride);
             T Tn[TME];
 #pragma unroll
@@ -424,6 +460,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
          const size_t CStride = (size_t)M.NCellsSize * K;
 #pragma nounroll
          for (int Lt = 0; Lt < NT; ++Lt) {
+            loopFence();
             const Real *TrL = uniformPtr(Tr + Lt * CStride);
             T Tn[TME];
 #pragma unroll
@@ -566,6 +603,7 @@ struct FusedDel2VertexBody {
 // L2 cell pass, ring form (HorzMesh::buildDel2Tables): same arithmetic as FusedDel2CellBody with
 // every row gathered once -- Div at the cell and its TME neighbours, RelVort on its TME ring vertices.
 template <int TME> struct Del2CellRingBody {
+   static constexpr bool HoistTables = true; // (KernelCommon.h: measured 0.588 against 0.600 ms for the pair)
    MeshView M;
    int K;
    const Real *Div, *RelVort;
@@ -622,6 +660,7 @@ template <int TME> struct Del2CellRingBody {
 
 // L2 vertex pass for VertexDegree 3, each row gathered once (7 instead of 12).
 struct Del2VertexSelBody {
+   static constexpr bool HoistTables = true;
    MeshView M;
    int K;
    const Real *Div, *RelVort;
@@ -1466,6 +1505,7 @@ template <int TME> struct CellPVFinalTracerBody {
       const size_t CStride = (size_t)M.NCellsSize * K;
 #pragma nounroll
       for (int Lt = 0; Lt < NT; ++Lt) {
+         loopFence();
          const Real *TrL = uniformPtr(Tr + Lt * CStride);
          const Real *D2L = uniformPtr(Del2Tr + Lt * CStride);
          T Tn[TME], Dn[TME];
@@ -1681,6 +1721,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
       }
 #pragma nounroll
       for (int Lt = 0; Lt < NT; ++Lt) {
+         loopFence();
          const Real *TrL = uniformPtr(Tr + Lt * CStride);
          const Real *D2L = uniformPtr(Del2Tr + Lt * CStride);
          T Tn[TME], Dn[TME];

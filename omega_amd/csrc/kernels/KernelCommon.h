@@ -15,6 +15,7 @@
 #define OMEGA_AMD_KERNELCOMMON_H
 
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 #include <hip/hip_runtime.h>
 
@@ -160,6 +161,23 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0) {
 /// The generic tile kernel: stage -> barrier -> column sweeps.
 /// Bodies may define `static constexpr int MinWaves` (2nd __launch_bounds__ argument: minimum
 /// waves per SIMD, i.e. the VGPR budget) and `static constexpr int MaxW` (levels per thread).
+/// Bodies with small tables may declare `static constexpr bool HoistTables = true`: the compiler may then keep the
+/// tile's LDS tables in registers across the level chunks.  For every other body a compiler-only fence at the top of
+/// each chunk keeps the (loop-invariant) LDS reads inside the loop -- hoisted, the tables of the big kernels would
+/// occupy more registers than the kernel has (the accessors of FusedKernels.hip use buffer instructions, whose
+/// stores provably do not alias LDS, so nothing else stops the hoisting).
+template <class B, class = void> struct BodyHoistTables {
+   static constexpr bool V = false;
+};
+template <class B> struct BodyHoistTables<B, std::enable_if_t<B::HoistTables>> {
+   static constexpr bool V = true;
+};
+template <class B> __device__ __forceinline__ void chunkFence() {
+#ifndef OMEGA_NO_CHUNK_FENCE
+   if constexpr (!BodyHoistTables<B>::V)
+      __asm__ volatile("" ::: "memory");
+#endif
+}
 template <class B, class = void> struct BodyMinWaves {
    static constexpr int V = 1;
 };
@@ -192,12 +210,10 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
    __syncthreads();
    for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
       for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
-{
-#ifdef OMEGA_KV_BARRIER
-            __asm__ volatile("" ::: "memory");
-#endif
-            B.template compute<T>(L, Le, First + Le, Kv);
-         }
+      {
+         chunkFence<Body>();
+         B.template compute<T>(L, Le, First + Le, Kv);
+      }
 }
 
 /// Two INDEPENDENT sweeps in one launch: the first NTilesA workgroups run body A over its tiles, the others body B.
@@ -219,7 +235,10 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       __syncthreads();
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
          for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+         {
+            chunkFence<BA>();
             A.template compute<T>(L, Le, First + Le, Kv);
+         }
    } else {
       const int First = xcdRemap(blockIdx.x - NTilesA, gridDim.x - NTilesA) * Tile;
       const int Cnt   = NB - First < Tile ? NB - First : Tile;
@@ -229,7 +248,10 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       __syncthreads();
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
          for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+         {
+            chunkFence<BB>();
             Bb.template compute<T>(L, Le, First + Le, Kv);
+         }
    }
 }
 
