@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--partition", default="graph", choices=["graph", "rcb"],
                     help="N > 1: built-in partitioner of the cell graph (graph = recursive graph bisection + FM / k-way "
                          "refinement, the stand-in for the reference's METIS k-way; rcb = coordinate bisection)")
-    ap.add_argument("--local-order", default="curve", choices=["curve", "global"],
+    ap.add_argument("--local-order", default="curve", choices=["curve", "hilbert", "global"],
                     help="local numbering chosen by Decomp: curve = along a Morton curve through the cell centres "
                          "(default: the library owns data locality), global = the reference's global-id order")
     ap.add_argument("--no-cpu-baseline", action="store_true")

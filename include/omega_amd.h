@@ -146,8 +146,9 @@ int omg_decomp_create(const omg_global_mesh *mesh, int nparts, int mytask, int h
                       const int32_t *cell_task, omg_decomp **out);
 /* local_order: 0 = the reference's numbering (owned cells in global-id order, every halo layer sorted by global id,
  * O/src/base/Decomp.cpp:1000-1080); 1 = every group ordered along a Morton curve through the cell centres, so that
- * consecutive local elements are spatial neighbours whatever order the mesh file uses (edges / vertices follow the
- * cells in both cases).  Per global id the results of every computation are identical. */
+ * consecutive local elements are spatial neighbours whatever order the mesh file uses; 2 = the same along a Hilbert
+ * curve (edges / vertices follow the cells in every case).  Per global id the results of every computation are
+ * identical. */
 int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
                               const int32_t *cell_task, int local_order, omg_decomp **out);
 /* Built-in partitioners of the cell graph (the reference calls METIS_PartGraphKway, O/src/base/Decomp.cpp:868-1000):

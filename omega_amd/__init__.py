@@ -392,13 +392,13 @@ def partition_cells(gm: GlobalMesh, nparts: int, method: str = "graph"):
 class Decomp:
     def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None,
                  local_order: str = "global"):
-        """local_order: "global" (the reference's numbering by global id) or "curve" (Morton curve through the cell
-        centres: spatially compact local numbering whatever the file's order)."""
+        """local_order: "global" (the reference's numbering by global id), "curve" (Morton curve through the cell
+        centres: spatially compact local numbering whatever the file's order) or "hilbert" (Hilbert curve)."""
         self.gm = gm
         h = C.c_void_p()
         ct = None if cell_task is None else np.ascontiguousarray(cell_task, dtype=np.int32)
         _chk(lib().omg_decomp_create_ordered(C.byref(gm.s), nparts, mytask, halo_width, _pi(ct),
-                                             {"global": 0, "curve": 1}[local_order], C.byref(h)))
+                                             {"global": 0, "curve": 1, "hilbert": 2}[local_order], C.byref(h)))
         self.h = h
 
     def get_int(self, name: str) -> int:

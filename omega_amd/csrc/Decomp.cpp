@@ -17,7 +17,7 @@ void Decomp::partitionRCB() { OMEGA::partitionRCB(G, NumTasks, CellTask); }
 void Decomp::buildCellOrder() {
    CellSeq.resize(NCellsGlobal);
    std::iota(CellSeq.begin(), CellSeq.end(), 0);
-   if (Order == LocalOrder::Curve) {
+   if (Order == LocalOrder::Curve || Order == LocalOrder::Hilbert) {
       OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: curve ordering needs cell coordinates");
       const R8 *C[3] = {G.XCell, G.YCell, G.ZCell};
       R8 Mn[3] = {0, 0, 0}, Sc[3] = {0, 0, 0};
@@ -41,12 +41,54 @@ void Decomp::buildCellOrder() {
          V = (V | V << 2) & 0x1249249249249249ULL;
          return V;
       };
+      // Hilbert index of a point of the 2^21-per-axis grid: the axes are brought into "transposed" form by the
+      // usual sequence of conditional reflections / exchanges from the top bit down and a Gray decode, then
+      // interleaved like the Morton key.  Axes with no extent do not take part.
+      int Ax[3], ND = 0;
+      for (int A = 0; A < 3; ++A)
+         if (C[A] && Sc[A] > 0)
+            Ax[ND++] = A;
+      auto HilbertKey = [&](const unsigned long long *Q) {
+         unsigned long long X[3] = {Q[0], Q[1], Q[2]};
+         const unsigned long long Top = 1ULL << 20;
+         for (unsigned long long B = Top; B > 1; B >>= 1) { // undo the excess work of the Gray code, top down
+            const unsigned long long P = B - 1;
+            for (int I = 0; I < ND; ++I) {
+               if (X[I] & B) {
+                  X[0] ^= P; // reflect the low bits of axis 0
+               } else {      // exchange the low bits of axis 0 and axis I
+                  const unsigned long long T = (X[0] ^ X[I]) & P;
+                  X[0] ^= T;
+                  X[I] ^= T;
+               }
+            }
+         }
+         for (int I = 1; I < ND; ++I) // Gray encode
+            X[I] ^= X[I - 1];
+         unsigned long long T = 0;
+         for (unsigned long long B = Top; B > 1; B >>= 1)
+            if (X[ND - 1] & B)
+               T ^= B - 1;
+         for (int I = 0; I < ND; ++I)
+            X[I] ^= T;
+         unsigned long long K = 0; // axis 0 carries the most significant bit of every digit
+         for (int I = 0; I < ND; ++I)
+            K |= Spread(X[I]) << (ND - 1 - I);
+         return K;
+      };
       std::vector<unsigned long long> Key(NCellsGlobal);
       for (I4 I = 0; I < NCellsGlobal; ++I) {
          unsigned long long K = 0;
-         for (int A = 0; A < 3; ++A)
-            if (C[A] && Sc[A] > 0)
-               K |= Spread((unsigned long long)((C[A][I] - Mn[A]) * S)) << A;
+         if (Order == LocalOrder::Hilbert && ND > 0) {
+            unsigned long long Q[3] = {0, 0, 0};
+            for (int D = 0; D < ND; ++D)
+               Q[D] = (unsigned long long)((C[Ax[D]][I] - Mn[Ax[D]]) * S) & 0x1fffffULL;
+            K = HilbertKey(Q);
+         } else {
+            for (int A = 0; A < 3; ++A)
+               if (C[A] && Sc[A] > 0)
+                  K |= Spread((unsigned long long)((C[A][I] - Mn[A]) * S)) << A;
+         }
          Key[I] = K;
       }
       std::sort(CellSeq.begin(), CellSeq.end(), [&](I4 A, I4 B) { return Key[A] < Key[B] || (Key[A] == Key[B] && A < B); });

@@ -44,9 +44,10 @@ enum PartMethod { PartMethodRCB, PartMethodUser };
 /// (Decomp.cpp:1000-1080: owned cells in global-id order, every halo layer sorted by global id); Curve orders
 /// each group along a space-filling (Morton) curve through the cell centres, so that consecutive local cells --
 /// a kernel's tile, an XCD's share of the sweep -- are spatial neighbours whatever numbering the mesh file came
-/// with.  Edges and vertices follow the cells (order of encounter) in both cases.  Results per global id are
-/// identical; only the local numbering differs.
-enum class LocalOrder { GlobalID = 0, Curve = 1 };
+/// with; Hilbert does the same along a Hilbert curve (no jumps: consecutive cells are always adjacent boxes of the
+/// quantisation grid).  Edges and vertices follow the cells (order of encounter) in every case.  Results per global
+/// id are identical; only the local numbering differs.
+enum class LocalOrder { GlobalID = 0, Curve = 1, Hilbert = 2 };
 
 /// Ordered local element lists of one rank (global 0-based ids) with layer bounds.
 struct LocalSets {

@@ -346,7 +346,7 @@ int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo
 int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
                               const int32_t *cell_task, int local_order, omg_decomp **out) {
    OMG_TRY
-   OMG_ARG(mesh && out && (local_order == 0 || local_order == 1));
+   OMG_ARG(mesh && out && local_order >= 0 && local_order <= 2);
    auto *R = new omg_decomp;
    try {
       R->D.reset(new Decomp(toDesc(*mesh), nparts, mytask, halo_width, cell_task, (LocalOrder)local_order));

@@ -47,15 +47,14 @@
 namespace OMEGA {
 
 // ---------------------------------------------------------------------------------------
-// Addressing.  Inside one array plane ([rows][K] doubles) an element is addressed by a 32-bit
-// BYTE offset from the plane's base pointer.  The base is wave-uniform (kernel argument, or
-// argument + tracer * plane size), so the compiler emits `global_load_dwordx4 v, v_off, s[base]`
-// and a gather costs one 32-bit VGPR per neighbour, shared by every array of that index space
-// (h, each tracer, each Del2Tracers plane, ...).  launchFusedRHS checks planes are < 4 GiB.
-#ifndef OMEGA_FLAT_ADDR
-// MUBUF form: the plane's base goes into a buffer resource (4 SGPRs, built from the wave-uniform pointer; no
-// stride, no bound below 4 GiB), the element offset is the instruction's 32-bit VGPR offset -- no 64-bit address
-// arithmetic and no address register pairs per access.
+// Addressing.  Inside one array plane ([rows][pitch] doubles) an element is addressed by a 32-bit BYTE offset from
+// the plane's base pointer, and every access is a buffer (MUBUF) instruction: the wave-uniform base (kernel argument,
+// or argument + tracer * plane size) goes into a buffer resource -- 4 SGPRs, no stride, no bound below 4 GiB
+// (fusedRHSSupported checks the planes are smaller) -- and the offset is the instruction's VGPR offset:
+// `buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`.  A gather costs one 32-bit VGPR per neighbour, shared by every
+// array of that index space (h, each tracer, each Del2Tracers plane, ...), and no address arithmetic.  (Written as
+// pointer arithmetic, two thirds of the accesses became 64-bit VGPR address computations and the tracer planes
+// flat_load: DESIGN.md section 4.)
 typedef unsigned BufV4 __attribute__((ext_vector_type(4)));
 typedef unsigned BufV2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bufRsrc(const Real *Base) {
@@ -67,7 +66,6 @@ template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned B
    else
       return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(bufRsrc(Base), ByteOff, 0, 0));
 }
-template <class T> __device__ __forceinline__ void stAux(Real *Base, unsigned ByteOff, T V, int) {}
 template <class T> __device__ __forceinline__ void sto(Real *Base, unsigned ByteOff, T V) {
    if constexpr (sizeof(T) == 16)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(BufV4, V), bufRsrc(Base), ByteOff, 0, 0);
@@ -84,24 +82,6 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
 /// keeps loop-invariant LDS reads inside the loop (a register each otherwise): nothing after this point may be
 /// assumed unchanged in memory
 __device__ __forceinline__ void loopFence() { __asm__ volatile("" ::: "memory"); }
-#else
-__device__ __forceinline__ void loopFence() {}
-template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned ByteOff) {
-   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(Base) + ByteOff);
-}
-template <class T> __device__ __forceinline__ void sto(Real *Base, unsigned ByteOff, T V) {
-   *reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff) = V;
-}
-/// streaming store for outputs nobody re-reads inside the same kernel: keeps the XCD's L2 for the
-/// gathered inputs
-template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned ByteOff, T V) {
-#ifdef OMEGA_NO_NT_STORES
-   *reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff) = V;
-#else
-   __builtin_nontemporal_store(V, reinterpret_cast<T *>(reinterpret_cast<char *>(Base) + ByteOff));
-#endif
-}
-#endif
 /// Device-side view of one variable's Runge-Kutta stage update (Kernels.h: StageUpdate)
 struct StageEpi {
    Real CB = 0, CA = 0;

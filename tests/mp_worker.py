@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="RK4 (gpu mode): exchange after the stage instead of overlapped")
     ap.add_argument("--user-stream", action="store_true",
                     help="gpu mode: step on a non-blocking stream created with omg_stream_create instead of the default stream")
-    ap.add_argument("--local-order", default="global", choices=["global", "curve"],
+    ap.add_argument("--local-order", default="global", choices=["global", "curve", "hilbert"],
                     help="Decomp local numbering: the reference's (global id) or along a Morton curve")
     ap.add_argument("--partition", default="rcb", choices=["rcb", "graph"], help="built-in partitioner (omg_partition_cells)")
     ap.add_argument("--rtol", type=float, default=0.0,
