@@ -49,16 +49,20 @@ namespace OMEGA {
 // ---------------------------------------------------------------------------------------
 // Addressing.  Inside one array plane ([rows][pitch] doubles) an element is addressed by a 32-bit BYTE offset from
 // the plane's base pointer, and every access is a buffer (MUBUF) instruction: the wave-uniform base (kernel argument,
-// or argument + tracer * plane size) goes into a buffer resource -- 4 SGPRs, no stride, no bound below 4 GiB
+// or argument + tracer * plane size) goes into a buffer resource -- 4 SGPRs, no stride, no bound below 4 GiB - 256 B
 // (fusedRHSSupported checks the planes are smaller) -- and the offset is the instruction's VGPR offset:
 // `buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`.  A gather costs one 32-bit VGPR per neighbour, shared by every
 // array of that index space (h, each tracer, each Del2Tracers plane, ...), and no address arithmetic.  (Written as
 // pointer arithmetic, two thirds of the accesses became 64-bit VGPR address computations and the tracer planes
 // flat_load: DESIGN.md section 4.)
+// Every resource has the size BufOOB: offsets below it are in range for any plane; a lane whose offset IS BufOOB is
+// out of range -- its load returns 0 without touching memory (checked on the hardware).  ldoIf uses that to switch a
+// load off by a (wave-uniform or per-lane) condition without a branch, so it can be issued early with the others.
+constexpr unsigned BufOOB = 0xffffff00u;
 typedef unsigned BufV4 __attribute__((ext_vector_type(4)));
 typedef unsigned BufV2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bufRsrc(const Real *Base) {
-   return __builtin_amdgcn_make_buffer_rsrc(const_cast<Real *>(Base), 0, 0xffffffffu, 0x00020000);
+   return __builtin_amdgcn_make_buffer_rsrc(const_cast<Real *>(Base), 0, BufOOB, 0x00020000);
 }
 template <class T> __device__ __forceinline__ T ldo(const Real *Base, unsigned ByteOff) {
    if constexpr (sizeof(T) == 16)
@@ -78,6 +82,9 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(BufV4, V), bufRsrc(Base), ByteOff, 0, 2);
    else
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(BufV2, V), bufRsrc(Base), ByteOff, 0, 2);
+}
+template <class T> __device__ __forceinline__ T ldoIf(bool Cond, const Real *Base, unsigned ByteOff) {
+   return ldo<T>(Base, Cond ? ByteOff : BufOOB);
 }
 /// keeps loop-invariant LDS reads inside the loop (a register each otherwise): nothing after this point may be
 /// assumed unchanged in memory
@@ -104,6 +111,27 @@ __device__ __forceinline__ void stageUpdate(const StageEpi &E, unsigned Off, T T
    stnt<T>(E.Next, Off, Base + E.CB * Tend);
    if (!E.Last) {
       const T Cur = E.First ? Base : ldo<T>(E.Cur, Off);
+      stnt<T>(E.Prov, Off, Cur + E.CA * Tend);
+   }
+}
+/// The same update with its loads split off, so that they can be asked for together with the loads of the
+/// arithmetic that produces Tend (stagePre) instead of after it; a load the stage does not need is switched off
+/// through its offset (ldoIf).  Same expressions as stageUpdate.
+template <class T> struct StagePre {
+   T NextOld, CurV;
+};
+template <class T, bool HaveReg> __device__ __forceinline__ StagePre<T> stagePre(const StageEpi &E, unsigned Off) {
+   StagePre<T> R;
+   R.NextOld = ldoIf<T>(!E.First, E.Next, Off);
+   R.CurV    = ldoIf<T>(E.First ? !HaveReg : !E.Last, E.Cur, Off);
+   return R;
+}
+template <class T, bool HaveReg>
+__device__ __forceinline__ void stageApply(const StageEpi &E, unsigned Off, T Tend, T CurIfFirst, const StagePre<T> &R) {
+   const T Base = E.First ? (HaveReg ? CurIfFirst : R.CurV) : R.NextOld;
+   stnt<T>(E.Next, Off, Base + E.CB * Tend);
+   if (!E.Last) {
+      const T Cur = E.First ? Base : R.CurV;
       stnt<T>(E.Prov, Off, Cur + E.CA * Tend);
    }
 }
@@ -351,6 +379,9 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
          Usp[J]      = ldo<T>(U, rowOff<T>(L.Spoke[Le * TME + J], K, Kv));
       }
       const T Hs = ldo<T>(H, OffS);
+      StagePre<T> PreH{};
+      if (EPI)
+         PreH = stagePre<T, true>(E, OffS);
       // ---- KineticAuxVars / ThicknessFluxDivOnCell: exactly FusedCell1Body ----
       T HMeanJ[TME], Flux[TME];
       {
@@ -374,7 +405,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
          if (!EPI || E.StoreTend)
             stnt<T>(HTend, OffS, HT);
          if (EPI)
-            stageUpdate<T, true>(E, OffS, HT, Hs);
+            stageApply<T, true>(E, OffS, HT, Hs, PreH);
       }
       // ---- VorticityAuxVars::computeVarsOnVertex at every ring vertex (VorticityAuxVars.h:24-59) ----
       // ((0 + t0) + t1) + t2 in the vertex's slot order: t0 + t1 commutes, so with the coefficients staged per
@@ -1293,7 +1324,10 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
             continue;
          const int Im     = (I + N - 1) % N;
          const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
-         T TendV          = splat<T>(0.0);
+         StagePre<T> PreU{};
+         if (EPI)
+            PreU = stagePre<T, true>(E, OffE[I]);
+         T TendV = splat<T>(0.0);
          TendV += Acc[I]; // EdgeMask is 1 on a regular edge
          TendV -= (KEs - ldo<T>(KE, OffN[I])) * InvDc;
          const T Ssh0 = Hn[I] - L.BDn[Li];
@@ -1309,7 +1343,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
          if (!EPI || E.StoreTend)
             stnt<T>(Tend, OffE[I], TendV);
          if (EPI)
-            stageUpdate<T, true>(E, OffE[I], TendV, Uj[I]);
+            stageApply<T, true>(E, OffE[I], TendV, Uj[I], PreU);
       }
    }
 };
@@ -1712,6 +1746,15 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
          }
          const T Ts = ldo<T>(TrL, OffS);
          const T Ds = HypOn ? ldo<T>(D2L, OffS) : splat<T>(0.0);
+         // stage update operands (EPI), asked for with the gathers instead of after the arithmetic; switched off
+         // through the offset in the stages that do not read them
+         Real *NextL = nullptr;
+         T NextOld = Ts, CurOld = Ts;
+         if (EPI) {
+            NextL   = uniformPtr(E.Next + Lt * CStride);
+            NextOld = ldoIf<T>(!E.First, NextL, OffS);
+            CurOld  = ldoIf<T>(!E.First && !E.Last, uniformPtr(E.Cur + Lt * CStride), OffS);
+         }
          T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
          if (Fast) {
             // center fluxes: h(c0)*tr(c0) + h(c1)*tr(c1) and h(c0)+h(c1) do not depend on which
@@ -1758,15 +1801,14 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
          if (!EPI || E.StoreTend)
             stnt<T>(uniformPtr(Tend + Lt * CStride), OffS, TendV);
          if (EPI) {
-            Real *NextL = uniformPtr(E.Next + Lt * CStride);
             // weightTracers + accumulateTracersUpdate (+ finalizeTracersUpdate in the last stage)
-            T Acc = E.First ? T(Ts * Hs) : ldo<T>(NextL, OffS);
+            T Acc = E.First ? T(Ts * Hs) : NextOld;
             Acc   = Acc + E.CB * TendV;
             if (E.Last)
                Acc = Acc / EpDivH;
             stnt<T>(NextL, OffS, Acc);
             if (!E.Last) { // updateTracersByTend: (CurTr*CurH + CA*Tend) / ProvH
-               const T CurT = E.First ? Ts : ldo<T>(uniformPtr(E.Cur + Lt * CStride), OffS);
+               const T CurT = E.First ? Ts : CurOld;
                stnt<T>(uniformPtr(E.Prov + Lt * CStride), OffS, (CurT * EpCurH + E.CA * TendV) / EpDivH);
             }
          }
@@ -1788,7 +1830,7 @@ static bool isDefaultTermSet(const TendParams &P) {
 bool fusedRHSSupported(const MeshView &M, int K) {
    const size_t MaxRows = (size_t)(M.NEdgesSize > M.NCellsSize ? M.NEdgesSize : M.NCellsSize);
    const size_t Rows    = MaxRows > (size_t)M.NVerticesSize ? MaxRows : (size_t)M.NVerticesSize;
-   return M.MaxEdges >= 5 && M.MaxEdges <= 8 && Rows * (size_t)levelPitch(K) * 8 < ((size_t)1 << 32);
+   return M.MaxEdges >= 5 && M.MaxEdges <= 8 && Rows * (size_t)levelPitch(K) * 8 <= (size_t)BufOOB;
 }
 
 template <int TME, bool Fast>
