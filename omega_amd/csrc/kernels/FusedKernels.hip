@@ -1724,14 +1724,10 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
       const size_t CStride = (size_t)M.NCellsSize * K;
       // stage update (EPI): thicknesses this cell's tracer update divides / multiplies by
       T EpCurH = Hs, EpDivH = Hs;
-      if (EPI) {
-         if (!E.Last) {
-            if (!E.First)
-               EpCurH = ldo<T>(E.CurH, OffS);
-            EpDivH = ldo<T>(E.ProvH, OffS);
-         } else {
-            EpDivH = ldo<T>(E.NextH, OffS);
-         }
+      if (EPI) { // (both asked for with the gathers above; the first is switched off where the stage does not read it)
+         const T LCur = ldoIf<T>(!E.Last && !E.First, E.CurH, OffS);
+         EpDivH       = ldo<T>(E.Last ? E.NextH : E.ProvH, OffS);
+         EpCurH       = (!E.Last && !E.First) ? LCur : Hs;
       }
 #pragma nounroll
       for (int Lt = 0; Lt < NT; ++Lt) {
