@@ -208,6 +208,9 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
    if (Cnt > 0)
       B.stage(L, First, Cnt, Tid, NThr);
    __syncthreads();
+#ifdef OMEGA_STAGE_ONLY // measurement build: what the staging of the tables costs (time, HBM bytes)
+   return;
+#endif
    for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
       for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
       {
@@ -233,6 +236,9 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       if (Cnt > 0)
          A.stage(L, First, Cnt, Tid, NThr);
       __syncthreads();
+#ifdef OMEGA_STAGE_ONLY
+      return;
+#endif
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
          for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
          {
@@ -246,6 +252,9 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       if (Cnt > 0)
          Bb.stage(L, First, Cnt, Tid, NThr);
       __syncthreads();
+#ifdef OMEGA_STAGE_ONLY
+      return;
+#endif
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
          for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
          {
