@@ -103,7 +103,7 @@ struct Geom {
    int Tile; ///< elements per workgroup
    int W;    ///< levels per thread (1 or 2)
 };
-inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0) {
+inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    if (Pitch <= 0)
       Pitch = K;
    Geom G;
@@ -128,6 +128,11 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0) {
    if (EnvTX > 0)
       TX = EnvTX < G.KV ? EnvTX : G.KV;
    int TY = 256 / TX;
+   // bodies with a short tracer loop run a little better on half-size tiles (QU30-sized, 6 tracers: -0.6..-1 %,
+   // EC30to60-sized, 2 tracers: -1.3 %); with 37 tracers the full tile is better (+3.5 % for the half tile): the
+   // launchers pass MaxTY = 16 for NT <= 8
+   while (MaxTY > 0 && TY > MaxTY && TY > 8)
+      TY /= 2;
    // small sweeps (an eighth of the QU30-sized mesh per GPU is ~1900 tiles of 32 elements: one round of
    // workgroups on 256 CUs): smaller tiles even out the tail (measured 0.884 -> 0.860 ms at that size)
    while (TY > 8 && (N + TY - 1) / TY < 4096)
@@ -264,6 +269,18 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
    }
 }
 
+template <class B, class = void> struct BodyHasNT {
+   static constexpr bool V = false;
+};
+template <class B> struct BodyHasNT<B, decltype((void)std::declval<B &>().NT)> {
+   static constexpr bool V = true;
+};
+template <class B> inline int bodyMaxTY(const B &Body) {
+   if constexpr (BodyHasNT<B>::V)
+      return Body.NT <= 8 ? 16 : 0;
+   else
+      return 0;
+}
 template <class B, class = void> struct BodyHasKLog {
    static constexpr bool V = false;
 };
@@ -281,7 +298,7 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
    B.K    = Pitch > 0 ? Pitch : levelPitch(K);
    if constexpr (BodyHasKLog<Body>::V)
       B.KLog = K;
-   Geom G           = makeGeom(N, K, BodyMaxW<Body>::V, B.K);
+   Geom G           = makeGeom(N, K, BodyMaxW<Body>::V, B.K, bodyMaxTY(B));
    const size_t Lds = B.ldsBytes(G.Tile);
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
@@ -312,7 +329,8 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
       A.KLog = K;
    if constexpr (BodyHasKLog<BB>::V)
       Bb.KLog = K;
-   Geom G = makeGeom(NA + NB, K, BodyMaxW<BA>::V, A.K);
+   const int TyA = bodyMaxTY(A), TyB = bodyMaxTY(Bb);
+   Geom G        = makeGeom(NA + NB, K, BodyMaxW<BA>::V, A.K, TyA > TyB ? TyA : TyB);
    const int NTA = (NA + G.Tile - 1) / G.Tile, NTB = (NB + G.Tile - 1) / G.Tile;
    const size_t LA = A.ldsBytes(G.Tile), LB = Bb.ldsBytes(G.Tile), Lds = LA > LB ? LA : LB;
    const dim3 Grid(NTA + NTB, G.Grid.y, 1);
