@@ -86,6 +86,16 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
 template <class T> __device__ __forceinline__ T ldoIf(bool Cond, const Real *Base, unsigned ByteOff) {
    return ldo<T>(Base, Cond ? ByteOff : BufOOB);
 }
+/// streaming load (nt) for values this launch reads exactly once (running PV sums, stage-update operands)
+template <class T> __device__ __forceinline__ T ldnt(const Real *Base, unsigned ByteOff) {
+   if constexpr (sizeof(T) == 16)
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(bufRsrc(Base), ByteOff, 0, 2));
+   else
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(bufRsrc(Base), ByteOff, 0, 2));
+}
+template <class T> __device__ __forceinline__ T ldntIf(bool Cond, const Real *Base, unsigned ByteOff) {
+   return ldnt<T>(Base, Cond ? ByteOff : BufOOB);
+}
 /// keeps loop-invariant LDS reads inside the loop (a register each otherwise): nothing after this point may be
 /// assumed unchanged in memory
 __device__ __forceinline__ void loopFence() { __asm__ volatile("" ::: "memory"); }
@@ -122,8 +132,8 @@ template <class T> struct StagePre {
 };
 template <class T, bool HaveReg> __device__ __forceinline__ StagePre<T> stagePre(const StageEpi &E, unsigned Off) {
    StagePre<T> R;
-   R.NextOld = ldoIf<T>(!E.First, E.Next, Off);
-   R.CurV    = ldoIf<T>(E.First ? !HaveReg : !E.Last, E.Cur, Off);
+   R.NextOld = ldntIf<T>(!E.First, E.Next, Off);
+   R.CurV    = ldntIf<T>(E.First ? !HaveReg : !E.Last, E.Cur, Off);
    return R;
 }
 template <class T, bool HaveReg>
@@ -1300,7 +1310,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
          Acc[I] = splat<T>(0.0);
          if (L.Role[Le * TME + I] != 2)
             continue;
-         Acc[I] = ldo<T>(Partial, OffE[I]);
+         Acc[I] = ldnt<T>(Partial, OffE[I]);
 #pragma unroll
          for (int J = 1; J < N; ++J) {
             const int Kk     = (I + J) % N;
@@ -1475,7 +1485,7 @@ template <int TME> struct CellPVFinalTracerBody {
             Acc[I] = splat<T>(0.0);
             if (L.Role[Le * TME + I] != 2)
                continue;
-            Acc[I] = ldo<T>(Partial, OffE[I]);
+            Acc[I] = ldnt<T>(Partial, OffE[I]);
 #pragma unroll
             for (int J = 1; J < N; ++J) {
                const int Kk     = (I + J) % N;
@@ -1748,8 +1758,8 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
          T NextOld = Ts, CurOld = Ts;
          if (EPI) {
             NextL   = uniformPtr(E.Next + Lt * CStride);
-            NextOld = ldoIf<T>(!E.First, NextL, OffS);
-            CurOld  = ldoIf<T>(!E.First && !E.Last, uniformPtr(E.Cur + Lt * CStride), OffS);
+            NextOld = ldntIf<T>(!E.First, NextL, OffS);
+            CurOld  = ldntIf<T>(!E.First && !E.Last, uniformPtr(E.Cur + Lt * CStride), OffS);
          }
          T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
          if (Fast) {
