@@ -1304,13 +1304,15 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
             QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
          }
       }
+      // (the running sums are asked for together ahead of the per-edge blocks: see CellPVFinalTracerBody)
       T Acc[N];
 #pragma unroll
+      for (int I = 0; I < N; ++I)
+         Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, OffE[I]);
+#pragma unroll
       for (int I = 0; I < N; ++I) {
-         Acc[I] = splat<T>(0.0);
          if (L.Role[Le * TME + I] != 2)
             continue;
-         Acc[I] = ldnt<T>(Partial, OffE[I]);
 #pragma unroll
          for (int J = 1; J < N; ++J) {
             const int Kk     = (I + J) % N;
@@ -1479,13 +1481,16 @@ template <int TME> struct CellPVFinalTracerBody {
                QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
             }
          }
+         // the running sums of the edges this cell finishes: asked for together, ahead of the per-edge blocks (a load
+         // inside a block is one more dependent round trip per block); switched off for the other slots
          T Acc[N];
 #pragma unroll
+         for (int I = 0; I < N; ++I)
+            Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, OffE[I]);
+#pragma unroll
          for (int I = 0; I < N; ++I) {
-            Acc[I] = splat<T>(0.0);
             if (L.Role[Le * TME + I] != 2)
                continue;
-            Acc[I] = ldnt<T>(Partial, OffE[I]);
 #pragma unroll
             for (int J = 1; J < N; ++J) {
                const int Kk     = (I + J) % N;
@@ -1508,17 +1513,18 @@ template <int TME> struct CellPVFinalTracerBody {
                continue;
             const int Im     = (I + N - 1) % N;
             const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
-            T TendV          = splat<T>(0.0);
+            const T KEnI = ldo<T>(KE, OffN[I]), DivNI = ldo<T>(Div, OffN[I]), D2NI = ldo<T>(Del2Div, OffN[I]);
+            T TendV = splat<T>(0.0);
             TendV += Acc[I];
-            TendV -= (KEs - ldo<T>(KE, OffN[I])) * InvDc;
+            TendV -= (KEs - KEnI) * InvDc;
             const T Ssh0 = Hn[I] - L.BDn[Li];
             TendV -= Grav * (Ssh1 - Ssh0) * InvDc;
             {
-               const T Del2U = ((DivS - ldo<T>(Div, OffN[I])) * InvDc - (Rv[I] - Rv[Im]) * InvDvS);
+               const T Del2U = ((DivS - DivNI) * InvDc - (Rv[I] - Rv[Im]) * InvDvS);
                TendV += L.C2[Li] * Del2U;
             }
             {
-               const T Del2U = (P.DivFactor * (D2S - ldo<T>(Del2Div, OffN[I])) * InvDc - (R2[I] - R2[Im]) * InvDvS);
+               const T Del2U = (P.DivFactor * (D2S - D2NI) * InvDc - (R2[I] - R2[Im]) * InvDvS);
                TendV -= L.C4[Li] * Del2U;
             }
             stnt<T>(Tend, OffE[I], TendV);
