@@ -83,6 +83,9 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
    else
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(BufV2, V), bufRsrc(Base), ByteOff, 0, 2);
 }
+template <class T> __device__ __forceinline__ void stoIf(bool Cond, Real *Base, unsigned ByteOff, T V) {
+   sto<T>(Base, Cond ? ByteOff : BufOOB, V); // (an out-of-range store is dropped)
+}
 template <class T> __device__ __forceinline__ T ldoIf(bool Cond, const Real *Base, unsigned ByteOff) {
    return ldo<T>(Base, Cond ? ByteOff : BufOOB);
 }
@@ -438,10 +441,11 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
             const T Xu = pick(Lu == 0, UB, UA), Yu = pick(Lu == 2, UB, UC), Zu = pick(Lu == 0, UA, pick(Lu == 1, UB, UC));
             const T RelVortTmp = ((Zero + Xu) + Yu) + Zu;
             const T Inv        = 1. / LayerThickVertex;
-            if ((Sel >> 4) & 1) { // this cell stores the vertex
+            { // the cell that stores the vertex (bit 4) writes; the other lanes' stores are switched off, not branched around
+               const bool Own      = (Sel >> 4) & 1;
                const unsigned OffV = rowOff<T>(L.Ring[Le * TME + R], K, Kv);
-               sto<T>(RelVortV, OffV, RelVortTmp);
-               sto<T>(InvThickV, OffV, Inv);
+               stoIf<T>(Own, RelVortV, OffV, RelVortTmp);
+               stoIf<T>(Own, InvThickV, OffV, Inv);
             }
             QR[R] = RelVortTmp * Inv;         // NormRelVortVertex   (:50-51)
             QF[R] = L.FV[Le * TME + R] * Inv; // NormPlanetVortVertex (:52-53)
