@@ -86,6 +86,9 @@ template <class T> __device__ __forceinline__ void stnt(Real *Base, unsigned Byt
 template <class T> __device__ __forceinline__ void stoIf(bool Cond, Real *Base, unsigned ByteOff, T V) {
    sto<T>(Base, Cond ? ByteOff : BufOOB, V); // (an out-of-range store is dropped)
 }
+template <class T> __device__ __forceinline__ void stntIf(bool Cond, Real *Base, unsigned ByteOff, T V) {
+   stnt<T>(Base, Cond ? ByteOff : BufOOB, V);
+}
 template <class T> __device__ __forceinline__ T ldoIf(bool Cond, const Real *Base, unsigned ByteOff) {
    return ldo<T>(Base, Cond ? ByteOff : BufOOB);
 }
@@ -483,22 +486,37 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
       // ---- TracerAuxVars::computeVarsOnCells: exactly FusedCell1Body ----
       if (DoDel2Tr) {
          const size_t CStride = (size_t)M.NCellsSize * K;
+#ifndef OMEGA_L1_TRUNROLL
+#define OMEGA_L1_TRUNROLL 2
+#endif
+         // TU tracers per trip: their gathers are asked for together (one memory round trip per trip); a tracer past
+         // the last one has its accesses switched off
+         constexpr int TU = OMEGA_L1_TRUNROLL;
 #pragma nounroll
-         for (int Lt = 0; Lt < NT; ++Lt) {
+         for (int Lt = 0; Lt < NT; Lt += TU) {
             loopFence();
-            const Real *TrL = uniformPtr(Tr + Lt * CStride);
-            T Tn[TME];
+            T Tn[TU][TME], Ts[TU];
 #pragma unroll
-            for (int J = 0; J < TME; ++J)
-               Tn[J] = ldo<T>(TrL, OffN[J]);
-            const T Ts = ldo<T>(TrL, OffS);
-            T Tmp      = splat<T>(0.0);
+            for (int Q = 0; Q < TU; ++Q) {
+               const bool Valid = TU == 1 || Lt + Q < NT;
+               const Real *TrL  = uniformPtr(Tr + (Valid ? Lt + Q : Lt) * CStride);
 #pragma unroll
-            for (int J = 0; J < TME; ++J) {
-               const T Grad = Fast ? T(Tn[J] - Ts) : T(pick(IsC0[J], Tn[J], Ts) - pick(IsC0[J], Ts, Tn[J]));
-               Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
+               for (int J = 0; J < TME; ++J)
+                  Tn[Q][J] = ldoIf<T>(Valid, TrL, OffN[J]);
+               Ts[Q] = ldoIf<T>(Valid, TrL, OffS);
             }
-            stnt<T>(uniformPtr(Del2Tr + Lt * CStride), OffS, Tmp * InvA);
+#pragma unroll
+            for (int Q = 0; Q < TU; ++Q) {
+               const bool Valid = TU == 1 || Lt + Q < NT;
+               T Tmp            = splat<T>(0.0);
+#pragma unroll
+               for (int J = 0; J < TME; ++J) {
+                  const T Grad =
+                      Fast ? T(Tn[Q][J] - Ts[Q]) : T(pick(IsC0[J], Tn[Q][J], Ts[Q]) - pick(IsC0[J], Ts[Q], Tn[Q][J]));
+                  Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
+               }
+               stntIf<T>(Valid, uniformPtr(Del2Tr + (Valid ? Lt + Q : Lt) * CStride), OffS, Tmp * InvA);
+            }
          }
       }
    }
@@ -1537,35 +1555,47 @@ template <int TME> struct CellPVFinalTracerBody {
       // ---- FusedCell3Body<TME, true> ----
       const Real InvA      = L.InvA[Le];
       const size_t CStride = (size_t)M.NCellsSize * K;
+#ifndef OMEGA_L3_TRUNROLL
+#define OMEGA_L3_TRUNROLL 1
+#endif
+      constexpr int TU = TME <= 6 ? OMEGA_L3_TRUNROLL : 1; // tracers per trip (see FusedCellL1PVBody); registers
 #pragma nounroll
-      for (int Lt = 0; Lt < NT; ++Lt) {
+      for (int Lt = 0; Lt < NT; Lt += TU) {
          loopFence();
-         const Real *TrL = uniformPtr(Tr + Lt * CStride);
-         const Real *D2L = uniformPtr(Del2Tr + Lt * CStride);
-         T Tn[TME], Dn[TME];
+         T Tn[TU][TME], Dn[TU][TME], Ts[TU], Ds[TU];
 #pragma unroll
-         for (int J = 0; J < TME; ++J) {
-            Tn[J] = ldo<T>(TrL, OffN[J]);
-            Dn[J] = ldo<T>(D2L, OffN[J]);
-         }
-         const T Ts = ldo<T>(TrL, OffS);
-         const T Ds = ldo<T>(D2L, OffS);
-         T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
-         const T HsTs = Hs * Ts;
+         for (int Q = 0; Q < TU; ++Q) {
+            const bool Valid = TU == 1 || Lt + Q < NT;
+            const Real *TrL  = uniformPtr(Tr + (Valid ? Lt + Q : Lt) * CStride);
+            const Real *D2L  = uniformPtr(Del2Tr + (Valid ? Lt + Q : Lt) * CStride);
 #pragma unroll
-         for (int J = 0; J < TME; ++J) {
-            const int I  = Le * TME + J;
-            const T HTr  = 0.5 * (HsTs + Hn[J] * Tn[J]);
-            HAdvTmp -= L.MDvS[I] * HTr * Uj[J] * InvA;
-            const T Mean = 0.5 * (Hs + Hn[J]);
-            DiffTmp -= L.Df2[I] * Mean * (Tn[J] - Ts);
-            HypTmp -= L.Df4[I] * (Dn[J] - Ds);
+            for (int J = 0; J < TME; ++J) {
+               Tn[Q][J] = ldoIf<T>(Valid, TrL, OffN[J]);
+               Dn[Q][J] = ldoIf<T>(Valid, D2L, OffN[J]);
+            }
+            Ts[Q] = ldoIf<T>(Valid, TrL, OffS);
+            Ds[Q] = ldoIf<T>(Valid, D2L, OffS);
          }
-         T TendV = splat<T>(0.0);
-         TendV -= HAdvTmp;
-         TendV += P.EddyDiff2 * DiffTmp * InvA;
-         TendV -= P.EddyDiff4 * HypTmp * InvA;
-         stnt<T>(uniformPtr(TrTend + Lt * CStride), OffS, TendV);
+#pragma unroll
+         for (int Q = 0; Q < TU; ++Q) {
+            const bool Valid = TU == 1 || Lt + Q < NT;
+            T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
+            const T HsTs = Hs * Ts[Q];
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const int I  = Le * TME + J;
+               const T HTr  = 0.5 * (HsTs + Hn[J] * Tn[Q][J]);
+               HAdvTmp -= L.MDvS[I] * HTr * Uj[J] * InvA;
+               const T Mean = 0.5 * (Hs + Hn[J]);
+               DiffTmp -= L.Df2[I] * Mean * (Tn[Q][J] - Ts[Q]);
+               HypTmp -= L.Df4[I] * (Dn[Q][J] - Ds[Q]);
+            }
+            T TendV = splat<T>(0.0);
+            TendV -= HAdvTmp;
+            TendV += P.EddyDiff2 * DiffTmp * InvA;
+            TendV -= P.EddyDiff4 * HypTmp * InvA;
+            stntIf<T>(Valid, uniformPtr(TrTend + (Valid ? Lt + Q : Lt) * CStride), OffS, TendV);
+         }
       }
    }
 };
