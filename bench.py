@@ -45,6 +45,8 @@ WORKLOADS = {
     "ico7": (0, 7, 0.0, 80, 6, "spherical icosahedral Voronoi mesh, 163842 cells (12 pentagons), 80L, 6 tracers"),
     "ico8": (0, 8, 0.0, 80, 6, "spherical icosahedral Voronoi mesh, 655362 cells (12 pentagons), 80L, 6 tracers "
                                "(QU30-sized on the sphere; the mesh generator needs a few minutes)"),
+    "fib7": (0, -163842, 0.0, 80, 6, "spherical Voronoi mesh of a relaxed Fibonacci lattice, 163842 cells (pentagons, "
+                                     "hexagons AND heptagons: maxEdges 7 with valence 6 dominant, as real MPAS meshes), 80L, 6 tracers"),
     "ico6": (0, 6, 0.0, 60, 2, "spherical icosahedral Voronoi mesh, 40962 cells (12 pentagons), 60L, 2 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
 }
@@ -96,6 +98,8 @@ def main():
     ap.add_argument("--partition", default="graph", choices=["graph", "rcb"],
                     help="N > 1: built-in partitioner of the cell graph (graph = recursive graph bisection + FM / k-way "
                          "refinement, the stand-in for the reference's METIS k-way; rcb = coordinate bisection)")
+    ap.add_argument("--max-edges", type=int, default=0,
+                    help="store the mesh with this (larger) maxEdges dimension, as mesh files often do (padding slots)")
     ap.add_argument("--local-order", default="curve", choices=["curve", "hilbert", "global"],
                     help="local numbering chosen by Decomp: curve = along a Morton curve through the cell centres "
                          "(default: the library owns data locality), global = the reference's global-id order")
@@ -124,7 +128,8 @@ def main():
 
     nx, ny, dc, K, NT, desc = WORKLOADS[args.workload]
     if args.dt <= 0:
-        cell = dc if dc > 0 else (4.0 * np.pi * 6371.22e3 ** 2 / (10 * 4 ** ny + 2)) ** 0.5   # icosahedral: mean spacing
+        ncell_sphere = -ny if ny < 0 else 10 * 4 ** ny + 2
+        cell = dc if dc > 0 else (4.0 * np.pi * 6371.22e3 ** 2 / ncell_sphere) ** 0.5   # sphere: mean spacing
         # (below 30 km the fixed Default.yml del4 viscosity limits the step like cell^4: use cell^2 as a compromise)
         args.dt = 600.0 * cell / 30.0e3 if cell >= 30.0e3 else 600.0 * (cell / 30.0e3) ** 2
     dist = None
@@ -150,16 +155,21 @@ def main():
     halo_width = args.halo_width if args.halo_width > 0 else (4 if N > 1 else 3)
 
     t0 = time.time()
-    if args.workload.startswith("ico"):   # sphere: cells already numbered along a Morton curve in (lon, z)
+    if args.workload.startswith("fib"):
+        g = spherical_voronoi(-ny, lloyd=2)
+    elif args.workload.startswith("ico"):   # sphere: cells already numbered along a Morton curve in (lon, z)
         g = spherical_voronoi(points=icosahedral_points(ny), lloyd=0)
     else:
         g = planar_hex(nx, ny, dc)
-    if args.workload.startswith("ico"):
+    if args.workload.startswith(("ico", "fib")):
         pass
     elif args.block <= 0:
         g = reorder_cells_morton(g, hilbert=args.block < 0)
     elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
+    if args.max_edges > g["maxEdges"]:
+        from omega_amd.meshgen import pad_max_edges
+        g = pad_max_edges(g, args.max_edges)
     gm = oa.GlobalMesh(g)
     cell_task, edge_cut = (oa.partition_cells(gm, N, args.partition) if N > 1 else (None, 0))
     decomp = oa.Decomp(gm, N, rank, halo_width, cell_task=cell_task, local_order=args.local_order)

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 namespace OMEGA {
@@ -89,6 +90,7 @@ HorzMesh::HorzMesh(const std::string &Name, const Decomp *D, I4 InNVertLayers, b
    AngleEdgeH         = gatherLocal(G.AngleEdge, D->EdgeIDH, NEdgesAll);
    KiteAreasOnVertexH = gatherLocal(G.KiteAreasOnVertex, D->VertexIDH, NVerticesAll, VertexDegree);
    WeightsOnEdgeH     = gatherLocal(G.WeightsOnEdge, D->EdgeIDH, NEdgesAll, MaxEdges2);
+   compactMaxEdges();
    FCellH             = gatherLocal(G.FCell, D->CellIDH, NCellsAll);
    FVertexH           = gatherLocal(G.FVertex, D->VertexIDH, NVerticesAll);
    FEdgeH             = gatherLocal(G.FEdge, D->EdgeIDH, NEdgesAll);
@@ -100,6 +102,42 @@ HorzMesh::HorzMesh(const std::string &Name, const Decomp *D, I4 InNVertLayers, b
       copyToDevice();
       buildCoefficientTables();
    }
+}
+
+// Mesh files often carry a maxEdges dimension larger than any cell uses (7, 8, 10 for a mesh of pentagons and
+// hexagons).  The kernels are instantiated for the table width, so the mesh keeps its cell-slot tables at the
+// largest valence actually present on this rank (never below 5): MaxEdges / MaxEdges2 of a HorzMesh are THAT width,
+// Decomp keeps the file's.  Padding slots never take part in any result.
+void HorzMesh::compactMaxEdges() {
+   MaxEdgesFile = MaxEdges;
+   // OMEGA_KEEP_MAXEDGES=1 (test hook): keep the file's width, so that the wide kernel instantiations and the
+   // edge-centric list for valences below MaxEdges-2 can be exercised with meshes that have no such cells
+   static const bool Keep = getenv("OMEGA_KEEP_MAXEDGES") && atoi(getenv("OMEGA_KEEP_MAXEDGES")) != 0;
+   if (Keep)
+      return;
+   int Eff      = 5;
+   for (int C = 0; C < NCellsAll; ++C)
+      Eff = std::max(Eff, (int)NEdgesOnCellH(C));
+   int Eff2 = 0; // EdgesOnEdge rows hold their entries contiguously from slot 0
+   for (int E = 0; E < NEdgesAll; ++E)
+      Eff2 = std::max(Eff2, (int)NEdgesOnEdgeH(E));
+   Eff = std::max(Eff, (Eff2 + 1) / 2);
+   if (Eff >= MaxEdges)
+      return;
+   auto Narrow = [](const auto &A, int NewW) {
+      std::decay_t<decltype(A)> R(A.Ext[0], NewW);
+      for (int I = 0; I < A.Ext[0]; ++I)
+         for (int J = 0; J < NewW; ++J)
+            R(I, J) = A(I, J);
+      return R;
+   };
+   CellsOnCellH    = Narrow(CellsOnCellH, Eff);
+   EdgesOnCellH    = Narrow(EdgesOnCellH, Eff);
+   VerticesOnCellH = Narrow(VerticesOnCellH, Eff);
+   EdgesOnEdgeH    = Narrow(EdgesOnEdgeH, 2 * Eff);
+   WeightsOnEdgeH  = Narrow(WeightsOnEdgeH, 2 * Eff);
+   MaxEdges        = Eff;
+   MaxEdges2       = 2 * Eff;
 }
 
 // HorzMesh::computeEdgeSign (reference HorzMesh.cpp:527-575)
@@ -692,8 +730,7 @@ void HorzMesh::buildCellPV() {
    IrregularEdges = Array1DI4("IrregularEdges", (int)std::max<size_t>(Irregular.size(), 1));
    if (!Irregular.empty())
       OMEGA::copyToDevice(IrregularEdges.Ptr, Irregular.data(), Irregular.size() * sizeof(I4));
-   std::vector<I4> CellsM1, CellsM2;
-   I4 NM0 = 0;
+   std::vector<I4> CellsM0, CellsM1, CellsM2;
    if (OK)
       for (int C = 0; C < NCellsAll; ++C) {
          const int N = NEdgesOnCellH(C);
@@ -701,20 +738,26 @@ void HorzMesh::buildCellPV() {
          for (int Kk = 0; Kk < ME; ++Kk)
             Any |= Role(C, Kk) != 0;
          if (Any && N == ME)
-            ++NM0;
+            CellsM0.push_back(C);
          if (Any && N == ME - 1)
             CellsM1.push_back(C);
          if (Any && N == ME - 2)
             CellsM2.push_back(C);
       }
+   RingCellsM0 = Array1DI4("RingCellsM0", (int)std::max<size_t>(CellsM0.size(), 1));
+   if (!CellsM0.empty())
+      OMEGA::copyToDevice(RingCellsM0.Ptr, CellsM0.data(), CellsM0.size() * sizeof(I4));
    RingCellsM1 = Array1DI4("RingCellsM1", (int)std::max<size_t>(CellsM1.size(), 1));
    RingCellsM2 = Array1DI4("RingCellsM2", (int)std::max<size_t>(CellsM2.size(), 1));
    if (!CellsM1.empty())
       OMEGA::copyToDevice(RingCellsM1.Ptr, CellsM1.data(), CellsM1.size() * sizeof(I4));
    if (!CellsM2.empty())
       OMEGA::copyToDevice(RingCellsM2.Ptr, CellsM2.data(), CellsM2.size() * sizeof(I4));
-   W.NRingCellsM0 = NM0, W.NRingCellsM1 = (I4)CellsM1.size(), W.NRingCellsM2 = (I4)CellsM2.size();
-   W.RingCellsM1 = RingCellsM1.Ptr, W.RingCellsM2 = RingCellsM2.Ptr;
+   W.NRingCellsM0 = (I4)CellsM0.size(), W.NRingCellsM1 = (I4)CellsM1.size(), W.NRingCellsM2 = (I4)CellsM2.size();
+   W.RingCellsM0 = RingCellsM0.Ptr, W.RingCellsM1 = RingCellsM1.Ptr, W.RingCellsM2 = RingCellsM2.Ptr;
+   // (the kernels' full sweeps are instantiated for the valence most cells have: MaxEdges or MaxEdges-1)
+   static const int DomEnv = getenv("OMEGA_DOM_VALENCE") ? atoi(getenv("OMEGA_DOM_VALENCE")) : 1;
+   W.DomM1 = (DomEnv != 0 && ME >= 6 && CellsM1.size() > CellsM0.size()) ? 1 : 0;
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
    W.RingVertOnCell = RingVertOnCell.Ptr, W.PVRoleOnCell = PVRoleOnCell.Ptr, W.PVWeightOnCell = PVWeightOnCell.Ptr;
    W.EdgeRegular = EdgeRegular.Ptr, W.IrregularEdges = IrregularEdges.Ptr;

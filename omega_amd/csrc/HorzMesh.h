@@ -91,8 +91,9 @@ struct MeshView {
    const I4 *EdgeRegular;          // [E] 1 regular, 0 handled by the edge-centric kernel
    const I4 *IrregularEdges;       // [NIrregularEdges]
    // cells of the rarer valences that own regular edges: the ring kernels run once more over each list
-   I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges (no list: full sweep), MaxEdges-1, MaxEdges-2
-   const I4 *RingCellsM1, *RingCellsM2;
+   I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges, MaxEdges-1, MaxEdges-2 (with regular edges)
+   const I4 *RingCellsM0, *RingCellsM1, *RingCellsM2;
+   I4 DomM1; ///< 1: most cells have MaxEdges-1 edges (a mesh of hexagons with a few heptagons): the full sweeps take that valence
    // ---- vertex quantities evaluated from the cell side (valid when CellL1OK; HorzMesh::buildCellL1Tables) ----
    // Ring vertex r of cell c (shared by edge slots r and r+1) touches the cells {c, across slot r, across slot r+1}
    // and the edges {slot r, slot r+1, "spoke" = the edge between the two neighbours}.  A thread that already holds
@@ -125,6 +126,8 @@ class HorzMesh : public Registry<HorzMesh> {
 
    I4 NCellsOwned, NCellsAll, NCellsSize;
    I4 NEdgesOwned, NEdgesAll, NEdgesSize, MaxCellsOnEdge, MaxEdges, MaxEdges2;
+   I4 MaxEdgesFile = 0; ///< the mesh file's maxEdges dimension (Decomp::MaxEdges); MaxEdges is the largest valence
+                        ///< present on this rank (HorzMesh.cpp: compactMaxEdges)
    I4 NVerticesOwned, NVerticesAll, NVerticesSize, VertexDegree;
    HostArrayI4 NCellsHaloH, NEdgesHaloH, NVerticesHaloH;
 
@@ -159,6 +162,7 @@ class HorzMesh : public Registry<HorzMesh> {
    const MeshView &view() const { return View; }
 
  private:
+   void compactMaxEdges();
    void computeEdgeSign();   // HorzMesh.cpp:527-575
    void setMasks();          // HorzMesh.cpp:581-602
    void setMeshScaling();    // HorzMesh.cpp:607-626
@@ -172,7 +176,7 @@ class HorzMesh : public Registry<HorzMesh> {
        Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex, Del2TrCoefSOnCell, Diff2CoefSOnCell, Diff4CoefSOnCell;
    DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
    Array2DReal RingSignOnCell;
-   Array1DI4 RingCellsM1, RingCellsM2, BandCells, InteriorCells;
+   Array1DI4 RingCellsM0, RingCellsM1, RingCellsM2, BandCells, InteriorCells;
    void buildBandLists(I4 HaloWidth);
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;

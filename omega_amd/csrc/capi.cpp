@@ -583,6 +583,7 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                      {"NEdgesAll", M.NEdgesAll},           {"NEdgesSize", M.NEdgesSize},
                                      {"NVerticesOwned", M.NVerticesOwned}, {"NVerticesAll", M.NVerticesAll},
                                      {"NVerticesSize", M.NVerticesSize},   {"MaxEdges", M.MaxEdges},
+                                     {"MaxEdgesFile", M.MaxEdgesFile},
                                      {"MaxEdges2", M.MaxEdges2},           {"VertexDegree", M.VertexDegree},
                                      {"NVertLayers", M.NVertLayers},       {"MaxCellsOnEdge", M.MaxCellsOnEdge}};
    if (!M.HostOnly) { // kernel-side table statistics (diagnostics)

@@ -304,7 +304,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
 #ifndef OMEGA_L1PV_MINW
 #define OMEGA_L1PV_MINW OMEGA_CELL_MINW
 #endif
-template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
+template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1PVBody {
    static constexpr int MinWaves = OMEGA_L1PV_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    static constexpr int TM1      = TME - 1;
@@ -454,28 +454,30 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
             QF[R] = L.FV[Le * TME + R] * Inv; // NormPlanetVortVertex (:52-53)
          }
       }
-      // ---- side-0 half of PotentialVortHAdvOnEdge: exactly CellPVBody<TME, Fast, 0> ----
-      if (N == TME) {
+      // ---- side-0 half of PotentialVortHAdvOnEdge: exactly CellPVBody<TME, Fast, 0, NR> ----
+      // (NR = the valence of most cells: MaxEdges, or MaxEdges-1 on a mesh of hexagons with a few heptagons; the other
+      // valences go through the list launches of CellPVBody)
+      if (N == NR) {
          bool Any = false;
 #pragma unroll
-         for (int J = 0; J < TME; ++J)
+         for (int J = 0; J < NR; ++J)
             Any |= L.Role[Le * TME + J] == 1;
          if (Any) {
             T QRe[TME], QFe[TME];
 #pragma unroll
-            for (int J = 0; J < TME; ++J) {
-               const int Jm = (J + TME - 1) % TME;
+            for (int J = 0; J < NR; ++J) {
+               const int Jm = (J + NR - 1) % NR;
                QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
                QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
             }
 #pragma unroll
-            for (int I = 0; I < TME; ++I) {
+            for (int I = 0; I < NR; ++I) {
                if (L.Role[Le * TME + I] != 1)
                   continue;
                T Acc = splat<T>(0.0);
 #pragma unroll
-               for (int J = 1; J < TME; ++J) {
-                  const int Kk     = (I + J) % TME;
+               for (int J = 1; J < NR; ++J) {
+                  const int Kk     = (I + J) % NR;
                   const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
                   Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Ue[Kk] * NormVort;
                }
@@ -491,7 +493,7 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCellL1PVBody {
 #endif
          // TU tracers per trip: their gathers are asked for together (one memory round trip per trip); a tracer past
          // the last one has its accesses switched off
-         constexpr int TU = OMEGA_L1_TRUNROLL;
+         constexpr int TU = OMEGA_L1_TRUNROLL; // (also for the 7-wide tables, where it costs 32 B of scratch: -6 %)
 #pragma nounroll
          for (int Lt = 0; Lt < NT; Lt += TU) {
             loopFence();
@@ -1385,7 +1387,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
 // CellPVFinalBody<TME, TME> and the default-term FusedCell3Body in one thread: the L3 work of a cell with one gather
 // of h and u (32 B per cell-level less than the paired launch of the two kernels; same expressions, so same bits).
 // Plain RHS only: with the stage updates in the epilogues the paired launch is the faster one.
-template <int TME> struct CellPVFinalTracerBody {
+template <int TME, int NR = TME> struct CellPVFinalTracerBody {
    static constexpr int MinWaves = OMEGA_PVF_MINW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
@@ -1475,15 +1477,15 @@ template <int TME> struct CellPVFinalTracerBody {
          Uj[J]   = ldo<T>(U, OffE[J]);
          Hn[J]   = ldo<T>(H, OffN[J]);
       }
-      bool Any = L.N[Le] == TME;
+      bool Any = L.N[Le] == NR;
       if (Any) {
          Any = false;
 #pragma unroll
-         for (int J = 0; J < TME; ++J)
+         for (int J = 0; J < NR; ++J)
             Any |= L.Role[Le * TME + J] == 2;
       }
-      if (Any) { // ---- CellPVFinalBody<TME, TME> ----
-         constexpr int N = TME;
+      if (Any) { // ---- CellPVFinalBody<TME, NR> ----
+         constexpr int N = NR;
          unsigned OffV[N];
          T Flux[N], QRe[N], QFe[N];
          {
@@ -1879,10 +1881,17 @@ bool fusedRHSSupported(const MeshView &M, int K) {
    return M.MaxEdges >= 5 && M.MaxEdges <= 8 && Rows * (size_t)levelPitch(K) * 8 <= (size_t)BufOOB;
 }
 
-template <int TME, bool Fast>
+/// ND = the valence the full sweeps of the cell-centric PV kernels are instantiated for: TME, or TME-1 when most
+/// cells have one edge fewer than the widest (hexagons with a few heptagons).  NA = the other of the two; cells of
+/// valence NA and TME-2 go through list launches.
+template <int TME, bool Fast, int ND = TME>
 static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
                          Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
                          hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage) {
+   constexpr int NA     = ND == TME ? TME - 1 : TME;
+   const I4 NMain       = ND == TME ? M.NRingCellsM0 : M.NRingCellsM1; // cells of the sweeps' valence
+   const I4 NOther      = ND == TME ? M.NRingCellsM1 : M.NRingCellsM0; // cells of valence NA (list launches)
+   const I4 *OtherCells = ND == TME ? M.RingCellsM1 : M.RingCellsM0;
    // Runge-Kutta stage update folded into the tendency-producing kernels (Fast term set only;
    // launchFusedRHS has checked that this mesh takes the cell-centric PV path)
    [[maybe_unused]] StageEpi EH, EU, ET;
@@ -1919,7 +1928,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (MergeL1) {
       auto LaunchL1 = [&](auto Epi) {
          constexpr bool EP = decltype(Epi)::value;
-         FusedCellL1PVBody<TME, Fast, EP> B{M,  K,  NT,    P,      DoDel2Tr,        H,
+         FusedCellL1PVBody<TME, Fast, EP, ND> B{M,  K,  NT,    P,      DoDel2Tr,        H,
                                             U,  Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
                                             A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
          launchTile(B, M.NCellsAll, K, S);
@@ -1992,7 +2001,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    static const int FuseFinalEnv = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
    // the side-1 PV + velocity kernel and the tracer kernel are independent: their main sweeps share a launch
    const bool PairL3 = PairEnv && Fast && EdgeMode == 0 && M.CellPVOK && EdgeScratch && P.PVTendencyEnable &&
-                       FuseFinalEnv && M.CellPVFinalOK && NT > 0 && M.NRingCellsM0 > 0;
+                       FuseFinalEnv && M.CellPVFinalOK && NT > 0 && NMain > 0;
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
@@ -2000,15 +2009,15 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       if (PVOn) {
          // the rarer valences (MaxEdges-1, MaxEdges-2: e.g. the pentagons of a mesh stored with
          // maxEdges = 6 or 7) run the same ring code, instantiated for their size, over cell lists
-         constexpr int NM1 = TME - 1, NM2 = TME >= 6 ? TME - 2 : TME - 1;
-         CellPVBody<TME, Fast, 0> B0{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
-         if (M.NRingCellsM0 > 0 && !MergeL1) // (merged: done by the L1 kernel; only the rarer valences remain)
+         constexpr int NM1 = NA, NM2 = TME >= 6 ? TME - 2 : TME - 1; // (NM1: "the other big valence")
+         CellPVBody<TME, Fast, 0, ND> B0{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
+         if (NMain > 0 && !MergeL1) // (merged: done by the L1 kernel; only the rarer valences remain)
             launchTile(B0, M.NCellsAll, K, S);
-         FusedKernelNames[4] = (!MergeL1 || M.NRingCellsM1 > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVBody<side 0>" : "";
-         if (M.NRingCellsM1 > 0) {
+         FusedKernelNames[4] = (!MergeL1 || NOther > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVBody<side 0>" : "";
+         if (NOther > 0) {
             CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
-                                             M.RingCellsM1};
-            launchTile(Bm, M.NRingCellsM1, K, S);
+                                             OtherCells};
+            launchTile(Bm, NOther, K, S);
          }
          if (TME >= 6 && M.NRingCellsM2 > 0) {
             CellPVBody<TME, Fast, 0, NM2> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
@@ -2024,7 +2033,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             const bool Overlap = Stage && Stage->AfterBand && M.NBandCells > 0;
             auto LaunchFinal = [&](auto Epi) {
                constexpr bool EP = decltype(Epi)::value;
-               CellPVFinalBody<TME, TME, EP> B1{M,
+               CellPVFinalBody<TME, ND, EP> B1{M,
                                                 K,
                                                 P,
                                                 H,
@@ -2040,7 +2049,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 UTend,
                                                 nullptr,
                                                 EU};
-               if (M.NRingCellsM0 > 0 && !PairL3) { // (paired: launched together with the tracer kernel below)
+               if (NMain > 0 && !PairL3) { // (paired: launched together with the tracer kernel below)
                   if (Overlap) {
                      B1.List = M.BandCells;
                      launchTile(B1, M.NBandCells, K, S);
@@ -2048,11 +2057,11 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                      launchTile(B1, M.NCellsAll, K, S);
                   }
                }
-               if (M.NRingCellsM1 > 0) {
+               if (NOther > 0) {
                   CellPVFinalBody<TME, NM1, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
                                                    B1.RelVortV, B1.InvThickV, B1.Partial, B1.RelVort, B1.KE,
-                                                   B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM1, EU};
-                  launchTile(Bm, M.NRingCellsM1, K, S);
+                                                   B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, OtherCells, EU};
+                  launchTile(Bm, NOther, K, S);
                }
                if (TME >= 6 && M.NRingCellsM2 > 0) {
                   CellPVFinalBody<TME, NM2, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
@@ -2065,8 +2074,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             LaunchFinalInterior = [&, Overlap]() {
                (void)Overlap;
                if constexpr (Fast) {
-                  if (Overlap && M.NRingCellsM0 > 0 && M.NInteriorCells > 0 && !PairL3) {
-                     CellPVFinalBody<TME, TME, true> B1{M,
+                  if (Overlap && NMain > 0 && M.NInteriorCells > 0 && !PairL3) {
+                     CellPVFinalBody<TME, ND, true> B1{M,
                                                         K,
                                                         P,
                                                         H,
@@ -2094,15 +2103,15 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             // (paired: the main sweep runs in slot 6 together with the tracer kernel; only the list launches of the
             // rarer valences remain here)
             FusedKernelNames[5] = !PairL3 ? "CellPVFinalBody"
-                                          : ((M.NRingCellsM1 > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVFinalBody (rarer valences)" : "");
+                                          : ((NOther > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVFinalBody (rarer valences)" : "");
          } else {
-            CellPVBody<TME, Fast, 1> B1{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
-            if (M.NRingCellsM0 > 0)
+            CellPVBody<TME, Fast, 1, ND> B1{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
+            if (NMain > 0)
                launchTile(B1, M.NCellsAll, K, S);
-            if (M.NRingCellsM1 > 0) {
+            if (NOther > 0) {
                CellPVBody<TME, Fast, 1, NM1> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
-                                                M.RingCellsM1};
-               launchTile(Bm, M.NRingCellsM1, K, S);
+                                                OtherCells};
+               launchTile(Bm, NOther, K, S);
             }
             if (TME >= 6 && M.NRingCellsM2 > 0) {
                CellPVBody<TME, Fast, 1, NM2> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
@@ -2192,7 +2201,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       if constexpr (Fast) {
          auto Go = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
-            CellPVFinalBody<TME, TME, EP> B1{M,
+            CellPVFinalBody<TME, ND, EP> B1{M,
                                              K,
                                              P,
                                              H,
@@ -2211,7 +2220,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             FusedCell3Body<TME, true, EP> B3{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
             if constexpr (!EP) {
                if (FuseL3) { // one thread per (cell, levels) does both: h and u gathered once
-                  CellPVFinalTracerBody<TME> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                  CellPVFinalTracerBody<TME, ND> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                 A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                 A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
                   launchTile(BF, M.NCellsAll, K, S);
@@ -2281,10 +2290,22 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
    const bool Fast = isDefaultTermSet(P);
    if (Stage && !stageFusedSupported(M, P, EdgeScratch))
       return false;
+   // (the sweeps' valence: MaxEdges, or MaxEdges-1 where that is what most cells have -- default term set, ME >= 6)
+#define OMEGA_DISPATCH_DOM(ME_)                                                                                    \
+   do {                                                                                                            \
+      if constexpr ((ME_) >= 6) {                                                                                  \
+         if (M.DomM1) {                                                                                            \
+            launchFusedT<ME_, true, (ME_)-1>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch,   \
+                                             Stage);                                                               \
+            break;                                                                                                 \
+         }                                                                                                         \
+      }                                                                                                            \
+      launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage);          \
+   } while (0)
 #define OMEGA_CASE(ME_)                                                                                            \
    case ME_:                                                                                                       \
       if (Fast)                                                                                                    \
-         launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage);       \
+         OMEGA_DISPATCH_DOM(ME_);                                                                                 \
       else                                                                                                         \
          launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr);    \
       break;
@@ -2297,6 +2318,7 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
       return false; // callers check fusedRHSSupported()
    }
 #undef OMEGA_CASE
+#undef OMEGA_DISPATCH_DOM
    return true;
 }
 

@@ -72,6 +72,19 @@ def test_generic_fallback_kernels_in_a_child_process():
     assert " passed" in out and "failed" not in out
 
 
+def test_file_width_kernels_in_a_child_process():
+    """OMEGA_KEEP_MAXEDGES=1: HorzMesh keeps the file's maxEdges instead of the largest valence present, so the
+    icosahedral mesh stored with maxEdges = 8 runs the 8-wide kernel instantiations with its hexagons as a "rarer
+    valence" and its pentagons' edges on the edge-centric list -- what a mesh with real 8-valent cells would do."""
+    env = dict(os.environ, OMEGA_KEEP_MAXEDGES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
+                        "ico3pad8 or sphere_meshes_take_the_fast_paths or rk4_on_the_sphere"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert " passed" in out and "failed" not in out
+
+
 def test_five_ranks_graph_partition_curve_order_one_gpu():
     """Five ranks on one card (the pool allows six processes on a GPU; one is left for the test runner): graph partition, Morton-ordered local numbering, HaloWidth 4, every
     Default.yml term, overlapped exchanges -- several neighbours per rank in one pack / unpack launch each."""
