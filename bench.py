@@ -352,8 +352,9 @@ def main():
                     return "+".join(x.split("<")[0].strip() for x in n.split("+"))
                 base = bases(name)
                 cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and bases(k) == base]
-                # `..., true>` instantiations are the RK4 stage-fused variants; the RHS timed here is the plain one
-                plain = [k for k in cands if ", true>" not in k] or cands
+                # the RK4 stage-fused instantiations of the same body move more bytes (accumulator, provisional
+                # state); the RHS timed here is the plain instantiation: the candidate with the fewest bytes
+                plain = sorted(cands, key=lambda k: pmc[k]["hbm_bytes_per_launch"])
                 if plain:
                     traffic = pmc[plain[0]]["hbm_bytes_per_launch"]
                     traffic_src = os.path.relpath(pmc_file, ROOT) + " (kernel_source_sha " + sha + ")"

@@ -593,6 +593,7 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"CellL1OK", W.CellL1OK},
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
+                                        {"DomM1", W.DomM1},
                                         {"Del2RingOK", W.Del2RingOK},
                                         {"Del2VertOK", W.Del2VertOK},
                                         {"NBandCells", W.NBandCells},

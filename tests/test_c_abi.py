@@ -59,6 +59,22 @@ def test_host_only_objects_and_loud_device_failures():
             oa.HorzMesh(d, 4)  # device mirrors cannot be allocated without a GPU
 
 
+def test_mesh_tables_are_kept_at_the_largest_valence_present():
+    """A mesh file's maxEdges dimension is often larger than any cell's valence (HorzMesh.cpp: compactMaxEdges):
+    HorzMesh keeps its cell-slot tables at the largest valence present, Decomp keeps the file's width."""
+    from omega_amd.meshgen import pad_max_edges
+    g = pad_max_edges(planar_hex(8, 8, 1.0), 8)
+    gm = oa.GlobalMesh(g)
+    d = oa.Decomp(gm, 1, 0, 3)
+    m = oa.HorzMesh(d, 4, host_only=True)
+    assert d.get_int("MaxEdges") == 8 and m.get_int("MaxEdgesFile") == 8 and m.get_int("MaxEdges") == 6
+    eoc, eoe = m.get_array("EdgesOnCell"), m.get_array("EdgesOnEdge")
+    assert eoc.shape == (65, 6) and eoe.shape[1] == 12
+    m0 = oa.HorzMesh(oa.Decomp(oa.GlobalMesh(planar_hex(8, 8, 1.0)), 1, 0, 3), 4, host_only=True)
+    assert np.array_equal(eoc, m0.get_array("EdgesOnCell")) and np.array_equal(eoe, m0.get_array("EdgesOnEdge"))
+    assert np.array_equal(m.get_array("WeightsOnEdge"), m0.get_array("WeightsOnEdge"))
+
+
 def test_bad_arguments_return_errors():
     g = planar_hex(8, 8, 1.0)
     gm = oa.GlobalMesh(g)

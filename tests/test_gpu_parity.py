@@ -52,6 +52,7 @@ CASES = [
     ("ico3", 0, 0, 12, 2, {}),                                 # icosahedral, 642 cells: 12 pentagons, MaxEdges 6
     ("fib1500", 0, 0, 10, 2, {}),                              # 1500 cells with pentagons AND heptagons, MaxEdges 7
     ("ico4", 0, 0, 60, 2, {}),                                 # 2562 cells, 60 levels, T+S
+    ("hex24pad8", 0, 0, 6, 2, {}),                             # planar hexagons stored with maxEdges = 8: tables compacted to 6
     ("ico3pad8", 0, 0, 6, 1, {}),                              # same mesh stored with maxEdges = 8: pentagons
                                                                # fall outside the ring kernels' valences
     # the DEFAULT wind interpolation (isotropic, kite-weighted: InterpCellToEdge, HorzOperators.h:161-180)
@@ -72,6 +73,8 @@ def sphere(name):
             _SPHERES[name] = spherical_voronoi(int(name[3:]), lloyd=4)
         elif name == "ico3pad8":
             _SPHERES[name] = pad_max_edges(sphere("ico3"), 8)
+        elif name == "hex24pad8":
+            _SPHERES[name] = pad_max_edges(planar_hex(24, 20, 30e3), 8)
         elif name.startswith("ico"):
             _SPHERES[name] = spherical_voronoi(points=icosahedral_points(int(name[3:])), lloyd=2)
         else:
@@ -144,6 +147,7 @@ def test_sphere_meshes_take_the_fast_paths():
     assert P.mesh.get_int("NIrregularEdges") == 0          # pentagons are handled by the 5-ring instantiation
     P = _mk(("fib1500", 0, 0, 4, 1, {}))
     assert P.mesh.get_int("MaxEdges") == 7 and P.mesh.get_int("Del2RingOK") == 1
+    assert P.mesh.get_int("DomM1") == 1        # hexagons dominate a 7-wide mesh: the full sweeps take valence 6
     assert P.mesh.get_int("CellPVOK") == 1 and P.mesh.get_int("NIrregularEdges") == 0
     P = _mk(("ico3pad8", 0, 0, 4, 1, {}))
     assert P.mesh.get_int("MaxEdgesFile") == 8 and P.mesh.get_int("CellPVOK") == 1
