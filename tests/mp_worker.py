@@ -61,7 +61,7 @@ def main():
         g = spherical_voronoi(points=icosahedral_points(int(a.mesh[3:])), lloyd=2)
     else:
         g = spherical_voronoi(int(a.mesh[3:]), lloyd=4)
-    K, NT, dt = a.levels, a.tracers, 600.0
+    K, NT, dt = a.levels, a.tracers, (5.0 if a.mesh.startswith("fib") else 600.0)   # (fib: a few very short edges)
     gpu = a.mode == "gpu"
     if gpu:
         oa.device_init(0)

@@ -30,6 +30,8 @@ pytestmark = pytest.mark.gpu
     ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 6, "--local-order", "curve"],   # Morton-ordered local numbering
     ["--halo-width", 4, "--mesh", "ico4", "--levels", 6, "--partition", "graph", "--local-order", "curve"],  # sphere: pentagon
                                                                   # lists next to the paired launches, del4 on, overlapped
+    ["--halo-width", 4, "--mesh", "fib1500", "--levels", 6, "--partition", "graph", "--local-order", "curve"],  # pentagons,
+                                     # hexagons and heptagons, 7-wide tables: the sweeps take valence 6, band / interior lists
     ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 20],     # 20 levels: device rows padded to 32 (pack / unpack with a pitch)
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream"],               # non-blocking user stream,
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream", "--no-overlap"],  # overlapped and sequential
