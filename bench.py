@@ -189,12 +189,33 @@ def main():
     del hg, ug, trg
 
     comm = None
+    wire_note = None
     stream = oa.Stream()
     if N > 1 and args.backend == "rccl":
-        ident = [oa.RcclComm.unique_id() if rank == 0 else None]
+        # The communicator is created by all ranks or used by none: a rank whose ncclCommInitRank fails (raises)
+        # reports it over the side channel and every rank takes the host-staged wire instead -- the record then says
+        # so (config.halo_wire), so that a measurement exists and cannot be mistaken for the RCCL one.
+        err = ""
+        try:
+            ident = [oa.RcclComm.unique_id() if rank == 0 else None]
+        except Exception as exc:  # noqa: BLE001
+            ident, err = [None], f"rank {rank}: {exc}"
         dist.broadcast_object_list(ident, src=0)
-        comm = oa.RcclComm(ident[0], N, rank)     # collective: ncclCommInitRank
-        halo.use_rccl(comm)
+        if ident[0] is not None:
+            try:
+                comm = oa.RcclComm(ident[0], N, rank)     # collective: ncclCommInitRank
+            except Exception as exc:  # noqa: BLE001
+                comm, err = None, f"rank {rank}: {exc}"
+        errs = [None] * N
+        dist.all_gather_object(errs, err)
+        if any(errs):
+            comm = None
+            wire_note = "host-staged gloo, because RCCL could not be initialised: " + "; ".join(e for e in errs if e)[:300]
+            print("[bench] " + wire_note, file=sys.stderr, flush=True)
+            from omega_amd.transport import GlooStagedTransport
+            GlooStagedTransport(halo)
+        else:
+            halo.use_rccl(comm)
     elif N > 1:  # gloo rehearsal: host-staged messages (both ranks may share one GPU)
         from omega_amd.transport import GlooStagedTransport
         GlooStagedTransport(halo)
@@ -386,7 +407,7 @@ def main():
                           "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else
                           ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
-                           "host-staged gloo (rehearsal)"),
+                           (wire_note or "host-staged gloo (rehearsal)")),
                           "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
                                                    "row-major" if args.block == 1 else f"blocked{args.block}")
                                         + ", local numbering by Decomp: " + args.local_order,
