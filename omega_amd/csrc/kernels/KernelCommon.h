@@ -102,6 +102,10 @@ struct Geom {
    int KV;   ///< level-chunks per column (K / W)
    int Tile; ///< elements per workgroup
    int W;    ///< levels per thread (1 or 2)
+   /// Tail split: the first NFull tiles are one workgroup each (all level chunks); each of the remaining tiles -- the
+   /// sweep's last, partial round of workgroups -- is spread over TailSplit workgroups (one level chunk each), so
+   /// that the launch drains with short workgroups instead of waiting for a few long ones.  TailSplit 1: off.
+   int NFull = 0, TailSplit = 1;
 };
 inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    if (Pitch <= 0)
@@ -159,7 +163,20 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
          Split *= 2;                                         // 74 us at 4; an eighth of QU30 (7225 tiles) loses at any
    if (Split > NChunks)
       Split = NChunks;
-   G.Grid = dim3(NTiles > 0 ? NTiles : 1, Split > 0 ? Split : 1, 1);
+   G.Grid  = dim3(NTiles > 0 ? NTiles : 1, Split > 0 ? Split : 1, 1);
+   G.NFull = NTiles;
+   // (wave slots: 8 waves per CU for the kernels that matter -- two per SIMD; the tail is what the last round leaves)
+   static const int EnvTail = getenv("OMEGA_TAIL_SPLIT") ? atoi(getenv("OMEGA_TAIL_SPLIT")) : 1;
+   const int WavesPerWG     = (TX * TY + 63) / 64;
+   const int Cap            = 256 * 8 / (WavesPerWG > 0 ? WavesPerWG : 1);
+   if (EnvTail && Split == 1 && NChunks > 1 && NTiles >= Cap) {
+      const int R = NTiles % Cap;
+      if (R > 0) {
+         G.NFull     = NTiles - R;
+         G.TailSplit = NChunks;
+         G.Grid      = dim3(G.NFull + R * NChunks, 1, 1);
+      }
+   }
    return G;
 }
 
@@ -200,10 +217,20 @@ template <class B> struct BodyMaxW<B, decltype((void)B::MaxW)> {
 #define OMEGA_LB 256
 #endif
 template <class Body, class T>
-__global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Body B, int N, int KV, int Tile) {
+__global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
+    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit) {
    extern __shared__ __align__(16) unsigned char Lds[];
-   const int TileId = xcdRemap(blockIdx.x, gridDim.x);
-   const int First  = TileId * Tile;
+   // level chunks of this workgroup: C0, C0 + CS, ...  (whole tile: gridDim.y-way split; tail tile: one chunk each)
+   int TileId, C0 = blockIdx.y, CS = gridDim.y;
+   if ((int)blockIdx.x < NFull) {
+      TileId = xcdRemap(blockIdx.x, NFull);
+   } else {
+      const int Bt = blockIdx.x - NFull;
+      TileId       = NFull + Bt / TailSplit;
+      C0           = Bt % TailSplit;
+      CS           = TailSplit;
+   }
+   const int First = TileId * Tile;
    int Cnt          = N - First;
    if (Cnt > Tile)
       Cnt = Tile;
@@ -217,7 +244,7 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
    return;
 #endif
    for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-      for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+      for (int Kv = C0 * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * CS)
       {
          chunkFence<Body>();
          B.template compute<T>(L, Le, First + Le, Kv);
@@ -230,7 +257,7 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V) tileKernel(Bo
 template <class BA, class BB, class T>
 __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<BB>::V ? BodyMinWaves<BA>::V
                                                                                        : BodyMinWaves<BB>::V))
-    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA) {
+    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit) {
    extern __shared__ __align__(16) unsigned char Lds[];
    const int Tid  = threadIdx.y * blockDim.x + threadIdx.x;
    const int NThr = blockDim.x * blockDim.y;
@@ -251,7 +278,17 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
             A.template compute<T>(L, Le, First + Le, Kv);
          }
    } else {
-      const int First = xcdRemap(blockIdx.x - NTilesA, gridDim.x - NTilesA) * Tile;
+      // (the second body's last tiles are the launch's tail: one level chunk per workgroup, see Geom::TailSplit)
+      const int Bb_ = blockIdx.x - NTilesA;
+      int TileId, C0 = blockIdx.y, CS = gridDim.y;
+      if (Bb_ < NFullB) {
+         TileId = xcdRemap(Bb_, NFullB);
+      } else {
+         TileId = NFullB + (Bb_ - NFullB) / TailSplit;
+         C0     = (Bb_ - NFullB) % TailSplit;
+         CS     = TailSplit;
+      }
+      const int First = TileId * Tile;
       const int Cnt   = NB - First < Tile ? NB - First : Tile;
       typename BB::Lds L = Bb.carve(Lds, Tile);
       if (Cnt > 0)
@@ -261,7 +298,7 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       return;
 #endif
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+         for (int Kv = C0 * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * CS)
          {
             chunkFence<BB>();
             Bb.template compute<T>(L, Le, First + Le, Kv);
@@ -302,12 +339,12 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
    const size_t Lds = B.ldsBytes(G.Tile);
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile);
+   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit);
    HIP_CHECK(hipGetLastError());
 }
 
@@ -333,15 +370,27 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
    Geom G        = makeGeom(NA + NB, K, BodyMaxW<BA>::V, A.K, TyA > TyB ? TyA : TyB);
    const int NTA = (NA + G.Tile - 1) / G.Tile, NTB = (NB + G.Tile - 1) / G.Tile;
    const size_t LA = A.ldsBytes(G.Tile), LB = Bb.ldsBytes(G.Tile), Lds = LA > LB ? LA : LB;
-   const dim3 Grid(NTA + NTB, G.Grid.y, 1);
+   // tail split on the second body's last tiles (the combined sweep's last, partial round of workgroups)
+   int NFullB = NTB, TailSplit = 1;
+   dim3 Grid(NTA + NTB, G.TailSplit > 1 ? 1 : G.Grid.y, 1);
+   if (G.TailSplit > 1) {
+      const int R = (NTA + NTB) - G.NFull; // makeGeom(NA + NB): tiles of the partial round (tile counts differ by <= 1)
+      if (R > 0 && R <= NTB) {
+         NFullB    = NTB - R;
+         TailSplit = G.TailSplit;
+         Grid      = dim3(NTA + NFullB + R * TailSplit, 1, 1);
+      }
+   }
    if constexpr (BodyMaxW<BA>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA);
+         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
+                            TailSplit);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA);
+   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
+                      TailSplit);
    HIP_CHECK(hipGetLastError());
 }
 
