@@ -49,6 +49,13 @@ WORKLOADS = {
                                      "hexagons AND heptagons: maxEdges 7 with valence 6 dominant, as real MPAS meshes), 80L, 6 tracers"),
     "ico6": (0, 6, 0.0, 60, 2, "spherical icosahedral Voronoi mesh, 40962 cells (12 pentagons), 60L, 2 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
+    # culled meshes (land removed the way MPAS ocean meshes are: omega_amd/meshgen.py cull / coast_mask "continents")
+    "qu30_coast": (800, 800, 30.0e3, 80, 6, "QU30-sized CULLED planar mesh: 800x800 hexagons with 28 % land removed "
+                                            "(continents + one-cell islands), 80L, 6 tracers"),
+    "ico7_coast": (0, 7, 0.0, 80, 6, "spherical icosahedral Voronoi mesh of 163842 cells with 28 % land removed, 80L, 6 tracers"),
+    "fib7_coast": (0, -163842, 0.0, 80, 6, "relaxed Fibonacci sphere (valences 5, 6, 7) of 163842 cells with 28 % land removed, "
+                                           "80L, 6 tracers"),
+    "small_coast": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96 with 28 % land removed, 80L, 6 tracers"),
 }
 
 
@@ -167,6 +174,9 @@ def main():
         g = reorder_cells_morton(g, hilbert=args.block < 0)
     elif args.block > 1:
         g = reorder_cells_blocked(g, args.block)
+    if args.workload.endswith("_coast"):
+        from omega_amd.meshgen import coast_mask, cull
+        g = cull(g, coast_mask(g, "continents"))
     if args.max_edges > g["maxEdges"]:
         from omega_amd.meshgen import pad_max_edges
         g = pad_max_edges(g, args.max_edges)
@@ -177,6 +187,9 @@ def main():
     halo = oa.Halo(decomp) if N > 1 else None
     cell_id, edge_id = decomp.get_array("CellID"), decomp.get_array("EdgeID")
     hg, ug, trg = synthetic_state(g, K, NT)
+    if "boundaryEdge" in g:     # an ocean state: no normal flow through the coast
+        from omega_amd.meshgen import zero_boundary_velocity
+        ug = zero_boundary_velocity(g, ug)
 
     def to_local(glob, ids, rows):
         out = np.zeros(glob.shape[:-2] + (rows, glob.shape[-1]))
@@ -395,7 +408,7 @@ def main():
     # ------------------------------------------------ CPU baseline (rank 0, N = 1 only): the oracle
     cpu = None
     if N == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(nx, ny, K, NT, dc, args.dt) if nx > 0 else None
+        cpu = cpu_baseline(nx, ny, K, NT, dc, args.dt) if (nx > 0 and not args.workload.endswith("_coast")) else None
 
     if rank == 0:
         out = {"metric": "tendency_cell_level_updates_per_sec", "value": value, "unit": "cell-level-updates/s",
@@ -403,6 +416,9 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
+                          "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
+                          "kernel_paths": {f: mesh.get_int(f) for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK",
+                                                                        "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1")},
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
                           "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else

@@ -1,5 +1,6 @@
 // Halo.cpp -- see Halo.h.
 #include "Halo.h"
+#include "PeerWire.h"
 #include "Rccl.h"
 #include "kernels/Kernels.h"
 
@@ -70,6 +71,18 @@ Halo::Halo(const std::string &, const Decomp *D) {
                SendLists[Kd][N].push_back((*Kinds[Kd].LocOf)[IDs[I]]);
       }
    }
+   // where my message lands in each neighbour's receive buffer: its layout is neighbour-major in ascending task
+   // order (planFor), and every owner of one of its halo elements is one of its neighbours
+   PeerRecvPrefix.assign(NNghbr, {0, 0, 0});
+   for (int N = 0; N < NNghbr; ++N) {
+      const LocalSets &S             = Sets[NeighborList[N]];
+      const std::vector<I4> *IDs[3]  = {&S.CellID, &S.EdgeID, &S.VertexID};
+      const I4 Owned[3]              = {S.NCellsOwned, S.NEdgesOwned, S.NVerticesOwned};
+      for (int Kd = 0; Kd < 3; ++Kd)
+         for (size_t I = Owned[Kd]; I < IDs[Kd]->size(); ++I)
+            if ((*Kinds[Kd].TaskOf)[(*IDs[Kd])[I]] < MyTask)
+               ++PeerRecvPrefix[N][Kd];
+   }
    SendPtrs.assign(NNghbr, nullptr);
    RecvPtrs.assign(NNghbr, nullptr);
 }
@@ -85,6 +98,23 @@ void Halo::useRccl(RcclComm *Comm) {
    for (I4 T : NeighborList)
       OMEGA_REQUIRE(T < Comm->NRanks, "Halo::useRccl: a neighbour task is outside the communicator");
    setTransport(&RcclComm::transport, Comm);
+}
+
+void Halo::usePeerWire(PeerWire *Wire) {
+   OMEGA_REQUIRE(Wire != nullptr && Wire->connected(), "Halo::usePeerWire: the wire is not connected");
+   OMEGA_REQUIRE(Wire->Rank == MyTask, "Halo::usePeerWire: the wire's rank is not this Halo's task");
+   OMEGA_REQUIRE(NNghbr <= PeerWire::MaxPeers, "Halo::usePeerWire: too many neighbours");
+   for (I4 T : NeighborList)
+      OMEGA_REQUIRE(T < Wire->NRanks, "Halo::usePeerWire: a neighbour task is outside the wire");
+   Peer      = Wire;
+   Transport = nullptr;
+}
+
+size_t Halo::recvRows(size_t NTC, size_t NTE, size_t NTV) const {
+   size_t R = 0;
+   for (int N = 0; N < NNghbr; ++N)
+      R += RecvLists[0][N].size() * NTC + RecvLists[1][N].size() * NTE + RecvLists[2][N].size() * NTV;
+   return R;
 }
 
 size_t Halo::requiredBytes(int N, size_t TC, size_t TE, size_t TV) const {
@@ -143,6 +173,10 @@ const Halo::Plan &Halo::planFor(const std::vector<Piece> &Pieces) {
          copyToDevice(D.Ptr, Jobs.data(), Jobs.size() * sizeof(I4));
       return D;
    };
+   Pl.RemoteOff.assign(NNghbr, 0);
+   for (int N = 0; N < NNghbr; ++N)
+      for (const Piece &P : Pieces)
+         Pl.RemoteOff[N] += (size_t)P.NT * PeerRecvPrefix[N][P.Elem] * RowBytes;
    Pl.SendJobs = Build(SendLists, Pl.SendOff, Pl.SendBytes, "HaloSendJobs", Pl.NSendRows);
    Pl.RecvJobs = Build(RecvLists, Pl.RecvOff, Pl.RecvBytes, "HaloRecvJobs", Pl.NRecvRows);
    return Plans.emplace(Key, std::move(Pl)).first->second;
@@ -151,17 +185,22 @@ const Halo::Plan &Halo::planFor(const std::vector<Piece> &Pieces) {
 I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
    if (NNghbr == 0)
       return 0;
-   OMEGA_REQUIRE(Transport != nullptr, "Halo: no transport set for a multi-rank exchange");
+   OMEGA_REQUIRE(Transport != nullptr || Peer != nullptr, "Halo: no transport set for a multi-rank exchange");
    OMEGA_REQUIRE(!Pieces.empty() && Pieces.size() <= (size_t)HaloMaxPieces, "Halo: too many arrays in one exchange");
    const Plan &Pl        = planFor(Pieces);
    const size_t RowBytes = (size_t)Pl.K * sizeof(Real);
-   ensureBuffers(Pl.NSendRows * RowBytes, Pl.NRecvRows * RowBytes);
+   ensureBuffers(Pl.NSendRows * RowBytes, Peer ? 0 : Pl.NRecvRows * RowBytes);
+   if (Peer)
+      OMEGA_REQUIRE(Pl.NRecvRows * RowBytes <= Peer->mailboxBytes(),
+                    "Halo: this exchange receives " + std::to_string(Pl.NRecvRows * RowBytes) +
+                        " bytes, more than the peer wire's mailbox holds: create the wire with Halo::recvRows() * K * 8");
+   char *const RecvBase = static_cast<char *>(Peer ? Peer->mailbox() : RecvBuf->Ptr);
    HaloBases B{};
    for (size_t I = 0; I < Pieces.size(); ++I)
       B.P[I] = Pieces[I].Ptr;
    for (int N = 0; N < NNghbr; ++N) {
       SendPtrs[N] = static_cast<char *>(SendBuf->Ptr) + Pl.SendOff[N];
-      RecvPtrs[N] = static_cast<char *>(RecvBuf->Ptr) + Pl.RecvOff[N];
+      RecvPtrs[N] = RecvBase + Pl.RecvOff[N];
    }
    if (!EvLast)
       HIP_CHECK(hipEventCreateWithFlags(&EvLast, hipEventDisableTiming));
@@ -169,12 +208,16 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
       HIP_CHECK(hipStreamWaitEvent(S, EvLast, 0)); // the shared buffers are free once the previous exchange is done
    // pack: one launch for every neighbour and array (Halo.h:324-414)
    launchHaloPackAll(static_cast<Real *>(SendBuf->Ptr), B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, Pl.Pitch, S);
-   const int Err = Transport(TransportCtx, NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
-                             RecvPtrs.data(), Pl.RecvBytes.data(), (void *)S);
+   const int Err = Peer ? Peer->put(NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
+                                    Pl.RemoteOff.data(), S)
+                        : Transport(TransportCtx, NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
+                                    RecvPtrs.data(), Pl.RecvBytes.data(), (void *)S);
    if (Err != 0)
       return -1;
    // unpack: one launch (Halo.h:566-653)
-   launchHaloUnpackAll(B, static_cast<const Real *>(RecvBuf->Ptr), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, S);
+   launchHaloUnpackAll(B, reinterpret_cast<const Real *>(RecvBase), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, S);
+   if (Peer && Peer->release(NNghbr, NeighborList.data(), S) != 0)
+      return -1;
    HIP_CHECK(hipEventRecord(EvLast, S));
    HaveLast = true;
    return 0;

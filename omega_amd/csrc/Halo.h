@@ -22,6 +22,7 @@
 #include "Base.h"
 #include "Decomp.h"
 
+#include <array>
 #include <map>
 
 namespace OMEGA {
@@ -50,6 +51,12 @@ class Halo : public Registry<Halo> {
    }
    /// production wire: grouped RCCL send / recv on the exchange's stream (the communicator outlives the Halo)
    void useRccl(class RcclComm *Comm);
+   /// the other stream-ordered wire: direct peer copies into the neighbours' mailboxes (PeerWire.h); the mailbox of
+   /// the wire replaces this Halo's receive buffer.  The wire must be connected and outlive the Halo.
+   void usePeerWire(class PeerWire *Wire);
+   /// rows of K values this rank receives in one exchange of NTCell / NTEdge / NTVertex arrays-per-element
+   /// (to size a PeerWire mailbox: bytes = recvRows(...) * K * 8)
+   size_t recvRows(size_t NTCell, size_t NTEdge, size_t NTVertex) const;
    /// Bytes needed per neighbour for exchanging arrays of `TotSizeCell`, `TotSizeEdge`,
    /// `TotSizeVertex` values per element in one message.
    size_t requiredBytes(int INghbr, size_t TotSizeCell, size_t TotSizeEdge, size_t TotSizeVertex) const;
@@ -77,11 +84,16 @@ class Halo : public Registry<Halo> {
       size_t NSendRows = 0, NRecvRows = 0;
       Array1DI4 SendJobs, RecvJobs; ///< [NRows][2] = (piece, row)
       std::vector<size_t> SendOff, RecvOff, SendBytes, RecvBytes; ///< per neighbour, bytes
+      std::vector<size_t> RemoteOff; ///< per neighbour: where my message starts in ITS receive buffer, bytes
    };
    const Plan &planFor(const std::vector<Piece> &Pieces);
    I4 exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S);
    void ensureBuffers(size_t SendBytes, size_t RecvBytes);
 
+   /// [neighbour][kind]: number of the NEIGHBOUR's halo elements of that kind owned by tasks below mine = rows (per
+   /// array-per-element) that precede my message in its receive buffer.  Derived locally, like the lists.
+   std::vector<std::array<size_t, 3>> PeerRecvPrefix;
+   class PeerWire *Peer      = nullptr;
    HaloTransportFn Transport = nullptr;
    void *TransportCtx        = nullptr;
    std::map<std::vector<int>, Plan> Plans; ///< keyed by (Elem, NT, RowsSize, K) of every piece

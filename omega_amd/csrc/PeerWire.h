@@ -1,0 +1,98 @@
+// PeerWire.h -- the second halo wire: direct peer copies between the GPUs of one node (xGMI), stream-ordered end to
+// end, no host synchronisation and no library between the ranks.
+//
+// Reference analogue: the MPI calls inside Halo (components/omega/src/base/Halo.h:851-907 startReceives /
+// startSends + the MPI_Test polling loop).  There every exchange fences the device and the HOST polls for
+// completion.  Here nothing ever waits on the host:
+//
+//   * every rank owns a MAILBOX in device memory (its receive buffer) and a small block of FLAGS, both exported once
+//     with hipIpcGetMemHandle and opened by the peers (one process per GPU; on a one-GPU test box all ranks' memory
+//     is on the same device, which is what lets the multi-rank tests exercise this wire there);
+//   * exchange number s on stream S:  pack kernel -> [wait until every neighbour has consumed my message s-1]
+//     -> one hipMemcpyAsync(device to device) per neighbour straight into ITS mailbox at the offset its unpack
+//     kernel expects (both sides derive the layout from the mesh, Halo.cpp) -> [set "arrived = s" in every
+//     neighbour's flags, wait until all my neighbours' messages s have arrived] -> unpack kernel ->
+//     [set "consumed = s" in every neighbour's flags];
+//   * the bracketed steps are one-wavefront kernels on S: system-scope release stores into the peer's flag block,
+//     acquire loads (with s_sleep) on the local one.  A wait gives up after a fixed time (a peer that died must
+//     not park a wave forever), raises a sticky status the host sees at the next call, and lets the stream drain.
+//
+// Mailbox and flags are allocated uncached (fine grained): a peer's writes arrive through the fabric, not through this
+// GPU's L2, and the unpack kernel must not find stale lines there.
+#ifndef OMEGA_AMD_PEERWIRE_H
+#define OMEGA_AMD_PEERWIRE_H
+
+#include "Base.h"
+
+namespace OMEGA {
+
+class PeerWire {
+ public:
+   static constexpr int MaxPeers    = 32;  ///< neighbours of one rank in one exchange
+   static constexpr int HandleBytes = 160; ///< two hipIpcMemHandle_t (64 B each) + sizes
+
+   /// The calling process must already have selected its GPU (deviceInit).  MailboxBytes: capacity of this rank's
+   /// receive buffer (the largest exchange it will take part in: Halo::recvRows * K * 8).
+   PeerWire(int NRanks, int Rank, size_t MailboxBytes);
+   ~PeerWire();
+   PeerWire(const PeerWire &)            = delete;
+   PeerWire &operator=(const PeerWire &) = delete;
+
+   int NRanks, Rank;
+   I8 NExchanges = 0;
+
+   /// this rank's handle block, to be distributed to every rank by any side channel (once)
+   void localHandle(char Out[HandleBytes]) const;
+   /// All = NRanks * HandleBytes bytes in rank order.  Opens the peers' mailboxes and flag blocks.  Collective in
+   /// the sense that every rank must call it before the first exchange; it does not communicate.
+   void connect(const char *All);
+   bool connected() const { return Connected; }
+
+   void *mailbox() const { return Mailbox; }
+   size_t mailboxBytes() const { return MailboxBytes; }
+
+   /// Steps 2-4 of an exchange (see above) on stream S: message I goes from SendPtrs[I] (SendBytes[I] bytes, local
+   /// device memory, complete in stream order) to Peers[I]'s mailbox at byte offset RemoteOff[I]; returns when the
+   /// work is QUEUED.  After it, in stream order, all neighbours' messages are in the local mailbox.
+   int put(int N, const int *Peers, void *const *SendPtrs, const size_t *SendBytes, const size_t *RemoteOff,
+           hipStream_t S);
+   /// Step 6: the mailbox has been read (unpack kernel queued on S before this call): tell the neighbours.
+   int release(int N, const int *Peers, hipStream_t S);
+
+   /// 0, or the sticky failure raised by a wait kernel that gave up (bit 0: "consumed" wait, bit 1: "arrived" wait)
+   int status() const;
+   const std::string &lastError() const { return LastError; }
+   /// how long a wait kernel spins before it gives up [s] (default 20)
+   void setTimeout(double Seconds);
+
+ private:
+   size_t MailboxBytes;
+   void *Mailbox = nullptr;
+   unsigned long long *Flags = nullptr; ///< [2 * NRanks]: arrived[r], consumed[r] written by rank r
+   int *Status               = nullptr; ///< pinned host word the wait kernels raise
+   bool Connected            = false;
+   long long TimeoutTicks;
+   std::vector<void *> PeerMailbox;               ///< opened mappings, by rank
+   std::vector<unsigned long long *> PeerFlags;
+   std::vector<size_t> PeerMailboxBytes;
+   std::string LastError;
+};
+
+// kernels/PeerKernels.hip
+struct PeerFlagPtrs {
+   unsigned long long *P[PeerWire::MaxPeers];
+   int N;
+};
+struct PeerFlagIdx {
+   int I[PeerWire::MaxPeers];
+   int N;
+};
+/// wait until Local[Idx.I[i]] >= Seq for every i (bounded; raises *Status |= Bit on timeout)
+void launchPeerWait(const unsigned long long *Local, const PeerFlagIdx &Idx, unsigned long long Seq, int *Status, int Bit,
+                    long long TimeoutTicks, hipStream_t S);
+/// *Remote.P[i] = Seq (system-scope release), then optionally wait as above
+void launchPeerSignalWait(const PeerFlagPtrs &Remote, unsigned long long Seq, const unsigned long long *Local,
+                          const PeerFlagIdx &Idx, bool Wait, int *Status, int Bit, long long TimeoutTicks, hipStream_t S);
+
+} // namespace OMEGA
+#endif

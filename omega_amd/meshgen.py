@@ -529,3 +529,183 @@ def pad_max_edges(mesh: dict, max_edges: int) -> dict:
     w[:, : 2 * old] = mesh["weightsOnEdge"]
     out["edgesOnEdge"], out["weightsOnEdge"] = e, w
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# Land boundaries: culled meshes (every real ocean mesh -- QU240, EC30to60, QU30, oRRS18to6 -- is one)
+# ---------------------------------------------------------------------------------------
+def cull(mesh: dict, keep, *, first_cell_valid: bool = True, compact_edges_on_edge: bool = False) -> dict:
+    """Remove the cells with ``keep[c] == False`` and renumber, the way a culled MPAS ocean mesh looks
+    (MPAS-Tools MpasCellCuller; what Omega then reads: components/omega/src/base/Decomp.cpp:553-574
+    missing -> sentinel row, :2043-2064 per-cell edge compaction, :2187-2199 zero EdgesOnEdge entries kept in
+    place; components/omega/src/ocn/HorzMesh.cpp:581-602 EdgeMask = 0 on edges with a missing cell):
+
+    * an edge survives if at least one of its cells does, a vertex if at least one of its cells does;
+    * ``cellsOnCell`` / ``cellsOnEdge`` / ``cellsOnVertex`` / ``edgesOnVertex`` keep their slots, a removed
+      neighbour becomes -1 (0 in the 1-based file convention); every edge and vertex of a surviving cell survives;
+    * ``first_cell_valid`` (the culler's convention): a boundary edge whose first cell was removed has its cells and
+      its vertices exchanged, so the surviving cell comes first and the normal still points from cell 0 outwards;
+      ``angleEdge`` and the ``weightsOnEdge`` entries that involve the edge are flipped with it.  With False the
+      edge keeps [missing, cell] (the pattern a partition's outer rim also produces);
+    * ``edgesOnEdge``: a removed edge leaves a hole IN PLACE (weight kept, it multiplies the zero sentinel row) --
+      or, with ``compact_edges_on_edge``, the surviving entries are moved up and ``nEdgesOnEdge`` reduced.
+
+    Isolated cells, one-cell-wide straits and lakes are all legal results.  Adds ``boundaryEdge`` (0/1) and
+    ``cullCellMap`` (old index of every new cell)."""
+    keep = np.asarray(keep, dtype=bool)
+    nC, nE, nV = mesh["nCells"], mesh["nEdges"], mesh["nVertices"]
+    assert keep.shape == (nC,) and keep.any()
+
+    def mapping(kept):
+        m = np.full(len(kept) + 1, -1, dtype=np.int64)      # index -1 (missing) -> -1
+        m[:-1][kept] = np.arange(int(kept.sum()))
+        return m
+
+    cmap = mapping(keep)
+    coe_old = mesh["cellsOnEdge"].astype(np.int64)
+    cov_old = mesh["cellsOnVertex"].astype(np.int64)
+    ekeep = (cmap[coe_old] >= 0).any(axis=1)
+    vkeep = (cmap[cov_old] >= 0).any(axis=1)
+    emap, vmap = mapping(ekeep), mapping(vkeep)
+    kept = {"Cell": keep, "Edge": ekeep, "Vertex": vkeep}
+    maps = {"Cell": cmap, "Edge": emap, "Vertex": vmap}
+
+    owner = {"nEdgesOnCell": "Cell", "cellsOnCell": "Cell", "edgesOnCell": "Cell", "verticesOnCell": "Cell",
+             "areaCell": "Cell", "fCell": "Cell", "bottomDepth": "Cell", "cellsOnEdge": "Edge",
+             "verticesOnEdge": "Edge", "edgesOnEdge": "Edge", "weightsOnEdge": "Edge", "nEdgesOnEdge": "Edge",
+             "angleEdge": "Edge", "dcEdge": "Edge", "dvEdge": "Edge", "fEdge": "Edge", "cellsOnVertex": "Vertex",
+             "edgesOnVertex": "Vertex", "kiteAreasOnVertex": "Vertex", "areaTriangle": "Vertex", "fVertex": "Vertex"}
+    for el in ("Cell", "Edge", "Vertex"):
+        for pre in ("x", "y", "z", "lon", "lat"):
+            owner[pre + el] = el
+    target = {"cellsOnCell": "Cell", "edgesOnCell": "Edge", "verticesOnCell": "Vertex", "cellsOnEdge": "Cell",
+              "verticesOnEdge": "Vertex", "edgesOnEdge": "Edge", "cellsOnVertex": "Cell", "edgesOnVertex": "Edge"}
+    out = {k: v for k, v in mesh.items() if k not in owner}
+    for name, own in owner.items():
+        if name not in mesh:
+            continue
+        a = mesh[name][kept[own]]
+        if name in target:
+            a = maps[target[name]][a.astype(np.int64)].astype(I4)
+        out[name] = np.ascontiguousarray(a)
+    out["nCells"], out["nEdges"], out["nVertices"] = int(keep.sum()), int(ekeep.sum()), int(vkeep.sum())
+    out["cullCellMap"] = np.nonzero(keep)[0].astype(I4)
+    # every edge / vertex of a surviving cell survives
+    n = out["nEdgesOnCell"]
+    live = np.arange(mesh["maxEdges"])[None, :] < n[:, None]
+    assert (out["edgesOnCell"][live] >= 0).all() and (out["verticesOnCell"][live] >= 0).all()
+
+    coe = out["cellsOnEdge"]
+    out["boundaryEdge"] = (coe < 0).any(axis=1).astype(I4)
+    if first_cell_valid:
+        flip = np.nonzero(coe[:, 0] < 0)[0]
+        coe[flip] = coe[flip][:, ::-1]
+        out["verticesOnEdge"][flip] = out["verticesOnEdge"][flip][:, ::-1]
+        ang = out["angleEdge"]
+        ang[flip] = np.where(ang[flip] > 0, ang[flip] - np.pi, ang[flip] + np.pi)
+        # u_e -> -u_e on the flipped edges: row e (tangent k x n flips) and every entry that refers to e
+        sgn = np.ones(out["nEdges"] + 1)
+        sgn[flip] = -1.0
+        w = out["weightsOnEdge"]
+        w *= sgn[:-1, None]
+        w *= sgn[out["edgesOnEdge"].astype(np.int64)]        # holes (-1) pick the trailing +1
+    if compact_edges_on_edge:
+        eoe, w = out["edgesOnEdge"], out["weightsOnEdge"]
+        order = np.argsort(eoe < 0, axis=1, kind="stable")   # surviving entries first, original order
+        out["edgesOnEdge"] = np.take_along_axis(eoe, order, axis=1)
+        w = np.take_along_axis(w, order, axis=1)
+        out["nEdgesOnEdge"] = (out["edgesOnEdge"] >= 0).sum(axis=1).astype(I4)
+        w[out["edgesOnEdge"] < 0] = 0.0
+        out["weightsOnEdge"] = w
+    return out
+
+
+def coast_mask(mesh: dict, kind: str, seed: int = 5) -> np.ndarray:
+    """``keep`` masks for :func:`cull`: land shapes that produce every coastal pattern the kernels have to cope with.
+
+    ``island``   a disc of land (and a second, single-cell island);
+    ``channel``  planar: two rows of land (walls of a zonal channel); sphere: land poleward of 60 degrees;
+    ``strait``   a wall with a one-cell-wide gap in it, plus a wall one cell away from it (a one-cell-wide channel);
+    ``lakes``    a land mass holding a one-cell lake, a two-cell lake and a bay one cell wide;
+    ``ragged``   random land cells, 18 % of the mesh (isolated cells, diagonal contacts, every vertex pattern);
+    ``mixed``    island + ragged patches: the default for parity tests;
+    ``continents`` a smooth random field thresholded at 28 % land plus a sprinkle of one-cell islands: the shape of a
+                 real ocean mesh (bench.py's culled workloads)."""
+    nC = mesh["nCells"]
+    if mesh.get("on_a_sphere", False):
+        R = mesh["sphere_radius"]
+        p = np.stack([mesh["xCell"], mesh["yCell"], mesh["zCell"]], axis=1) / R
+
+        def dist(q):                                   # great-circle distance / mean cell spacing
+            q = np.asarray(q, dtype=np.float64)
+            q /= np.linalg.norm(q)
+            return np.arccos(np.clip(p @ q, -1, 1)) / np.sqrt(4 * np.pi / nC)
+        d1, d2, d3 = dist([1, 0.2, 0.3]), dist([-0.5, 1, -0.2]), dist([0, -1, 0.1])
+        lat = mesh["latCell"]
+        polar = np.abs(lat) > np.pi / 3
+        lon = mesh["lonCell"]
+        wall = (np.abs(lon - np.pi) < 1.2 * np.sqrt(4 * np.pi / nC)) & (np.abs(lat) < 1.0)
+        gap = wall & (np.abs(lat - 0.2) < 0.6 * np.sqrt(4 * np.pi / nC))
+    else:
+        dc = mesh["dc"]
+        x, y = mesh["xCell"] / dc, mesh["yCell"] / (dc * np.sqrt(3.0) / 2.0)
+        nx, ny = mesh["x_period"] / dc, mesh["y_period"] / (dc * np.sqrt(3.0) / 2.0)
+
+        def dist(q):
+            dx = np.abs(x - q[0] * nx)
+            dy = np.abs(y - q[1] * ny)
+            dx, dy = np.minimum(dx, nx - dx), np.minimum(dy, ny - dy) * np.sqrt(3.0) / 2.0
+            return np.hypot(dx, dy)
+        d1, d2, d3 = dist([0.3, 0.35]), dist([0.7, 0.6]), dist([0.55, 0.15])
+        row = np.rint(y).astype(np.int64)
+        polar = (row % int(ny) == 1) | (row % int(ny) == int(ny) // 2 + 1)
+        col = np.rint(x - 0.25).astype(np.int64)
+        wall = col == int(nx) // 2
+        gap = wall & (row == int(ny) // 3)
+    rng = np.random.default_rng(seed)
+    rnd = rng.random(nC)
+    rad = max(2.0, 0.12 * np.sqrt(nC))
+    if kind == "continents":
+        f = np.zeros(nC)
+        for _ in range(12):
+            if mesh.get("on_a_sphere", False):
+                q = rng.normal(size=3)
+                q /= np.linalg.norm(q)
+                f += rng.uniform(0.5, 1.0) * np.cos(rng.integers(1, 5) * np.arccos(np.clip(p @ q, -1, 1)) + rng.uniform(0, 6.3))
+            else:
+                kx, ky = rng.integers(-3, 4), rng.integers(-3, 4)
+                f += rng.uniform(0.5, 1.0) * np.cos(2 * np.pi * (kx * x / nx + ky * y / ny) + rng.uniform(0, 6.3))
+        land = (f > np.quantile(f, 0.72)) | (rnd < 0.002)
+        keep = ~land
+        return keep
+    if kind == "island":
+        land = (d1 < rad) | (d2 < 0.6)
+    elif kind == "channel":
+        land = polar
+    elif kind == "strait":
+        wall2 = np.roll(wall, 2) if not mesh.get("on_a_sphere", False) else (d3 < 1.5)
+        land = (wall & ~gap) | wall2
+    elif kind == "lakes":
+        land = d1 < 1.6 * rad
+        order = np.argsort(d1)
+        land[order[0]] = False                                   # one-cell lake at the centre
+        ring = order[(d1[order] > 0.5 * rad) & (d1[order] < 0.5 * rad + 1.2)]
+        land[ring[:2]] = False                                   # a two-cell lake (or two single ones)
+        land[(d2 < rad) & (rnd < 0.5)] = True                    # a porous land mass: bays and channels one cell wide
+    elif kind == "ragged":
+        land = rnd < 0.18
+    elif kind == "mixed":
+        land = (d1 < rad) | (d2 < 0.6) | ((d3 < 1.5 * rad) & (rnd < 0.3))
+    else:
+        raise ValueError(kind)
+    keep = ~land
+    assert keep.any()
+    return keep
+
+
+def zero_boundary_velocity(mesh: dict, u: np.ndarray) -> np.ndarray:
+    """No-normal-flow condition on the coast (what an ocean initial state satisfies): u = 0 on boundary edges."""
+    if "boundaryEdge" in mesh:
+        u = u.copy()
+        u[mesh["boundaryEdge"] != 0] = 0.0
+    return u

@@ -42,7 +42,8 @@ def main():
                     help="0 = owned elements must equal the single-rank run bit for bit; > 0 = the partitioned run may "
                          "deviate by at most this (relative to the field's max), and MUST deviate (the setting is known "
                          "not to be partition independent: HaloWidth 3 with the radius-2 del4 terms)")
-    ap.add_argument("--mesh", default="hex", help="hex (planar nx x ny) | icoN (icosahedral level N) | fibN (N cells)")
+    ap.add_argument("--mesh", default="hex", help="hex (planar nx x ny) | any name of tests/meshes.py: icoN, fibN, "
+                                                  "hexNXxNY, <base>_coast_<kind>[_raw][_compact], <base>_pad8")
     a = ap.parse_args()
 
     import torch
@@ -51,16 +52,12 @@ def main():
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
 
     import omega_amd as oa
-    from omega_amd.meshgen import planar_hex, synthetic_state, spherical_voronoi, icosahedral_points
+    from omega_amd.meshgen import planar_hex, synthetic_state
     from oracle import oracle as O
     from tests.problem import Problem
+    from tests.meshes import named_mesh
 
-    if a.mesh == "hex":
-        g = planar_hex(a.nx, a.ny, 30.0e3)
-    elif a.mesh.startswith("ico"):
-        g = spherical_voronoi(points=icosahedral_points(int(a.mesh[3:])), lloyd=2)
-    else:
-        g = spherical_voronoi(int(a.mesh[3:]), lloyd=4)
+    g = planar_hex(a.nx, a.ny, 30.0e3) if a.mesh == "hex" else named_mesh(a.mesh)
     K, NT, dt = a.levels, a.tracers, (5.0 if a.mesh.startswith("fib") else 600.0)   # (fib: a few very short edges)
     gpu = a.mode == "gpu"
     if gpu:
@@ -139,7 +136,7 @@ def main():
             # the overlapped path splits the last kernels of a stage into a band and an interior launch:
             # make sure this mesh has both, or the test would not exercise it
             nb, ni = P.mesh.get_int("NBandCells"), P.mesh.get_int("NInteriorCells")
-            assert nb > 0 and (ni > 0 or a.nx * a.ny <= 24 * 24), (nb, ni)
+            assert nb > 0 and (ni > 0 or g["nCells"] <= 24 * 24), (nb, ni)
         user_stream = oa.Stream() if a.user_stream else None   # hipStreamNonBlocking: no implicit ordering with stream 0
         for _ in range(a.steps):
             st.do_step(P.state, stream=user_stream)

@@ -35,6 +35,11 @@ pytestmark = pytest.mark.gpu
     ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 20],     # 20 levels: device rows padded to 32 (pack / unpack with a pitch)
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream"],               # non-blocking user stream,
     ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream", "--no-overlap"],  # overlapped and sequential
+    # partition lines crossing a coast (culled meshes): band / interior lists, irregular-edge list, masked boundary edges
+    ["--halo-width", 4, "--mesh", "hex48x24_coast_mixed", "--levels", 6, "--partition", "graph", "--local-order", "curve"],
+    ["--halo-width", 4, "--mesh", "hex64x16_coast_strait_raw", "--levels", 4, "--no-overlap"],
+    ["--halo-width", 4, "--mesh", "ico4_coast_lakes", "--levels", 6, "--partition", "graph", "--local-order", "curve"],
+    ["--no-del4", "--mesh", "fib1500_coast_ragged", "--levels", 4, "--stepper", "Forward-Backward"],
 ])
 def test_two_ranks_one_gpu(extra):
     outs = run_ranks("gpu", 2, extra, timeout=900)
@@ -67,7 +72,7 @@ def test_generic_fallback_kernels_in_a_child_process():
     is like that, so OMEGA_FORCE_GENERIC=1 clears the ring-table flags and the parity tests run again."""
     env = dict(os.environ, OMEGA_FORCE_GENERIC="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
-                        "(compute_all_tendencies and fused and (K80 or K4_ or K5 or ico3)) or time_steppers or generic_flags"],
+                        "(compute_all_tendencies and fused and (K80 or K4_ or K5 or ico3 or coast)) or time_steppers or generic_flags"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
@@ -100,7 +105,7 @@ def test_unmerged_unpaired_kernel_structure_in_a_child_process():
     tables fall back to) must still equal the oracle."""
     env = dict(os.environ, OMEGA_MERGE_L1="0", OMEGA_PAIR="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
-                        "(compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500)) or time_steppers or rk4_on_the_sphere"],
+                        "(compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500 or coast)) or time_steppers or rk4_on_the_sphere"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
@@ -112,7 +117,7 @@ def test_paired_level3_launch_for_the_plain_rhs_in_a_child_process():
     (default: both in one thread, CellPVFinalTracerBody); same bits required."""
     env = dict(os.environ, OMEGA_FUSE_L3="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
-                        "compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500)"],
+                        "compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500 or coast)"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]

@@ -61,25 +61,24 @@ CASES = [
     ("ico3", 0, 0, 6, 1, {"WindForcingTendencyEnable": 1, "WindInterpIsotropic": 1}),   # same, on the sphere
     (20, 24, 30e3, 80, 37, {}),                                # BASELINE configs[4]: 80 levels, 37 BGC tracers
     ("ico3", 0, 0, 80, 37, {}),                                # 37 tracers with the pentagon ring launches
+    # land boundaries (culled meshes, as every real ocean mesh is: omega_amd/meshgen.py cull / coast_mask)
+    ("hex32x24_coast_mixed", 0, 0, 8, 2, {}),                  # island + single-cell island + ragged patch
+    ("hex24x20_coast_lakes", 0, 0, 6, 2, {}),                  # one- and two-cell lakes, one-cell-wide bays
+    ("hex24x20_coast_strait", 0, 0, 80, 6, {}),                # walls with a one-cell gap, a one-cell-wide channel
+    ("hex24x20_coast_ragged_raw", 0, 0, 5, 1, {}),             # random land; boundary edges keep [missing, cell]; odd K
+    ("hex20x16_coast_channel_compact", 0, 0, 60, 2, {"FluxThicknessUpwind": 1, "FluxTracerUpwind": 1}),
+    ("ico4_coast_mixed", 0, 0, 12, 2, {}),                     # sphere with pentagons on and off the coast
+    ("fib1500_coast_ragged", 0, 0, 10, 2, {}),                 # 7-wide tables, hexagons dominant, random land
+    ("ico3_pad8_coast_island_raw_compact", 0, 0, 6, 1, {}),    # stored with maxEdges = 8
+    ("hex24x20_coast_mixed", 0, 0, 8, 2, {"WindForcingTendencyEnable": 1, "BottomDragTendencyEnable": 1,
+                                          "BottomDragCoeff": 1.0e-3, "WindInterpIsotropic": 1}),
 ]
 
-_SPHERES = {}
-
-
 def sphere(name):
-    """Spherical test meshes, generated once per session."""
-    if name not in _SPHERES:
-        if name.startswith("fib") and int(name[3:]) < 1000:
-            _SPHERES[name] = spherical_voronoi(int(name[3:]), lloyd=4)
-        elif name == "ico3pad8":
-            _SPHERES[name] = pad_max_edges(sphere("ico3"), 8)
-        elif name == "hex24pad8":
-            _SPHERES[name] = pad_max_edges(planar_hex(24, 20, 30e3), 8)
-        elif name.startswith("ico"):
-            _SPHERES[name] = spherical_voronoi(points=icosahedral_points(int(name[3:])), lloyd=2)
-        else:
-            _SPHERES[name] = spherical_voronoi(int(name[3:]), lloyd=4)
-    return _SPHERES[name]
+    """Named test meshes (tests/meshes.py), generated once per session."""
+    from tests.meshes import named_mesh
+    alias = {"ico3pad8": "ico3_pad8", "hex24pad8": "hex24x20_pad8"}
+    return named_mesh(alias.get(name, name))
 
 
 def _mk(case):
