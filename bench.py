@@ -116,9 +116,16 @@ def main():
                     help="N > 1: exchange halos after the producing stage instead of overlapped with its interior part")
     ap.add_argument("--no-fuse-stages", action="store_true",
                     help="RK4 with the separate update kernels instead of stage updates folded into the RHS kernels")
-    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
-                    help="rccl (= nccl) = RCCL send/recv over xGMI issued inside the library (production); "
-                         "gloo = host-staged rehearsal of the N>1 code path")
+    ap.add_argument("--backend", default="auto", choices=["auto", "rccl", "nccl", "peer", "gloo"],
+                    help="halo wire for N > 1.  rccl (= nccl): RCCL send/recv over xGMI issued inside the library; STRICT -- "
+                         "if the communicator cannot be created the RHS record is printed with rk4.error set and the run "
+                         "exits non-zero.  peer: the library's direct peer-copy wire (HIP IPC mailboxes + flag kernels, "
+                         "PeerWire.h), equally stream-ordered and device-to-device.  auto (default): rccl, and if RCCL cannot "
+                         "be initialised on every rank, peer -- never a host-staged wire; config.halo_wire names what ran and "
+                         "why.  gloo: host-staged rehearsal of the N>1 code path (needs --allow-host-staged)")
+    ap.add_argument("--allow-host-staged", action="store_true",
+                    help="permit --backend gloo: messages staged through host memory (a correctness rig, not a measurement "
+                         "of the halo wire)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--halo-width", type=int, default=0,
                     help="0 = 4 for N > 1 (partition-independent results with the del4 terms: two RHS evaluations per "
@@ -157,7 +164,10 @@ def main():
         if args.single_device:
             local_rank = 0
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the side channel stays on the loopback device
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+    if N == 1 and rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as O   # the checker's -O3 -march=native build: compiled (a child `make`) before this
+        O.use_native_build()             # process touches the GPU
     oa.device_init(local_rank)
     halo_width = args.halo_width if args.halo_width > 0 else (4 if N > 1 else 3)
 
@@ -204,34 +214,9 @@ def main():
     comm = None
     wire_note = None
     stream = oa.Stream()
-    if N > 1 and args.backend == "rccl":
-        # The communicator is created by all ranks or used by none: a rank whose ncclCommInitRank fails (raises)
-        # reports it over the side channel and every rank takes the host-staged wire instead -- the record then says
-        # so (config.halo_wire), so that a measurement exists and cannot be mistaken for the RCCL one.
-        err = ""
-        try:
-            ident = [oa.RcclComm.unique_id() if rank == 0 else None]
-        except Exception as exc:  # noqa: BLE001
-            ident, err = [None], f"rank {rank}: {exc}"
-        dist.broadcast_object_list(ident, src=0)
-        if ident[0] is not None:
-            try:
-                comm = oa.RcclComm(ident[0], N, rank)     # collective: ncclCommInitRank
-            except Exception as exc:  # noqa: BLE001
-                comm, err = None, f"rank {rank}: {exc}"
-        errs = [None] * N
-        dist.all_gather_object(errs, err)
-        if any(errs):
-            comm = None
-            wire_note = "host-staged gloo, because RCCL could not be initialised: " + "; ".join(e for e in errs if e)[:300]
-            print("[bench] " + wire_note, file=sys.stderr, flush=True)
-            from omega_amd.transport import GlooStagedTransport
-            GlooStagedTransport(halo)
-        else:
-            halo.use_rccl(comm)
-    elif N > 1:  # gloo rehearsal: host-staged messages (both ranks may share one GPU)
-        from omega_amd.transport import GlooStagedTransport
-        GlooStagedTransport(halo)
+    if N > 1 and args.backend == "gloo" and not args.allow_host_staged:
+        raise SystemExit("--backend gloo stages every halo message through host memory; pass --allow-host-staged to "
+                         "run it as a rehearsal of the N > 1 code path")
 
     cfg = oa.default_config()
     state = oa.OceanState(mesh, halo, K, 2)
@@ -285,9 +270,88 @@ def main():
     cell_levels = n_cells_global * K
     value = cell_levels / (wall_rhs / args.steps)
 
+    # ------------------------------------------------ the halo wire (N > 1): needed by the stepping part only
+    wire = None
+    wire_errors = None
+
+    def gather_errors(err):
+        errs = [None] * N
+        dist.all_gather_object(errs, err)
+        return [e for e in errs if e]
+
+    def setup_rccl():
+        """All ranks get a communicator, or none keeps one.  Returns the list of error strings (empty = success)."""
+        nonlocal comm
+        err = ""
+        try:
+            ident = [oa.RcclComm.unique_id() if rank == 0 else None]
+        except Exception as exc:  # noqa: BLE001
+            ident, err = [None], f"rank {rank}: ncclGetUniqueId: {exc}"
+        dist.broadcast_object_list(ident, src=0)
+        if ident[0] is not None:
+            try:
+                comm = oa.RcclComm(ident[0], N, rank)     # collective: ncclCommInitRank
+            except Exception as exc:  # noqa: BLE001
+                comm, err = None, f"rank {rank}: ncclCommInitRank: {exc}"
+        errs = gather_errors(err)
+        if errs and comm is not None:
+            comm.abort()          # a communicator some ranks do not have must never carry traffic
+            comm = None
+        return errs
+
+    def setup_peer():
+        nonlocal wire
+        err = ""
+        try:
+            rows = max(halo.recv_rows(1 + NT, 1, 0), 1)
+            wire = oa.PeerWire(N, rank, rows * K * 8)
+            handle = wire.handle()
+        except Exception as exc:  # noqa: BLE001
+            wire, handle, err = None, None, f"rank {rank}: PeerWire: {exc}"
+        handles = [None] * N
+        dist.all_gather_object(handles, handle)
+        if err == "" and all(h is not None for h in handles):
+            try:
+                wire.connect(handles)
+            except Exception as exc:  # noqa: BLE001
+                err = f"rank {rank}: PeerWire.connect: {exc}"
+        errs = gather_errors(err)
+        if errs:
+            wire = None
+        return errs
+
+    if N > 1:
+        if args.backend in ("rccl", "auto"):
+            wire_errors = setup_rccl()
+            if not wire_errors:
+                halo.use_rccl(comm)
+            elif args.backend == "auto":
+                rccl_errors = wire_errors
+                wire_errors = setup_peer()
+                if not wire_errors:
+                    halo.use_peer(wire)
+                    wire_note = ("peer copies (HIP IPC mailboxes + flag kernels inside libomega_amd, PeerWire.h); RCCL was "
+                                 "tried first and could not be initialised: " + "; ".join(rccl_errors)[:300])
+                else:
+                    wire_errors = rccl_errors + wire_errors
+        elif args.backend == "peer":
+            wire_errors = setup_peer()
+            if not wire_errors:
+                halo.use_peer(wire)
+                wire_note = "peer copies (HIP IPC mailboxes + flag kernels inside libomega_amd, PeerWire.h)"
+        else:  # gloo rehearsal (opt-in above): host-staged messages, ranks may share one GPU
+            from omega_amd.transport import GlooStagedTransport
+            GlooStagedTransport(halo)
+            wire_note = "host-staged gloo (rehearsal, --allow-host-staged)"
+        if wire_errors and rank == 0:
+            print("[bench] no halo wire: " + "; ".join(wire_errors), file=sys.stderr, flush=True)
+
     # ------------------------------------------------ RK4 steps (SYPD)
     nrk = args.rk4_steps if args.rk4_steps >= 0 else max(2, args.steps // 4)
     sypd = t_rk4 = rk4_error = None
+    if wire_errors:     # strict: no wire, no stepping part; the RHS record stands and the run exits non-zero
+        rk4_error = "no halo wire could be initialised: " + "; ".join(wire_errors)[:600]
+        nrk = 0
     overlap = N > 1 and not (args.no_overlap or args.no_fuse_stages or args.unfused)
     if nrk > 0:
         if rank == 0:   # if a rank dies in the stepping part, the RHS measurement is at least in the log
@@ -314,8 +378,14 @@ def main():
             rk4_error = f"rank {rank}: {type(exc).__name__}: {exc}"
             sypd = t_rk4 = None
             print(f"[bench] RK4 FAILED on {rk4_error}", file=sys.stderr, flush=True)
-            if N > 1 and rank != 0:
-                os._exit(3)   # the launcher tears the job down; peers must not wait for this rank
+        if N > 1:
+            # the verdict is collective: every rank learns whether ANY rank failed, so that either all of them enter
+            # the cross-check below or none does, and rank 0 prints the record before anybody leaves.  (A rank stuck
+            # in a GPU wait because its peer died never gets here: the side channel's time limit ends the job.)
+            all_errs = gather_errors(rk4_error)
+            if all_errs and rk4_error is None:
+                rk4_error = "; ".join(all_errs)[:600]
+                sypd = t_rk4 = None
 
     # ------------------------------------------------ N > 1: the overlapped exchange against the sequential one
     # The one-GPU development boxes can only run the exchange logic over a host-staged wire, which synchronises the
@@ -324,6 +394,7 @@ def main():
     # and the tracers over owned elements, combined in rank order).
     overlap_check = None
     if N > 1 and nrk > 0 and rk4_error is None and overlap:
+        check_err = None
         try:
             ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
 
@@ -349,9 +420,12 @@ def main():
                 rk4_error = "overlapped and sequential halo exchanges give different states (see rk4.overlap_check)"
                 sypd = None
         except Exception as exc:  # noqa: BLE001
-            overlap_check = {"error": f"rank {rank}: {type(exc).__name__}: {exc}"}
-            if rank != 0:
-                os._exit(3)
+            check_err = f"rank {rank}: {type(exc).__name__}: {exc}"
+        check_errs = gather_errors(check_err)
+        if check_errs:
+            overlap_check = {"error": "; ".join(check_errs)[:600]}
+            rk4_error = "the overlapped-vs-sequential cross-check failed (see rk4.overlap_check)"
+            sypd = None
 
     # ------------------------------------------------ roofline of the dominant kernel (rank 0's view)
     roofline = None
@@ -423,7 +497,8 @@ def main():
                           "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else
                           ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
-                           (wire_note or "host-staged gloo (rehearsal)")),
+                           ((wire_note + (" " + json.dumps(wire.info()) if wire else "")) if wire_note else
+                            "none: " + "; ".join(wire_errors or ["?"])[:300])),
                           "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
                                                    "row-major" if args.block == 1 else f"blocked{args.block}")
                                         + ", local numbering by Decomp: " + args.local_order,
@@ -440,7 +515,10 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if N > 1:
-        dist.barrier()
+        oa.device_synchronize()
+        dist.barrier()      # every rank's GPU work is complete: the wires may be taken down
+        if wire is not None:
+            wire.close()
         dist.destroy_process_group()
     if N > 1 and rk4_error:
         sys.exit(3)   # the RHS record above stands; the stepping part failed and says so in rk4.error
@@ -450,8 +528,7 @@ def cpu_baseline(nx, ny, K, NT, dc, dt):
     """The CPU oracle (kind "port": restatement of the reference functors with the reference's launch structure,
     OpenMP over elements, built -O3 -march=native on this host) timed on the SAME mesh and state as the GPU run:
     a few RHS evaluations and one RK4 step (bounded to about 20-30 s of CPU work)."""
-    from oracle import oracle as O
-    O.use_native_build()
+    from oracle import oracle as O       # (native build selected at the top of main)
     budget_cells = 500_000 * 80 * (8 + 2 * 6)      # about the QU30 workload: larger ones are sampled
     scale = 1
     while (nx // scale) * (ny // scale) * K * (8 + 2 * NT) > budget_cells:
@@ -471,27 +548,41 @@ def cpu_baseline(nx, ny, K, NT, dc, dt):
     cores = O.default_threads()
     O.lib().orc_set_num_threads(cores)
     orc = O.Oracle(M, NT)
-    orc.compute_all_tendencies(hs, us, trs)  # warm-up (first touch of every aux array)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    for _ in range(2):   # warm-ups (first touch of every aux array): SURVEY 8(d) asks for 2
         orc.compute_all_tendencies(hs, us, trs)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or n >= 20:
+    # median of >= 10 RHS evaluations, bounded to about 16 s of CPU work
+    times = []
+    t0 = time.perf_counter()
+    while len(times) < 10 or (len(times) < 20 and time.perf_counter() - t0 < 10.0):
+        ta = time.perf_counter()
+        orc.compute_all_tendencies(hs, us, trs)
+        times.append(time.perf_counter() - ta)
+        if time.perf_counter() - t0 > 16.0 and len(times) >= 5:
             break
-    v = gs["nCells"] * K * n / el
+    n = len(times)
+    v = gs["nCells"] * K / float(np.median(times))
+    # RK4: >= 3 steps when they fit into about 20 s, at least 1
     st = orc.make_state(hs, us, trs)
+    steps = []
     t1 = time.perf_counter()
-    orc.step("rk4", st, dt)
-    el2 = time.perf_counter() - t1
+    while len(steps) < 3 and (not steps or time.perf_counter() - t1 + steps[-1] < 22.0):
+        ta = time.perf_counter()
+        orc.step("rk4", st, dt)
+        steps.append(time.perf_counter() - ta)
+    el2 = float(np.median(steps))
     ratio = (nx * ny) / gs["nCells"]
     sypd_cpu = (dt / (el2 * ratio)) / 365.0
     frac = "the full workload mesh" if scale == 1 else f"a 1/{scale * scale}-size mesh of the same shape"
-    return {"value": v, "unit": "cell-level-updates/s", "cores": cores,
-            "kind": "port" if scale == 1 else f"port, 1/{scale * scale} sample", "sypd": sypd_cpu, "rk4_steps": 1,
+    hc = O.host_cores()
+    return {"value": v, "unit": "cell-level-updates/s", "cores": cores, "threads_used": cores,
+            "cores_available": hc["cores_available"], "host": hc,
+            "kind": "port" if scale == 1 else f"port, 1/{scale * scale} sample", "sypd": sypd_cpu, "rk4_steps": len(steps),
+            "rhs_evaluations": n, "rhs_ms_median": 1e3 * float(np.median(times)), "rk4_ms_median": 1e3 * el2,
             "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp (oracle/Makefile: native)",
-            "sample": f"{n} RHS evaluations and 1 RK4 step on {frac} ({nxs}x{nys} = {gs['nCells']} cells x {K}L x "
-                      f"{NT} tracers), reference launch structure (23 passes), OpenMP threads = cores"
+            "sample": f"median of {n} RHS evaluations after 2 warm-ups and of {len(steps)} RK4 step(s) on {frac} ({nxs}x{nys} = "
+                      f"{gs['nCells']} cells x {K}L x {NT} tracers), reference launch structure (23 passes), "
+                      f"{cores} OpenMP threads (cap OMEGA_ORACLE_THREADS, default 16 = the one-GPU box's CPU share; the "
+                      f"process may use {hc['cores_available']} of the host's {hc['logical_cpus']} logical CPUs)"
                       + ("" if scale == 1 else f"; sypd scaled by the cell ratio {ratio:.0f}")}
 
 

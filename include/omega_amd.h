@@ -194,6 +194,9 @@ typedef struct omg_rccl omg_rccl;
 int omg_rccl_get_unique_id(char *id /* [OMG_RCCL_ID_BYTES] */);
 int omg_rccl_create(const char *id, int nranks, int rank, omg_rccl **out);
 int omg_rccl_destroy(omg_rccl *c);
+/* ncclCommAbort: give up a communicator (after an error, or when another rank could not create its own); every
+ * later exchange on it fails.  An error inside an exchange aborts the communicator by itself. */
+int omg_rccl_abort(omg_rccl *c);
 /* what RCCL itself reports: communicator size, this rank, library version code, grouped exchanges issued so far */
 int omg_rccl_info(const omg_rccl *c, int *nranks, int *rank, int *version, int64_t *exchanges);
 /* one grouped exchange on raw device buffers (same argument meaning as omg_transport_fn; byte counts multiples of 8) */
@@ -201,10 +204,41 @@ int omg_rccl_exchange(omg_rccl *c, int n, const int *peers, void *const *send_pt
                       void *const *recv_ptrs, const size_t *recv_bytes, void *stream);
 /* route this Halo's exchanges through the communicator (which must outlive the Halo's exchanges) */
 int omg_halo_use_rccl(omg_halo *h, omg_rccl *c);
+/* The second stream-ordered wire: direct peer copies between the GPUs of the node (PeerWire.h).  Every rank owns a
+ * mailbox (its receive buffer) and a block of flags in device memory, exported once with hipIpcGetMemHandle; an exchange
+ * is pack kernel -> hipMemcpyAsync device-to-device into each neighbour's mailbox -> flag kernels (release store into
+ * the peer's flags, bounded acquire wait on the local ones) -> unpack kernel, all on the exchange's stream: what the
+ * MPI_Irecv / MPI_Isend / MPI_Test loop of O/src/base/Halo.h:851-907 becomes without any host wait.
+ * omg_peer_create after omg_device_init; distribute the OMG_PEER_HANDLE_BYTES of omg_peer_local_handle to all ranks
+ * by any side channel, pass all of them in rank order to omg_peer_connect, then omg_halo_use_peer.
+ * mailbox_bytes >= omg_halo_recv_rows(...) * k * 8 of the largest exchange. */
+enum { OMG_PEER_HANDLE_BYTES = 160 };
+typedef struct omg_peer omg_peer;
+int omg_peer_create(int nranks, int rank, size_t mailbox_bytes, omg_peer **out);
+int omg_peer_destroy(omg_peer *p);
+int omg_peer_local_handle(const omg_peer *p, char *out /* [OMG_PEER_HANDLE_BYTES] */);
+int omg_peer_connect(omg_peer *p, const char *all_handles /* [nranks][OMG_PEER_HANDLE_BYTES] */);
+/* exchanges issued so far; sticky status (0 = fine, else a wait on a peer gave up); wait bound in seconds */
+int omg_peer_info(const omg_peer *p, int64_t *exchanges, int *status);
+int omg_peer_set_timeout(omg_peer *p, double seconds);
+int omg_halo_use_peer(omg_halo *h, omg_peer *p);
+/* rows of k values this rank receives in one exchange of per_cell / per_edge / per_vertex arrays per element */
+int omg_halo_recv_rows(const omg_halo *h, size_t per_cell, size_t per_edge, size_t per_vertex, size_t *rows);
 /* Halo::exchangeFullArrayHalo on a raw device array [nt][rows_size][row_pitch] (nt = 1 for 2-D) of which the first
  * k values of every row are exchanged (row_pitch 0 = compact rows of k) */
 int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
                       void *stream);
+
+/* ---- Measurement / test options (omega_amd/csrc/Tuning.h).  The library never reads the environment: every switch that
+ *      changes the kernel structure or the tile geometry is set through this call.  Defaults are what production
+ *      runs.  Names: W TX TY Sweeps ChunkSplit TailSplit (tile geometry); EdgeMode FuseFinal MergeL1 Pair FuseL3
+ *      (structure of the fused RHS; read at every launch); ForceGeneric KeepMaxEdges DomValence (mesh tables; read when
+ *      a HorzMesh is created); Graphs (-1 per object, 0 never, 1 default on).  Unknown names fail.
+ *      omg_set_timing_level: roctx ranges named after the reference's Pacer timers ("Tend:...", "AuxState:...",
+ *      "RK4:haloExch"; share/pacer/Pacer.cpp:138-200) are emitted for timers up to this level (default 3 = all). ---- */
+int omg_set_option(const char *name, int value);
+int omg_get_option(const char *name, int *value);
+int omg_set_timing_level(int level);
 
 /* ---- HorzMesh (O/src/ocn/HorzMesh.cpp:44-140 constructor; HorzMesh.h:100-265 members).
  *      host_only != 0 builds the host arrays only (no device mirrors; compute calls fail). ---- */

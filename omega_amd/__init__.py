@@ -78,7 +78,23 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.omg_last_error.restype = C.c_char_p
         _lib = L
+        # test / measurement plumbing (this file, not the library): OMEGA_AMD_OPTIONS="MergeL1=0,Pair=0" is turned into
+        # omg_set_option calls, so that a whole pytest or bench.py run can be repeated under another kernel structure
+        for item in filter(None, os.environ.get("OMEGA_AMD_OPTIONS", "").split(",")):
+            name, _, val = item.partition("=")
+            set_option(name.strip(), int(val))
     return _lib
+
+
+def set_option(name: str, value: int):
+    """omg_set_option (omega_amd/csrc/Tuning.h): measurement / test switches; the library never reads the environment."""
+    _chk(lib().omg_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int()
+    _chk(lib().omg_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def _chk(rc):
@@ -447,6 +463,9 @@ class RcclComm:
         _chk(lib().omg_rccl_info(self.h, C.byref(n), C.byref(r), C.byref(v), C.byref(e)))
         return {"nranks": n.value, "rank": r.value, "version": v.value, "exchanges": e.value}
 
+    def abort(self):
+        _chk(lib().omg_rccl_abort(self.h))
+
     def exchange(self, peers, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream=None):
         n = len(peers)
         _chk(lib().omg_rccl_exchange(self.h, n, (C.c_int * n)(*peers), (C.c_void_p * n)(*send_ptrs),
@@ -456,6 +475,49 @@ class RcclComm:
     def __del__(self):
         try:
             lib().omg_rccl_destroy(self.h)
+        except Exception:
+            pass
+
+
+class PeerWire:
+    """Direct peer-copy halo wire owned by the library (omega_amd/csrc/PeerWire.cpp): mailbox + flags exported with
+    HIP IPC, exchanges fully stream-ordered.  Create after device_init, all_gather `handle()` over any side channel,
+    `connect(list_of_handles_in_rank_order)`, then `Halo.use_peer(wire)`."""
+
+    HANDLE_BYTES = 160
+
+    def __init__(self, nranks: int, rank: int, mailbox_bytes: int):
+        h = C.c_void_p()
+        _chk(lib().omg_peer_create(nranks, rank, C.c_size_t(mailbox_bytes), C.byref(h)))
+        self.h = h
+        self.nranks = nranks
+
+    def handle(self) -> bytes:
+        buf = C.create_string_buffer(PeerWire.HANDLE_BYTES)
+        _chk(lib().omg_peer_local_handle(self.h, buf))
+        return buf.raw
+
+    def connect(self, handles):
+        blob = b"".join(handles)
+        assert len(blob) == self.nranks * PeerWire.HANDLE_BYTES
+        _chk(lib().omg_peer_connect(self.h, C.create_string_buffer(blob, len(blob))))
+
+    def info(self) -> dict:
+        e, s = C.c_int64(), C.c_int()
+        _chk(lib().omg_peer_info(self.h, C.byref(e), C.byref(s)))
+        return {"exchanges": e.value, "status": s.value}
+
+    def set_timeout(self, seconds: float):
+        _chk(lib().omg_peer_set_timeout(self.h, C.c_double(seconds)))
+
+    def close(self):
+        if self.h:
+            lib().omg_peer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
@@ -496,6 +558,16 @@ class Halo:
         """Route the exchanges through RCCL send / recv issued inside the library (production wire)."""
         _chk(lib().omg_halo_use_rccl(self.h, comm.h))
         self._comm = comm
+
+    def use_peer(self, wire: "PeerWire"):
+        """Route the exchanges through direct peer copies into the neighbours' mailboxes (stream-ordered, no host waits)."""
+        _chk(lib().omg_halo_use_peer(self.h, wire.h))
+        self._wire = wire
+
+    def recv_rows(self, per_cell: int, per_edge: int, per_vertex: int = 0) -> int:
+        r = C.c_size_t()
+        _chk(lib().omg_halo_recv_rows(self.h, C.c_size_t(per_cell), C.c_size_t(per_edge), C.c_size_t(per_vertex), C.byref(r)))
+        return r.value
 
     def set_transport(self, fn):
         """fn(tasks, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream_handle) -> int"""

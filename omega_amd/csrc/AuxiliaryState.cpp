@@ -1,6 +1,7 @@
 // AuxiliaryState.cpp -- see AuxiliaryState.h.
 #include "AuxiliaryState.h"
 #include "Halo.h"
+#include "Pacer.h"
 
 namespace OMEGA {
 
@@ -61,13 +62,20 @@ void AuxiliaryState::computeMomAux(const OceanState *State, int ThickTimeLevel, 
    const AuxPtrs A   = ptrs();
    const int K       = NVertLayers;
    const int Upwind  = LayerThicknessAux.FluxThickEdgeChoice == FluxThickEdgeOption::Upwind;
-   launchVertexAuxState1(M, K, A, LayerThickCell.Ptr, NormalVelEdge.Ptr, S);                  // :79-85
-   launchCellAuxState1(M, K, A, NormalVelEdge.Ptr, S);                                        // :88-93
-   launchEdgeAuxState1(M, A, WindForcingAux.InterpChoice == InterpCellToEdgeOption::Isotropic, S); // :99-103
-   launchEdgeAuxState2(M, K, A, LayerThickCell.Ptr, NormalVelEdge.Ptr, Upwind, S);            // :106-115
-   launchVertexAuxState2(M, K, A, S);                                                         // :118-123
-   launchCellAuxState2(M, K, A, S);                                                           // :126-131
-   launchCellAuxState3(M, K, A, LayerThickCell.Ptr, S);                                       // :134-140
+   Pacer::Range Timer("AuxState:computeMomAux", 1);
+   auto Timed = [](const char *Name, auto &&Launch) { // the reference's level-2 timer around each launch
+      Pacer::Range T2(Name, 2);
+      Launch();
+   };
+   Timed("AuxState:vertexAuxState1", [&] { launchVertexAuxState1(M, K, A, LayerThickCell.Ptr, NormalVelEdge.Ptr, S); }); // :79-85
+   Timed("AuxState:cellAuxState1", [&] { launchCellAuxState1(M, K, A, NormalVelEdge.Ptr, S); });                       // :88-93
+   Timed("AuxState:edgeAuxState1", [&] {
+      launchEdgeAuxState1(M, A, WindForcingAux.InterpChoice == InterpCellToEdgeOption::Isotropic, S); // :99-103
+   });
+   Timed("AuxState:edgeAuxState2", [&] { launchEdgeAuxState2(M, K, A, LayerThickCell.Ptr, NormalVelEdge.Ptr, Upwind, S); }); // :106-115
+   Timed("AuxState:vertexAuxState2", [&] { launchVertexAuxState2(M, K, A, S); });                                     // :118-123
+   Timed("AuxState:cellAuxState2", [&] { launchCellAuxState2(M, K, A, S); });                                         // :126-131
+   Timed("AuxState:cellAuxState3", [&] { launchCellAuxState3(M, K, A, LayerThickCell.Ptr, S); });                     // :134-140
 }
 
 void AuxiliaryState::computeAll(const OceanState *State, const Array3DReal &TracerArray, int ThickTimeLevel,
@@ -75,12 +83,17 @@ void AuxiliaryState::computeAll(const OceanState *State, const Array3DReal &Trac
    Array2DReal LayerThickCell, NormalVelEdge;
    OMEGA_REQUIRE(State->getLayerThickness(LayerThickCell, ThickTimeLevel) == 0, "AuxiliaryState: bad thickness time level");
    OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelTimeLevel) == 0, "AuxiliaryState: bad velocity time level");
+   Pacer::Range Timer("AuxState:computeAll", 1);
    computeMomAux(State, ThickTimeLevel, VelTimeLevel, S);
    const MeshView &M = Mesh->view();
    const AuxPtrs A   = ptrs();
    const int Upwind  = TracerAux.TracersOnEdgeChoice == FluxTracerEdgeOption::Upwind;
+   Pacer::start("AuxState:edgeAuxState4", 2);
    launchEdgeAuxState4(M, NVertLayers, NTracers, A, NormalVelEdge.Ptr, LayerThickCell.Ptr, TracerArray.Ptr, Upwind, S); // :165-171
+   Pacer::stop("AuxState:edgeAuxState4", 2);
+   Pacer::start("AuxState:cellAuxState4", 2);
    launchCellAuxState4(M, NVertLayers, NTracers, A, TracerArray.Ptr, S);                                               // :176-182
+   Pacer::stop("AuxState:cellAuxState4", 2);
 }
 
 I4 AuxiliaryState::exchangeHalo(hipStream_t S) {

@@ -1,10 +1,72 @@
 // Device.cpp -- HIP memory helpers and the error sink.
 #include "Base.h"
+#include "Tuning.h"
+
+#include <cctype>
+#include <cstdlib>
 
 #include <cstring>
 #include <sstream>
 
 namespace OMEGA {
+
+namespace {
+struct OptionName {
+   const char *Name;
+   int TuningOptions::*Field;
+};
+const OptionName OptionTable[] = {
+    {"W", &TuningOptions::W},
+    {"TX", &TuningOptions::TX},
+    {"TY", &TuningOptions::TY},
+    {"Sweeps", &TuningOptions::Sweeps},
+    {"ChunkSplit", &TuningOptions::ChunkSplit},
+    {"TailSplit", &TuningOptions::TailSplit},
+    {"EdgeMode", &TuningOptions::EdgeMode},
+    {"FuseFinal", &TuningOptions::FuseFinal},
+    {"MergeL1", &TuningOptions::MergeL1},
+    {"Pair", &TuningOptions::Pair},
+    {"FuseL3", &TuningOptions::FuseL3},
+    {"ForceGeneric", &TuningOptions::ForceGeneric},
+    {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
+    {"DomValence", &TuningOptions::DomValence},
+    {"Graphs", &TuningOptions::Graphs},
+};
+} // namespace
+
+TuningOptions &tuning() {
+   static TuningOptions T = [] {
+      TuningOptions X;
+#ifdef OMEGA_TUNING_ENV
+      // measurement builds only: OMEGA_TX, OMEGA_MERGEL1, ... (upper-cased option names)
+      for (const OptionName &O : OptionTable) {
+         std::string Var = "OMEGA_";
+         for (const char *C = O.Name; *C; ++C)
+            Var += (char)std::toupper((unsigned char)*C);
+         if (const char *V = std::getenv(Var.c_str()))
+            X.*(O.Field) = std::atoi(V);
+      }
+#endif
+      return X;
+   }();
+   return T;
+}
+bool setTuningOption(const std::string &Name, int Value) {
+   for (const OptionName &O : OptionTable)
+      if (Name == O.Name) {
+         tuning().*(O.Field) = Value;
+         return true;
+      }
+   return false;
+}
+bool getTuningOption(const std::string &Name, int &Value) {
+   for (const OptionName &O : OptionTable)
+      if (Name == O.Name) {
+         Value = tuning().*(O.Field);
+         return true;
+      }
+   return false;
+}
 
 void abortError(const char *File, int Line, const std::string &Msg) {
    std::ostringstream OS;

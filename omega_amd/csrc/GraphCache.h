@@ -17,6 +17,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include "Tuning.h"
+
 #include <functional>
 
 namespace OMEGA {
@@ -31,15 +33,9 @@ class GraphCache {
             (void)hipGraphExecDestroy(E.Exec);
       Entries.clear();
    }
-   /// environment default of the UseGraphs switches (OMEGA_GRAPHS=1), and the global veto (OMEGA_GRAPHS=0)
-   static bool defaultOn() {
-      static const bool On = getenv("OMEGA_GRAPHS") && atoi(getenv("OMEGA_GRAPHS")) != 0;
-      return On;
-   }
-   static bool enabled() {
-      static const bool Off = getenv("OMEGA_GRAPHS") && atoi(getenv("OMEGA_GRAPHS")) == 0;
-      return !Off;
-   }
+   /// default of the UseGraphs switches (option Graphs = 1), and the global veto (Graphs = 0): Tuning.h
+   static bool defaultOn() { return tuning().Graphs > 0; }
+   static bool enabled() { return tuning().Graphs != 0; }
    template <class T> static void add(Key &K, const T &V) {
       unsigned long long W[(sizeof(T) + 7) / 8] = {};
       std::memcpy(W, &V, sizeof(T));

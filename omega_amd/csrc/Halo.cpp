@@ -110,6 +110,8 @@ void Halo::usePeerWire(PeerWire *Wire) {
    Transport = nullptr;
 }
 
+std::string Halo::wireError() const { return (Peer && !Peer->lastError().empty()) ? ": " + Peer->lastError() : ""; }
+
 size_t Halo::recvRows(size_t NTC, size_t NTE, size_t NTV) const {
    size_t R = 0;
    for (int N = 0; N < NNghbr; ++N)

@@ -57,6 +57,8 @@ class Halo : public Registry<Halo> {
    /// rows of K values this rank receives in one exchange of NTCell / NTEdge / NTVertex arrays-per-element
    /// (to size a PeerWire mailbox: bytes = recvRows(...) * K * 8)
    size_t recvRows(size_t NTCell, size_t NTEdge, size_t NTVertex) const;
+   /// ": <message of the wire>" after an exchange returned -1 through the peer wire, else ""
+   std::string wireError() const;
    /// Bytes needed per neighbour for exchanging arrays of `TotSizeCell`, `TotSizeEdge`,
    /// `TotSizeVertex` values per element in one message.
    size_t requiredBytes(int INghbr, size_t TotSizeCell, size_t TotSizeEdge, size_t TotSizeVertex) const;

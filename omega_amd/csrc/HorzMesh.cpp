@@ -1,5 +1,6 @@
 // HorzMesh.cpp -- see HorzMesh.h.
 #include "HorzMesh.h"
+#include "Tuning.h"
 
 #include <cstdlib>
 
@@ -110,10 +111,9 @@ HorzMesh::HorzMesh(const std::string &Name, const Decomp *D, I4 InNVertLayers, b
 // Decomp keeps the file's.  Padding slots never take part in any result.
 void HorzMesh::compactMaxEdges() {
    MaxEdgesFile = MaxEdges;
-   // OMEGA_KEEP_MAXEDGES=1 (test hook): keep the file's width, so that the wide kernel instantiations and the
+   // option KeepMaxEdges (test hook, Tuning.h): keep the file's width, so that the wide kernel instantiations and the
    // edge-centric list for valences below MaxEdges-2 can be exercised with meshes that have no such cells
-   static const bool Keep = getenv("OMEGA_KEEP_MAXEDGES") && atoi(getenv("OMEGA_KEEP_MAXEDGES")) != 0;
-   if (Keep)
+   if (tuning().KeepMaxEdges != 0)
       return;
    int Eff      = 5;
    for (int C = 0; C < NCellsAll; ++C)
@@ -426,7 +426,7 @@ void HorzMesh::buildCoefficientTables() {
    buildCellL1Tables();
    buildBandLists((I4)NCellsHaloH.size());
    // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
-   if (const char *Fg = getenv("OMEGA_FORCE_GENERIC"); Fg && atoi(Fg) == 1)
+   if (tuning().ForceGeneric == 1)
       W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = W.CellL1OK = 0;
 }
 
@@ -756,7 +756,7 @@ void HorzMesh::buildCellPV() {
    W.NRingCellsM0 = (I4)CellsM0.size(), W.NRingCellsM1 = (I4)CellsM1.size(), W.NRingCellsM2 = (I4)CellsM2.size();
    W.RingCellsM0 = RingCellsM0.Ptr, W.RingCellsM1 = RingCellsM1.Ptr, W.RingCellsM2 = RingCellsM2.Ptr;
    // (the kernels' full sweeps are instantiated for the valence most cells have: MaxEdges or MaxEdges-1)
-   static const int DomEnv = getenv("OMEGA_DOM_VALENCE") ? atoi(getenv("OMEGA_DOM_VALENCE")) : 1;
+   const int DomEnv = tuning().DomValence;
    W.DomM1 = (DomEnv != 0 && ME >= 6 && CellsM1.size() > CellsM0.size()) ? 1 : 0;
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
    W.RingVertOnCell = RingVertOnCell.Ptr, W.PVRoleOnCell = PVRoleOnCell.Ptr, W.PVWeightOnCell = PVWeightOnCell.Ptr;

@@ -1,0 +1,44 @@
+// Pacer.h -- the reference's timer names as roctx ranges.
+//
+// The reference brackets its launches with Pacer::start / Pacer::stop (share/pacer/Pacer.cpp:153-200, GPTL timers
+// written to omega.timing), e.g. "Tend:computeAllTendencies", "AuxState:vertexAuxState1", "RK4:haloExch"
+// (components/omega/src/ocn/Tendencies.cpp:270-588, AuxiliaryState.cpp:76-175, timeStepping/*.cpp).  Here the same
+// names open and close roctx ranges, so `rocprofv3 --marker-trace --kernel-trace` lines the kernels of this build up
+// under the timer names of an Omega run.  Without a profiler attached a range costs two calls into the roctx stub.
+// The fused kernels cover several reference timers at once; their ranges are named "Tend:fused:<level>" and list
+// the reference timers they replace.
+#ifndef OMEGA_AMD_PACER_H
+#define OMEGA_AMD_PACER_H
+
+#include <rocprofiler-sdk-roctx/roctx.h>
+
+namespace OMEGA {
+namespace Pacer {
+
+/// timers above this level are not emitted (reference: Pacer::setTimingLevel, Pacer.cpp:138-150)
+inline int &timingLevel() {
+   static int Level = 3;
+   return Level;
+}
+inline bool start(const char *Name, int Level = 0) {
+   if (Level <= timingLevel())
+      roctxRangePushA(Name);
+   return true;
+}
+inline bool stop(const char * /*Name*/, int Level = 0) {
+   if (Level <= timingLevel())
+      roctxRangePop();
+   return true;
+}
+/// scoped start / stop
+struct Range {
+   int Level;
+   Range(const char *Name, int Level_ = 0) : Level(Level_) { start(Name, Level); }
+   ~Range() { stop(nullptr, Level); }
+   Range(const Range &)            = delete;
+   Range &operator=(const Range &) = delete;
+};
+
+} // namespace Pacer
+} // namespace OMEGA
+#endif

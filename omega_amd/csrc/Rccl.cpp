@@ -29,10 +29,15 @@ RcclComm::RcclComm(const char Id[UniqueIdBytes], int NRanks_, int Rank_) {
    ncclComm_t C = nullptr;
    RCCL_CHECK(ncclCommInitRank(&C, NRanks_, U, Rank_));
    Comm = C;
-   RCCL_CHECK(ncclCommCount(C, &NRanks));
-   RCCL_CHECK(ncclCommUserRank(C, &Rank));
-   RCCL_CHECK(ncclGetVersion(&Version));
-   OMEGA_REQUIRE(NRanks == NRanks_ && Rank == Rank_, "RcclComm: communicator reports a different rank / size");
+   try { // the destructor does not run when the constructor throws: give the communicator back here
+      RCCL_CHECK(ncclCommCount(C, &NRanks));
+      RCCL_CHECK(ncclCommUserRank(C, &Rank));
+      RCCL_CHECK(ncclGetVersion(&Version));
+      OMEGA_REQUIRE(NRanks == NRanks_ && Rank == Rank_, "RcclComm: communicator reports a different rank / size");
+   } catch (...) {
+      abort();
+      throw;
+   }
 }
 
 RcclComm::~RcclComm() {
@@ -40,11 +45,26 @@ RcclComm::~RcclComm() {
       (void)ncclCommDestroy(static_cast<ncclComm_t>(Comm));
 }
 
+// An error on a communicator is fatal for the job (no retry anywhere in this library or in bench.py): the
+// communicator is aborted -- queued operations are dropped, peers see the failure instead of waiting for messages
+// that never come -- and every later exchange is refused.
+void RcclComm::abort() {
+   if (Comm)
+      (void)ncclCommAbort(static_cast<ncclComm_t>(Comm));
+   Comm   = nullptr;
+   Failed = true;
+}
+
 int RcclComm::exchange(int N, const int *Peers, void *const *SendPtrs, const size_t *SendBytes, void *const *RecvPtrs,
                        const size_t *RecvBytes, hipStream_t S) {
+   if (Failed || !Comm) {
+      LastError = "RcclComm::exchange: the communicator was aborted after an earlier error (" + LastError + ")";
+      return 1;
+   }
    ncclComm_t C = static_cast<ncclComm_t>(Comm);
    auto Fail    = [&](const char *What, ncclResult_t R) {
       LastError = std::string(What) + ": " + ncclGetErrorString(R);
+      abort(); // a partly enqueued group must not leave peers waiting for the rest
       return 1;
    };
    for (int I = 0; I < N; ++I)

@@ -36,13 +36,18 @@ class RcclComm {
    int exchange(int N, const int *Peers, void *const *SendPtrs, const size_t *SendBytes, void *const *RecvPtrs,
                 const size_t *RecvBytes, hipStream_t S);
    const std::string &lastError() const { return LastError; }
+   /// ncclCommAbort: after any error, or when the job decides not to use this communicator (e.g. another rank could
+   /// not create its own).  Every later exchange returns an error.
+   void abort();
+   bool failed() const { return Failed; }
 
    /// HaloTransportFn-compatible thunk (Halo.h): Ctx is the RcclComm
    static int transport(void *Ctx, int NNghbr, const int *Tasks, void *const *SendPtrs, const size_t *SendBytes,
                         void *const *RecvPtrs, const size_t *RecvBytes, void *Stream);
 
  private:
-   void *Comm = nullptr; ///< ncclComm_t
+   void *Comm  = nullptr; ///< ncclComm_t
+   bool Failed = false;
    std::string LastError;
 };
 

@@ -1,5 +1,6 @@
 // Tendencies.cpp -- see Tendencies.h.
 #include "Tendencies.h"
+#include "Pacer.h"
 
 namespace OMEGA {
 
@@ -48,26 +49,33 @@ TendParams Tendencies::paramsFor(const AuxiliaryState *Aux) const {
 // Tendencies.cpp:257-297
 void Tendencies::computeThicknessTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
                                                 hipStream_t S) {
+   Pacer::Range Timer("Tend:computeThicknessTendenciesOnly", 1);
    Array2DReal NormalVelEdge;
    OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
    launchThicknessTendOnly(Mesh->view(), NVertLayers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                            NormalVelEdge.Ptr, S);
-   if (CustomThicknessTend) // Tendencies.cpp:288-291
+   if (CustomThicknessTend) { // Tendencies.cpp:288-291
+      Pacer::Range T2("Tend:customThicknessTend", 2);
       CustomThicknessTend(LayerThicknessTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
+   }
 }
 // Tendencies.cpp:301-423
 void Tendencies::computeVelocityTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
                                                hipStream_t S) {
+   Pacer::Range Timer("Tend:computeVelocityTendenciesOnly", 1);
    Array2DReal NormalVelEdge;
    OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
    launchVelocityTendOnly(Mesh->view(), NVertLayers, paramsFor(Aux), Aux->ptrs(), NormalVelocityTend.Ptr,
                           NormalVelEdge.Ptr, S);
-   if (CustomVelocityTend) // Tendencies.cpp:416-419
+   if (CustomVelocityTend) { // Tendencies.cpp:416-419
+      Pacer::Range T2("Tend:customVelocityTend", 2);
       CustomVelocityTend(NormalVelocityTend, State, Aux, ThickLvl, VelLvl, ModelTime, S);
+   }
 }
 // Tendencies.cpp:427-486
 void Tendencies::computeTracerTendenciesOnly(const OceanState *State, const AuxiliaryState *Aux,
                                              const Array3DReal &TracerArray, int, int VelLvl, hipStream_t S) {
+   Pacer::Range Timer("Tend:computeTracerTendenciesOnly", 1);
    Array2DReal NormalVelEdge;
    OMEGA_REQUIRE(State->getNormalVelocity(NormalVelEdge, VelLvl) == 0, "Tendencies: bad velocity time level");
    launchTracerTendOnly(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), TracerTend.Ptr,
@@ -76,35 +84,45 @@ void Tendencies::computeTracerTendenciesOnly(const OceanState *State, const Auxi
 // Tendencies.cpp:488-519
 void Tendencies::computeThicknessTendencies(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
                                             hipStream_t S) {
+   Pacer::Range Timer("Tend:computeThicknessTendencies", 1);
    Array2DReal LayerThick, NormVel;
    OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
                  "Tendencies: bad time level");
    const TendParams P = paramsFor(Aux);
+   Pacer::start("Tend:computeLayerThickAux", 2);
    launchLayerThickAuxEdge(Mesh->view(), NVertLayers, Aux->ptrs(), LayerThick.Ptr, NormVel.Ptr, P.FluxThicknessUpwind, S);
+   Pacer::stop("Tend:computeLayerThickAux", 2);
    computeThicknessTendenciesOnly(State, Aux, ThickLvl, VelLvl, S);
 }
 // Tendencies.cpp:521-535
 void Tendencies::computeVelocityTendencies(const OceanState *State, const AuxiliaryState *Aux, int ThickLvl, int VelLvl,
                                            hipStream_t S) {
+   Pacer::Range Timer("Tend:computeVelocityTendencies", 1);
    Aux->computeMomAux(State, ThickLvl, VelLvl, S);
    computeVelocityTendenciesOnly(State, Aux, ThickLvl, VelLvl, S);
 }
 // Tendencies.cpp:537-575
 void Tendencies::computeTracerTendencies(const OceanState *State, const AuxiliaryState *Aux,
                                          const Array3DReal &TracerArray, int ThickLvl, int VelLvl, hipStream_t S) {
+   Pacer::Range Timer("Tend:computeTracerTendencies", 1);
    Array2DReal LayerThick, NormVel;
    OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
                  "Tendencies: bad time level");
    const TendParams P = paramsFor(Aux);
+   Pacer::start("Tend:computeTracerAuxEdge", 2);
    launchEdgeAuxState4(Mesh->view(), NVertLayers, NTracers, Aux->ptrs(), NormVel.Ptr, LayerThick.Ptr, TracerArray.Ptr,
                        P.FluxTracerUpwind, S);
+   Pacer::stop("Tend:computeTracerAuxEdge", 2);
+   Pacer::start("Tend:computeTracerAuxCell", 2);
    launchCellAuxState4(Mesh->view(), NVertLayers, NTracers, Aux->ptrs(), TracerArray.Ptr, S);
+   Pacer::stop("Tend:computeTracerAuxCell", 2);
    computeTracerTendenciesOnly(State, Aux, TracerArray, ThickLvl, VelLvl, S);
 }
 // Tendencies.cpp:579-600
 bool Tendencies::computeAllTendenciesStage(const OceanState *State, const AuxiliaryState *Aux,
                                            const Array3DReal &TracerArray, int ThickLvl, int VelLvl,
                                            const StageUpdate &Stage, hipStream_t S) {
+   Pacer::Range Timer("Tend:computeAllTendencies", 1);
    if (!(UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)))
       return false;
    if (CustomThicknessTend || CustomVelocityTend)
@@ -121,6 +139,7 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
 
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
                                       int ThickLvl, int VelLvl, hipStream_t S) {
+   Pacer::Range Timer("Tend:computeAllTendencies", 1);
    if (UseFusedRHS && !fusedRHSSupported(Mesh->view(), NVertLayers) && !WarnedUnfused) {
       // (32-bit byte offsets inside an array plane: more than ~2.2 M cells x 80 levels per GPU, or MaxEdges outside 5..8)
       std::fprintf(stderr,

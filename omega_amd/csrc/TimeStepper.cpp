@@ -1,5 +1,6 @@
 // TimeStepper.cpp -- see TimeStepper.h.
 #include "TimeStepper.h"
+#include "Pacer.h"
 
 #include <cfloat>
 #include <cmath>
@@ -210,7 +211,13 @@ void TimeStepper::updateTimeLevels(OceanState *State, hipStream_t S) const {
       const int NT = Trc ? Trc->NTracers : 0;
       if (NT > 0)
          Trc->getAll(Tr, 1);
-      OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? &Tr : nullptr, NT, S) == 0, "TimeStepper: halo exchange failed");
+      // (the reference's name for this exchange: "RK4:haloExch" / "RK2:haloExch" / "ForwardBackward:haloExch", level 3)
+      Pacer::Range Timer(Type == TimeStepperType::RungeKutta4   ? "RK4:haloExch"
+                         : Type == TimeStepperType::RungeKutta2 ? "RK2:haloExch"
+                                                                : "ForwardBackward:haloExch",
+                         3);
+      OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? &Tr : nullptr, NT, S) == 0,
+                    "TimeStepper: halo exchange failed" + MeshHalo->wireError());
    }
    State->rotateTimeLevels();
    if (Trc)
@@ -302,10 +309,11 @@ void RungeKutta4Stepper::startExchange(const ExchangeJob &Job) {
       HIP_CHECK(hipEventCreateWithFlags(&EvBand, hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&EvDone, hipEventDisableTiming));
    }
+   Pacer::Range Timer(Job.Provis ? "RK4:haloExchProvis" : "RK4:haloExch", 3);
    HIP_CHECK(hipEventRecord(EvBand, Job.S));
    HIP_CHECK(hipStreamWaitEvent(CommStream, EvBand, 0));
    OMEGA_REQUIRE(MeshHalo->exchangeState(Job.H, Job.U, Job.NT > 0 ? Job.Tr : nullptr, Job.NT, CommStream) == 0,
-                 "RungeKutta4: overlapped halo exchange failed");
+                 "RungeKutta4: overlapped halo exchange failed" + MeshHalo->wireError());
    HIP_CHECK(hipEventRecord(EvDone, CommStream));
    ExchangePending = true;
 }
@@ -353,9 +361,9 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
          // this stage's output is exchanged next: the provisional state before stage 2 (:107-113), the
          // new state at the end of the step (:130-131)
          if (Stage == 1)
-            Job.H = OutH, Job.U = OutU, Job.Tr = ProvT[Stage % 2];
+            Job.H = OutH, Job.U = OutU, Job.Tr = ProvT[Stage % 2], Job.Provis = true;
          else
-            Job.H = NextH, Job.U = NextU, Job.Tr = &NextTr;
+            Job.H = NextH, Job.U = NextU, Job.Tr = &NextTr, Job.Provis = false;
          Su.AfterBand = &RungeKutta4Stepper::startExchangeThunk, Su.AfterBandCtx = &Job;
       }
       bool Ok;
@@ -373,8 +381,9 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
             } else {
                Array2DReal H, U;
                In->getLayerThickness(H, CurLevel), In->getNormalVelocity(U, CurLevel);
+               Pacer::Range Timer("RK4:haloExchProvis", 3);
                OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? ProvT[(Stage - 1) % 2] : nullptr, NT, S) == 0,
-                             "RungeKutta4: provisional halo exchange failed");
+                             "RungeKutta4: provisional halo exchange failed" + MeshHalo->wireError());
             }
          }
          Ok = Tend->computeAllTendenciesStage(In, AuxState, *ProvT[(Stage - 1) % 2], CurLevel, CurLevel, Su, S);
@@ -439,8 +448,9 @@ void RungeKutta4Stepper::doStep(OceanState *State, hipStream_t S) {
             Array2DReal H, U;
             ProvisState->getLayerThickness(H, CurLevel);
             ProvisState->getNormalVelocity(U, CurLevel);
+            Pacer::Range Timer("RK4:haloExchProvis", 3);
             OMEGA_REQUIRE(MeshHalo->exchangeState(H, U, NT > 0 ? &ProvisTracers : nullptr, NT, S) == 0,
-                          "RungeKutta4: provisional halo exchange failed");
+                          "RungeKutta4: provisional halo exchange failed" + MeshHalo->wireError());
          }
          Tend->computeAllTendencies(ProvisState.get(), AuxState, ProvisTracers, CurLevel, CurLevel, S);
          updateStateByTend(State, NextLevel, State, NextLevel, coeff(RKB[Stage]), S);

@@ -145,6 +145,7 @@ class RungeKutta4Stepper : public TimeStepper {
       Array2DReal H, U;
       Array3DReal *Tr;
       int NT;
+      bool Provis = false; ///< the mid-step exchange of the provisional state (timer "RK4:haloExchProvis")
    };
    static void startExchangeThunk(void *Job);
    void startExchange(const ExchangeJob &Job);

@@ -1,0 +1,42 @@
+// Tuning.h -- measurement / test switches of the library, set through an explicit API (omg_set_option), never through
+// the environment: a backend that drops into components/omega must not change its kernel structure because a job
+// script exports a variable.  The defaults are what production runs; everything else exists so that tests can force
+// the fallback structures a generated mesh would never take, and so that A/B measurements can be made on one build.
+// (A build with -DOMEGA_TUNING_ENV additionally initialises the options from OMEGA_<NAME> environment variables --
+// not the default build.)
+#ifndef OMEGA_AMD_TUNING_H
+#define OMEGA_AMD_TUNING_H
+
+#include <string>
+
+namespace OMEGA {
+
+struct TuningOptions {
+   // ---- tile geometry (KernelCommon.h: makeGeom); 0 / -1 = the built-in choice
+   int W          = 2;  ///< levels per thread (1: scalar accesses everywhere)
+   int TX         = 0;  ///< threads along the levels
+   int TY         = 0;  ///< elements per workgroup
+   int Sweeps     = 1;  ///< tiles per workgroup
+   int ChunkSplit = -1; ///< level chunks over gridDim.y (-1: by sweep size)
+   int TailSplit  = 1;  ///< spread the last partial round of workgroups over the level chunks
+   // ---- kernel structure of the fused RHS (FusedKernels.hip: launchFusedT)
+   int EdgeMode  = 0; ///< 1: edge-centric chain kernel instead of the cell-centric PV kernels
+   int FuseFinal = 1; ///< side-1 PV sums and the remaining velocity terms in one kernel
+   int MergeL1   = 1; ///< vertex pass + side-0 PV sums inside the level-1 cell kernel
+   int Pair      = 1; ///< independent sweeps share a launch
+   int FuseL3    = 1; ///< plain RHS: both level-3 kernels in one thread
+   // ---- mesh tables (read when a HorzMesh is constructed)
+   int ForceGeneric = 0; ///< clear every ring-table flag: all kernels in their generic form
+   int KeepMaxEdges = 0; ///< keep the mesh file's maxEdges as the table width
+   int DomValence   = 1; ///< full sweeps at the valence most cells have
+   // ---- HIP-graph replay: -1 = as each object's UseGraphs says, 0 = never, 1 = default on
+   int Graphs = -1;
+};
+
+TuningOptions &tuning();
+/// false if there is no option of that name
+bool setTuningOption(const std::string &Name, int Value);
+bool getTuningOption(const std::string &Name, int &Value);
+
+} // namespace OMEGA
+#endif

@@ -12,7 +12,10 @@
 #include "MeshIO.h"
 #include "Partition.h"
 #include "History.h"
+#include "Pacer.h"
+#include "PeerWire.h"
 #include "Rccl.h"
+#include "Tuning.h"
 #include "TimeStepper.h"
 
 #include <cstring>
@@ -29,6 +32,9 @@ struct omg_halo {
 };
 struct omg_rccl {
    std::unique_ptr<RcclComm> C;
+};
+struct omg_peer {
+   std::unique_ptr<PeerWire> P;
 };
 struct omg_mesh {
    std::unique_ptr<HorzMesh> M;
@@ -514,6 +520,12 @@ int omg_rccl_destroy(omg_rccl *c) {
    delete c;
    return 0;
 }
+int omg_rccl_abort(omg_rccl *c) {
+   OMG_TRY
+   OMG_ARG(c);
+   c->C->abort();
+   OMG_CATCH
+}
 int omg_rccl_info(const omg_rccl *c, int *nranks, int *rank, int *version, int64_t *exchanges) {
    OMG_TRY
    OMG_ARG(c);
@@ -541,6 +553,80 @@ int omg_halo_use_rccl(omg_halo *h, omg_rccl *c) {
    h->H->useRccl(c->C.get());
    OMG_CATCH
 }
+int omg_set_option(const char *name, int value) {
+   OMG_TRY
+   OMG_ARG(name);
+   if (!setTuningOption(name, value))
+      OMEGA_ABORT(std::string("omg_set_option: no option named '") + name + "'");
+   OMG_CATCH
+}
+int omg_get_option(const char *name, int *value) {
+   OMG_TRY
+   OMG_ARG(name && value);
+   if (!getTuningOption(name, *value))
+      OMEGA_ABORT(std::string("omg_get_option: no option named '") + name + "'");
+   OMG_CATCH
+}
+int omg_set_timing_level(int level) {
+   Pacer::timingLevel() = level;
+   return 0;
+}
+int omg_peer_create(int nranks, int rank, size_t mailbox_bytes, omg_peer **out) {
+   OMG_TRY
+   OMG_ARG(out);
+   auto *R = new omg_peer;
+   try {
+      R->P.reset(new PeerWire(nranks, rank, mailbox_bytes));
+   } catch (...) {
+      delete R;
+      throw;
+   }
+   *out = R;
+   OMG_CATCH
+}
+int omg_peer_destroy(omg_peer *p) {
+   delete p;
+   return 0;
+}
+int omg_peer_local_handle(const omg_peer *p, char *out) {
+   OMG_TRY
+   OMG_ARG(p && out);
+   p->P->localHandle(out);
+   OMG_CATCH
+}
+int omg_peer_connect(omg_peer *p, const char *all_handles) {
+   OMG_TRY
+   OMG_ARG(p && all_handles);
+   p->P->connect(all_handles);
+   OMG_CATCH
+}
+int omg_peer_info(const omg_peer *p, int64_t *exchanges, int *status) {
+   OMG_TRY
+   OMG_ARG(p);
+   if (exchanges)
+      *exchanges = p->P->NExchanges;
+   if (status)
+      *status = p->P->status();
+   OMG_CATCH
+}
+int omg_peer_set_timeout(omg_peer *p, double seconds) {
+   OMG_TRY
+   OMG_ARG(p);
+   p->P->setTimeout(seconds);
+   OMG_CATCH
+}
+int omg_halo_use_peer(omg_halo *h, omg_peer *p) {
+   OMG_TRY
+   OMG_ARG(h && p);
+   h->H->usePeerWire(p->P.get());
+   OMG_CATCH
+}
+int omg_halo_recv_rows(const omg_halo *h, size_t per_cell, size_t per_edge, size_t per_vertex, size_t *rows) {
+   OMG_TRY
+   OMG_ARG(h && rows);
+   *rows = h->H->recvRows(per_cell, per_edge, per_vertex);
+   OMG_CATCH
+}
 int omg_halo_set_transport(omg_halo *h, omg_transport_fn fn, void *ctx) {
    OMG_TRY
    OMG_ARG(h);
@@ -552,7 +638,7 @@ int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int
    OMG_TRY
    OMG_ARG(h && dev_array && nt >= 1 && elem >= 0 && elem < 3 && k >= 1 && (row_pitch == 0 || row_pitch >= k));
    if (h->H->exchangeRaw(dev_array, nt, rows_size, k, row_pitch, (MeshElement)elem, (hipStream_t)stream) != 0)
-      OMEGA_ABORT("Halo::exchangeFullArrayHalo failed");
+      OMEGA_ABORT("Halo::exchangeFullArrayHalo failed" + h->H->wireError());
    OMG_CATCH
 }
 

@@ -18,6 +18,7 @@
 // Compiled with -ffp-contract=off.
 #include "KernelCommon.h"
 #include "Kernels.h"
+#include "../Pacer.h"
 
 #include <cstdlib>
 #include <functional>
@@ -1908,14 +1909,17 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       if (Ev)
          (void)hipEventRecord(Ev[I], S);
    };
-   // L1
+   // L1: replaces AuxState:vertexAuxState1, cellAuxState1, edgeAuxState1/2 (flux thickness), cellAuxState4 (Del2Tracers),
+   // Tend:thicknessFluxDiv and the cell-0 half of Tend:potientialVortHAdv
+   Pacer::start("Tend:fused:L1[AuxState:vertexAuxState1,cellAuxState1,edgeAuxState2,cellAuxState4;Tend:thicknessFluxDiv]", 2);
    Mark(0);
    // the vertex kernel stores RelVort and 1/LayerThickVertex; the two normalised vorticities are rebuilt from
    // them where they are consumed; without the cell-centric tables the edge kernels read the reference's arrays
-   static const int EdgeModeV = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
+   const TuningOptions &Tn = tuning();
+   const int EdgeModeV     = Tn.EdgeMode;
    const bool CellCentric     = EdgeModeV == 0 && M.CellPVOK && EdgeScratch;
-   // vertex pass and side-0 PV sums inside the L1 cell kernel (OMEGA_MERGE_L1=0: the three separate kernels)
-   static const int MergeL1Env = getenv("OMEGA_MERGE_L1") ? atoi(getenv("OMEGA_MERGE_L1")) : 1;
+   // vertex pass and side-0 PV sums inside the L1 cell kernel (option MergeL1 = 0: the three separate kernels)
+   const int MergeL1Env = Tn.MergeL1;
    const bool MergeL1 = CellCentric && M.CellL1OK && P.PVTendencyEnable && MergeL1Env != 0 &&
                         (Fast || TME <= 7); // (8 edge slots with run-time option flags would spill registers)
    FusedKernelNames[0]        = MergeL1 ? "" : "VortVertexBody";
@@ -1958,10 +1962,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    if (P.WindForcingTendencyEnable)
       launchEdgeAuxState1(M, A, P.WindInterpIsotropic, S);
-   // L2 (only the del4 term consumes it)
+   Pacer::stop("Tend:fused:L1", 2);
+   // L2 (only the del4 term consumes it): replaces AuxState:edgeAuxState3 (Del2Edge), cellAuxState2, vertexAuxState2
+   Pacer::start("Tend:fused:L2[AuxState:vertexAuxState2,cellAuxState2]", 2);
    Mark(2);
-   // independent sweeps share a launch (KernelCommon.h: tileKernel2); OMEGA_PAIR=0 launches them one by one
-   static const int PairEnv = getenv("OMEGA_PAIR") ? atoi(getenv("OMEGA_PAIR")) : 1;
+   // independent sweeps share a launch (KernelCommon.h: tileKernel2); option Pair = 0 launches them one by one
+   const int PairEnv = Tn.Pair;
    const bool PairL2        = PairEnv && P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.Del2VertOK;
    FusedKernelNames[2] = FusedKernelNames[3] = "";
    if (PairL2) {
@@ -1990,15 +1996,18 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          launchTile(BV, M.NVerticesAll, K, S);
       }
    }
-   // L3
+   Pacer::stop("Tend:fused:L2", 2);
+   // L3: replaces Tend:potientialVortHAdv, KEGrad, SSHGrad, velocityDiffusion, velocityHyperDiff, windForcing, bottomDrag,
+   // AuxState:edgeAuxState4 (HTracersEdge) and Tend:tracerHorzAdv, tracerDiffusion, tracerHyperDiff
+   Pacer::start("Tend:fused:L3[Tend:potientialVortHAdv,KEGrad,SSHGrad,velocityDiffusion,velocityHyperDiff,tracerHorzAdv,"
+                "tracerDiffusion,tracerHyperDiff]", 2);
    Mark(4);
    bool Marked5        = false;
    std::function<void()> LaunchFinalInterior; // set when the side-1 sweep is split for an overlapped exchange
    FusedKernelNames[4] = "FusedEdgeChainBody", FusedKernelNames[5] = "";
-   // OMEGA_EDGE_MODE=1 forces the edge-centric chain kernel (the fallback of meshes without the
+   // option EdgeMode = 1 forces the edge-centric chain kernel (the fallback of meshes without the
    // cell-centric PV tables) for A/B measurements
-   static const int EdgeMode = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
-   static const int FuseFinalEnv = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
+   const int EdgeMode = Tn.EdgeMode, FuseFinalEnv = Tn.FuseFinal;
    // the side-1 PV + velocity kernel and the tracer kernel are independent: their main sweeps share a launch
    const bool PairL3 = PairEnv && Fast && EdgeMode == 0 && M.CellPVOK && EdgeScratch && P.PVTendencyEnable &&
                        FuseFinalEnv && M.CellPVFinalOK && NT > 0 && NMain > 0;
@@ -2026,7 +2035,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          }
          Mark(5);
          Marked5 = true;
-         static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
+         const int FuseFinal = Tn.FuseFinal;
          if (Fast && FuseFinal && M.CellPVFinalOK) {
             // Overlap == true: the full sweep is split into the band list now and the interior list after
             // the exchange has been started (Stage->AfterBand), see Kernels.h: StageUpdate
@@ -2190,8 +2199,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (!Marked5)
       Mark(5);
    Mark(6);
-   // OMEGA_FUSE_L3=0: the plain RHS keeps the paired launch too (A/B measurements)
-   static const int FuseL3Env = getenv("OMEGA_FUSE_L3") ? atoi(getenv("OMEGA_FUSE_L3")) : 1;
+   // option FuseL3 = 0: the plain RHS keeps the paired launch too (A/B measurements)
+   const int FuseL3Env = Tn.FuseL3;
    const bool FuseL3          = PairL3 && FuseL3Env && !Stage;
    FusedKernelNames[6]        = FuseL3   ? "CellPVFinalTracerBody"
                                 : PairL3 ? "CellPVFinalBody+FusedCell3Body"
@@ -2274,13 +2283,13 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          LaunchFinalInterior();
    }
    Mark(7);
+   Pacer::stop("Tend:fused:L3", 2);
 }
 
 /// does the stage-fused variant cover this mesh / option set?  (same conditions launchFusedT checks
 /// on its way to CellPVFinalBody)
 static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *EdgeScratch) {
-   static const int EdgeMode  = getenv("OMEGA_EDGE_MODE") ? atoi(getenv("OMEGA_EDGE_MODE")) : 0;
-   static const int FuseFinal = getenv("OMEGA_FUSE_FINAL") ? atoi(getenv("OMEGA_FUSE_FINAL")) : 1;
+   const int EdgeMode = tuning().EdgeMode, FuseFinal = tuning().FuseFinal;
    return isDefaultTermSet(P) && EdgeMode == 0 && FuseFinal && M.CellPVOK && M.CellPVFinalOK && EdgeScratch;
 }
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../Base.h"
+#include "../Tuning.h"
 
 namespace OMEGA {
 
@@ -111,7 +112,8 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    if (Pitch <= 0)
       Pitch = K;
    Geom G;
-   static const int EnvW = getenv("OMEGA_W") ? atoi(getenv("OMEGA_W")) : 2;
+   const TuningOptions &Tn = tuning();
+   const int EnvW          = Tn.W;
    G.W  = (K % 2 == 0 && MaxW >= 2 && EnvW >= 2) ? 2 : 1;
    G.KV = K / G.W;
    // threadIdx.x spans ONE 128-byte line of a column (8 level-pairs, or 16 single levels) and
@@ -126,9 +128,7 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    const int LineTX   = 128 / (8 * G.W);
    const bool Aligned = (Pitch * 8) % 128 == 0; // rows start on line boundaries (levelPitch pads K >= 16 to lines)
    int TX             = Aligned ? (G.KV < LineTX ? G.KV : LineTX) : (G.KV < 64 ? G.KV : 64);
-   static const int EnvTX = getenv("OMEGA_TX") ? atoi(getenv("OMEGA_TX")) : 0;
-   static const int EnvTY = getenv("OMEGA_TY") ? atoi(getenv("OMEGA_TY")) : 0;
-   static const int EnvSW = getenv("OMEGA_SWEEPS") ? atoi(getenv("OMEGA_SWEEPS")) : 1;
+   const int EnvTX = Tn.TX, EnvTY = Tn.TY, EnvSW = Tn.Sweeps;
    if (EnvTX > 0)
       TX = EnvTX < G.KV ? EnvTX : G.KV;
    int TY = 256 / TX;
@@ -155,7 +155,7 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    // hide it, so the chunks go to separate workgroups (gridDim.y) -- more, shorter workgroups; each stages its own
    // copy of the tile's tables.
    int NChunks = (G.KV + TX - 1) / TX, Split = 1;
-   static const int EnvSplit = getenv("OMEGA_CHUNK_SPLIT") ? atoi(getenv("OMEGA_CHUNK_SPLIT")) : -1;
+   const int EnvSplit = Tn.ChunkSplit;
    if (EnvSplit >= 0)
       Split = EnvSplit > 0 ? (EnvSplit < NChunks ? EnvSplit : NChunks) : 1;
    else
@@ -166,7 +166,7 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    G.Grid  = dim3(NTiles > 0 ? NTiles : 1, Split > 0 ? Split : 1, 1);
    G.NFull = NTiles;
    // (wave slots: 8 waves per CU for the kernels that matter -- two per SIMD; the tail is what the last round leaves)
-   static const int EnvTail = getenv("OMEGA_TAIL_SPLIT") ? atoi(getenv("OMEGA_TAIL_SPLIT")) : 1;
+   const int EnvTail        = Tn.TailSplit;
    const int WavesPerWG     = (TX * TY + 63) / 64;
    const int Cap            = 256 * 8 / (WavesPerWG > 0 ? WavesPerWG : 1);
    if (EnvTail && Split == 1 && NChunks > 1 && NTiles >= Cap) {

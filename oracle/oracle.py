@@ -91,14 +91,40 @@ def build(force: bool = False, native: bool = False) -> str:
     return _SO
 
 
-def default_threads() -> int:
-    """OpenMP team of the oracle: the host cores this process may use, capped at OMEGA_ORACLE_THREADS (default 16 =
-    a one-GPU box's CPU share).  Tests and bench.py's cpu_baseline use the same number."""
+def host_cores() -> dict:
+    """What this process may use of the host: logical CPUs of the machine, CPUs in its affinity mask, and the CPU
+    bandwidth quota of its cgroup (v2 cpu.max or v1 cfs quota), if any."""
+    out = {"logical_cpus": os.cpu_count() or 1, "affinity": None, "cgroup_quota_cores": None}
     try:
-        avail = len(os.sched_getaffinity(0))
+        out["affinity"] = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    return max(1, min(avail, int(os.environ.get("OMEGA_ORACLE_THREADS", "16"))))
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()
+            if q != "max":
+                out["cgroup_quota_cores"] = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = float(fq.read()), float(fp.read())
+                if q > 0:
+                    out["cgroup_quota_cores"] = q / p
+        except (OSError, ValueError):
+            pass
+    avail = out["affinity"] or out["logical_cpus"]
+    if out["cgroup_quota_cores"]:
+        avail = max(1, min(avail, int(out["cgroup_quota_cores"] + 0.5)))
+    out["cores_available"] = avail
+    return out
+
+
+def default_threads() -> int:
+    """OpenMP team of the oracle: the host cores this process may use (affinity mask and cgroup quota), capped at
+    OMEGA_ORACLE_THREADS (default 16 = a one-GPU box's CPU share: such a box shows every hardware thread of its host in
+    the affinity mask, and a team of hundreds of spinning threads on a 16-core share makes every small parallel region
+    take milliseconds).  Tests and bench.py's cpu_baseline use the same number and report both."""
+    return max(1, min(host_cores()["cores_available"], int(os.environ.get("OMEGA_ORACLE_THREADS", "16"))))
 
 
 def use_native_build():

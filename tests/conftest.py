@@ -14,3 +14,11 @@ def pytest_configure(config):
 def _build_oracle():
     from oracle import oracle as O
     O.build()
+
+
+def pytest_collection_modifyitems(config, items):
+    """Files whose tests start child processes that use the GPU (multi-rank runs, re-runs of the parity suite under
+    other kernel structures, the compiled boundary programs) come first, in file-name order, whatever order or
+    selection pytest was given: the test runner's own process then has not touched the GPU while they run."""
+    first = ("test_00_multirank_gpu.py", "test_01_boundary_programs.py")
+    items.sort(key=lambda it: (0, first.index(it.fspath.basename)) if it.fspath.basename in first else (1, 0))

@@ -42,6 +42,13 @@ def main():
                     help="0 = owned elements must equal the single-rank run bit for bit; > 0 = the partitioned run may "
                          "deviate by at most this (relative to the field's max), and MUST deviate (the setting is known "
                          "not to be partition independent: HaloWidth 3 with the radius-2 del4 terms)")
+    ap.add_argument("--wire", default="gloo", choices=["gloo", "ipc"],
+                    help="gpu mode: gloo = host-staged test wire (synchronises the stream); ipc = the library's PeerWire "
+                         "(HIP IPC mailboxes + flag kernels, fully stream-ordered: exercises the event ordering of the "
+                         "overlapped exchanges for real)")
+    ap.add_argument("--peer-timeout-test", action="store_true",
+                    help="--wire ipc: rank 0 exchanges while the others never do: its wait kernel must give up after the "
+                         "wire's time limit, raise the sticky status and make the next exchange fail loudly -- no hang")
     ap.add_argument("--mesh", default="hex", help="hex (planar nx x ny) | any name of tests/meshes.py: icoN, fibN, "
                                                   "hexNXxNY, <base>_coast_<kind>[_raw][_compact], <base>_pad8")
     a = ap.parse_args()
@@ -92,9 +99,40 @@ def main():
         for rl, rb in recvs:
             a3[:, rl, :] = rb.numpy()
 
-    if gpu:
+    wire = None
+    if gpu and a.wire == "ipc":
+        rows = max(halo.recv_rows(3, 0, 0), halo.recv_rows(0, 3, 0), halo.recv_rows(0, 0, 3), halo.recv_rows(1 + NT, 1, 0))
+        wire = oa.PeerWire(a.world, a.rank, max(rows, 1) * K * 8)
+        handles = [None] * a.world
+        dist.all_gather_object(handles, wire.handle())
+        wire.connect(handles)
+        halo.use_peer(wire)
+    elif gpu:
         from omega_amd.transport import GlooStagedTransport
         GlooStagedTransport(halo)
+
+    if a.peer_timeout_test:
+        assert wire is not None
+        wire.set_timeout(1.0)
+        if a.rank == 0:
+            import time
+            buf = oa.DeviceBuffer(np.zeros((sizes[0], K)))
+            t0 = time.time()
+            halo.exchange(buf.ptr, 1, sizes[0], K, 0)
+            oa.device_synchronize()
+            el = time.time() - t0
+            assert 0.9 < el < 10.0, el                       # the wave left after the limit, not before, not never
+            assert wire.info()["status"] == 2, wire.info()   # bit 1: the wait for the neighbours' messages gave up
+            try:
+                halo.exchange(buf.ptr, 1, sizes[0], K, 0)
+                raise AssertionError("an exchange after a timed-out one must fail")
+            except oa.OmegaAmdError as exc:
+                assert "timed out" in str(exc), str(exc)
+        dist.barrier()
+        wire.close()
+        dist.destroy_process_group()
+        print(f"rank {a.rank}/{a.world} OK (peer wire timeout)")
+        return
 
     # ---------------- (a) HaloTest: global ids on owned, garbage on halo, exchange, compare ----------------
     for elem in (0, 1, 2):
@@ -175,9 +213,16 @@ def main():
     assert np.array_equal(h[:nc], gh), f"rank {a.rank}: h differs from the single-rank run (max {np.abs(h[:nc]-gh).max()})"
     assert np.array_equal(u[:ne], gu), f"rank {a.rank}: u differs from the single-rank run (max {np.abs(u[:ne]-gu).max()})"
     assert np.array_equal(tr[:NT, :nc], gtr[:NT]), f"rank {a.rank}: tracers differ from the single-rank run"
-    dist.barrier()
+    note = ""
+    if wire is not None:
+        info = wire.info()
+        assert info["status"] == 0 and info["exchanges"] >= 6 + a.steps, info
+        note = f", peer wire: {info['exchanges']} exchanges"
+    dist.barrier()          # every rank's GPU work is complete (device_synchronize above): mailboxes may go
+    if wire is not None:
+        wire.close()
     dist.destroy_process_group()
-    print(f"rank {a.rank}/{a.world} OK ({a.mode}, {a.stepper}, {len(nbrs)} neighbours)")
+    print(f"rank {a.rank}/{a.world} OK ({a.mode}, {a.stepper}, {len(nbrs)} neighbours{note})")
 
 
 if __name__ == "__main__":

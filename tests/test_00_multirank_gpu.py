@@ -3,9 +3,11 @@ kernels, RungeKutta4Stepper::doStep with its two exchange points, one process pe
 GPU 0 (this pool's test boxes have one GPU), messages staged through gloo (omega_amd/transport.py
 test mode).  Must reproduce the single-rank CPU oracle bit for bit on owned elements.
 
-File name sorts first on purpose: the ranks are child processes, and this pool forbids starting
-a new program from a process that has already initialised the GPU -- so it runs before the
-in-process GPU tests touch the device.
+The ranks (and the re-runs of the parity suite under other kernel structures) are fresh child processes; nothing in
+this file touches the GPU in the test runner's own process.  tests/conftest.py collects the child-spawning files
+first, so that the runner has not initialised the GPU yet when they start (rule of the pool: no exec in a process
+that has touched the GPU -- fresh children are fine, but keeping the runner GPU-free while they run also keeps the
+number of processes on the card at ranks + 0).
 """
 import os
 import subprocess
@@ -46,6 +48,34 @@ def test_two_ranks_one_gpu(extra):
     assert all("OK" in o for o in outs)
 
 
+@pytest.mark.parametrize("world,extra", [
+    (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6]),                  # overlapped
+    (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6, "--no-overlap"]),   # sequential
+    (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--user-stream"]),       # non-blocking user stream
+    (2, ["--no-del4", "--stepper", "Forward-Backward", "--levels", 5, "--tracers", 1]),
+    (2, ["--halo-width", 4, "--nx", 48, "--ny", 24, "--levels", 20, "--steps", 4]),         # padded rows, more exchanges
+    (2, ["--halo-width", 4, "--mesh", "ico4_coast_lakes", "--levels", 6, "--partition", "graph", "--local-order", "curve"]),
+    (4, ["--halo-width", 4, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 6]),        # several neighbours per rank
+    (4, ["--halo-width", 4, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 6, "--no-overlap"]),
+    (5, ["--halo-width", 4, "--nx", 60, "--ny", 48, "--levels", 4, "--tracers", 3, "--partition", "graph",
+         "--local-order", "curve"]),
+])
+def test_peer_wire_stream_ordered_exchanges(world, extra):
+    """The same runs over the library's OTHER wire (PeerWire: HIP IPC mailboxes, device-to-device copies and flag
+    kernels on the exchange's stream -- no host synchronisation anywhere, unlike the host-staged gloo rig): the
+    overlapped stages' event ordering (band final -> communication stream -> halo in place -> next consumer) is
+    exercised for real, and must give the single-rank oracle's bits in overlapped and in sequential mode."""
+    outs = run_ranks("gpu", world, [*extra, "--wire", "ipc"], timeout=900)
+    assert all("OK" in o and "peer wire" in o for o in outs)
+
+
+def test_peer_wire_gives_up_on_a_silent_peer():
+    """A rank whose neighbour never takes part in an exchange: the wait kernel leaves after the wire's time limit
+    (every wave reaches its exit), the status is sticky and the next exchange fails with a message."""
+    outs = run_ranks("gpu", 2, ["--wire", "ipc", "--peer-timeout-test"], timeout=300)
+    assert all("OK (peer wire timeout)" in o for o in outs)
+
+
 def test_halo_width_3_with_del4_bound_on_the_gpu():
     """bench.py's former N > 1 setting (reference default HaloWidth 3 + del4): bounded, non-zero deviation from
     the single-rank oracle (see tests/test_multirank_cpu.py)."""
@@ -69,8 +99,9 @@ def test_bench_setting_halo_width_4_with_del4_is_bit_exact(world, extra):
 def test_generic_fallback_kernels_in_a_child_process():
     """Meshes whose EdgesOnEdge / EdgesOnCell lists are not in MPAS ring order take the generic kernels
     (FusedEdgeBody, FusedDel2CellBody, FusedDel2VertexBody, separate update sweeps).  No generated mesh
-    is like that, so OMEGA_FORCE_GENERIC=1 clears the ring-table flags and the parity tests run again."""
-    env = dict(os.environ, OMEGA_FORCE_GENERIC="1")
+    is like that, so the option ForceGeneric = 1 (omg_set_option, applied by omega_amd/__init__.py from OMEGA_AMD_OPTIONS in
+    the child) clears the ring-table flags and the parity tests run again."""
+    env = dict(os.environ, OMEGA_AMD_OPTIONS="ForceGeneric=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
                         "(compute_all_tendencies and fused and (K80 or K4_ or K5 or ico3 or coast)) or time_steppers or generic_flags"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -80,10 +111,10 @@ def test_generic_fallback_kernels_in_a_child_process():
 
 
 def test_file_width_kernels_in_a_child_process():
-    """OMEGA_KEEP_MAXEDGES=1: HorzMesh keeps the file's maxEdges instead of the largest valence present, so the
+    """Option KeepMaxEdges = 1: HorzMesh keeps the file's maxEdges instead of the largest valence present, so the
     icosahedral mesh stored with maxEdges = 8 runs the 8-wide kernel instantiations with its hexagons as a "rarer
     valence" and its pentagons' edges on the edge-centric list -- what a mesh with real 8-valent cells would do."""
-    env = dict(os.environ, OMEGA_KEEP_MAXEDGES="1")
+    env = dict(os.environ, OMEGA_AMD_OPTIONS="KeepMaxEdges=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
                         "ico3pad8 or sphere_meshes_take_the_fast_paths or rk4_on_the_sphere"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -101,9 +132,9 @@ def test_five_ranks_graph_partition_curve_order_one_gpu():
 
 
 def test_unmerged_unpaired_kernel_structure_in_a_child_process():
-    """OMEGA_MERGE_L1=0 OMEGA_PAIR=0: the seven separate kernels of round 1 (what meshes without the cell-side vertex
+    """Options MergeL1 = 0, Pair = 0: the seven separate kernels of round 1 (what meshes without the cell-side vertex
     tables fall back to) must still equal the oracle."""
-    env = dict(os.environ, OMEGA_MERGE_L1="0", OMEGA_PAIR="0")
+    env = dict(os.environ, OMEGA_AMD_OPTIONS="MergeL1=0,Pair=0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
                         "(compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500 or coast)) or time_steppers or rk4_on_the_sphere"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -113,9 +144,9 @@ def test_unmerged_unpaired_kernel_structure_in_a_child_process():
 
 
 def test_paired_level3_launch_for_the_plain_rhs_in_a_child_process():
-    """OMEGA_FUSE_L3=0: the plain RHS runs CellPVFinalBody + FusedCell3Body as the paired launch the RK4 stages use
+    """Option FuseL3 = 0: the plain RHS runs CellPVFinalBody + FusedCell3Body as the paired launch the RK4 stages use
     (default: both in one thread, CellPVFinalTracerBody); same bits required."""
-    env = dict(os.environ, OMEGA_FUSE_L3="0")
+    env = dict(os.environ, OMEGA_AMD_OPTIONS="FuseL3=0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
                         "compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500 or coast)"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)

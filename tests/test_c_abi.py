@@ -93,3 +93,29 @@ def test_time_stepper_coefficients_match_oracle():
     for mult in (1. / 6, 1. / 3, 0.5, 1.0):
         for dt in (600.0, 0.2, 0.1, 37.5, 1800.0):
             assert oa.coeff_seconds(mult, dt) == O.coeff_seconds(mult, dt)
+
+
+def test_library_never_reads_the_environment():
+    """No OMEGA_* name is compiled into the product library (default build): kernel structure and tile geometry change
+    through omg_set_option only (omega_amd/csrc/Tuning.h)."""
+    import subprocess
+    import omega_amd as oa
+    out = subprocess.run(["strings", oa.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert [l for l in out.splitlines() if "OMEGA_" in l] == []
+    assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", oa.LIB_PATH], stdout=subprocess.PIPE,
+                                          check=True).stdout.decode()
+
+
+def test_options_api():
+    import omega_amd as oa
+    import pytest
+    for name, default in (("MergeL1", 1), ("Pair", 1), ("FuseL3", 1), ("ForceGeneric", 0), ("KeepMaxEdges", 0),
+                          ("DomValence", 1), ("Graphs", -1), ("TX", 0), ("ChunkSplit", -1)):
+        if not __import__("os").environ.get("OMEGA_AMD_OPTIONS"):
+            assert oa.get_option(name) == default, name
+        old = oa.get_option(name)
+        oa.set_option(name, 7)
+        assert oa.get_option(name) == 7
+        oa.set_option(name, old)
+    with pytest.raises(oa.OmegaAmdError):
+        oa.set_option("NoSuchOption", 1)

@@ -150,8 +150,7 @@ def test_sphere_meshes_take_the_fast_paths():
     assert P.mesh.get_int("CellPVOK") == 1 and P.mesh.get_int("NIrregularEdges") == 0
     P = _mk(("ico3pad8", 0, 0, 4, 1, {}))
     assert P.mesh.get_int("MaxEdgesFile") == 8 and P.mesh.get_int("CellPVOK") == 1
-    import os
-    if os.environ.get("OMEGA_KEEP_MAXEDGES") == "1":   # (child run of tests/test_00_multirank_gpu.py)
+    if oa.get_option("KeepMaxEdges") == 1:   # (child run of tests/test_00_multirank_gpu.py)
         assert P.mesh.get_int("MaxEdges") == 8
         assert P.mesh.get_int("NIrregularEdges") == 12 * 5      # 5 < MaxEdges - 2: edge-centric list
     else:       # the mesh keeps its tables at the largest valence present, whatever the file's maxEdges
@@ -159,11 +158,10 @@ def test_sphere_meshes_take_the_fast_paths():
 
 
 def test_generic_flags_follow_the_environment():
-    """With OMEGA_FORCE_GENERIC=1 (set by tests/test_00_multirank_gpu.py for a child run) every ring-table
+    """With the option ForceGeneric = 1 (set by tests/test_00_multirank_gpu.py for a child run) every ring-table
     flag is off, so the parity tests of that run exercise the generic kernels; otherwise they are on."""
-    import os
     P = _mk((16, 16, 30e3, 4, 1, {}))
-    want = 0 if os.environ.get("OMEGA_FORCE_GENERIC") == "1" else 1
+    want = 0 if oa.get_option("ForceGeneric") == 1 else 1
     for flag in ("PVChainOK", "CellPVOK", "CellPVFinalOK", "Del2RingOK", "Del2VertOK"):
         assert P.mesh.get_int(flag) == want, flag
 
