@@ -199,7 +199,7 @@ int omg_rccl_destroy(omg_rccl *c);
 int omg_rccl_abort(omg_rccl *c);
 /* what RCCL itself reports: communicator size, this rank, library version code, grouped exchanges issued so far */
 int omg_rccl_info(const omg_rccl *c, int *nranks, int *rank, int *version, int64_t *exchanges);
-/* one grouped exchange on raw device buffers (same argument meaning as omg_transport_fn; byte counts multiples of 8) */
+/* one grouped exchange on raw device buffers (same argument meaning as omg_transport_fn) */
 int omg_rccl_exchange(omg_rccl *c, int n, const int *peers, void *const *send_ptrs, const size_t *send_bytes,
                       void *const *recv_ptrs, const size_t *recv_bytes, void *stream);
 /* route this Halo's exchanges through the communicator (which must outlive the Halo's exchanges) */
@@ -228,6 +228,13 @@ int omg_halo_recv_rows(const omg_halo *h, size_t per_cell, size_t per_edge, size
  * k values of every row are exchanged (row_pitch 0 = compact rows of k) */
 int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
                       void *stream);
+/* the same for the reference's other array types (O/src/base/Halo.h:304-351 rank 1, :324-760 I4 / I8 / R4 / R8, ranks
+ * 1-5): values of elem_bytes bytes (4 or 8).  Rank 1: nt = 1, k = 1, row_pitch = 1; ranks 4 and 5: nt = the product of
+ * the leading extents (the element index is the second-to-last, Halo.h:418-470).  omg_halo_exchange_i4 = elem_bytes 4. */
+int omg_halo_exchange_bytes(omg_halo *h, void *dev_array, int elem_bytes, int nt, int rows_size, int k, int row_pitch,
+                            int elem, void *stream);
+int omg_halo_exchange_i4(omg_halo *h, int32_t *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
+                         void *stream);
 
 /* ---- Measurement / test options (omega_amd/csrc/Tuning.h).  The library never reads the environment: every switch that
  *      changes the kernel structure or the tile geometry is set through this call.  Defaults are what production

@@ -582,8 +582,15 @@ class Halo:
         self._cb = TRANSPORT_FN(_cb)
         _chk(lib().omg_halo_set_transport(self.h, self._cb, None))
 
-    def exchange(self, dev_ptr: int, nt: int, rows_size: int, k: int, elem: int, stream=None, row_pitch: int = 0):
-        _chk(lib().omg_halo_exchange(self.h, C.cast(C.c_void_p(dev_ptr), PD), nt, rows_size, k, row_pitch, elem, _sh(stream)))
+    def exchange(self, dev_ptr: int, nt: int, rows_size: int, k: int, elem: int, stream=None, row_pitch: int = 0,
+                 elem_bytes: int = 8):
+        """Halo::exchangeFullArrayHalo on a raw device array [nt][rows_size][row_pitch or k] of elem_bytes-byte values
+        (8: R8 / I8, 4: I4 / R4); rank 1 is nt = 1, k = 1."""
+        if elem_bytes == 8:
+            _chk(lib().omg_halo_exchange(self.h, C.cast(C.c_void_p(dev_ptr), PD), nt, rows_size, k, row_pitch, elem, _sh(stream)))
+        else:
+            _chk(lib().omg_halo_exchange_bytes(self.h, C.c_void_p(dev_ptr), elem_bytes, nt, rows_size, k, row_pitch, elem,
+                                               _sh(stream)))
 
     def __del__(self):
         try:

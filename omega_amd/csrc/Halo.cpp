@@ -140,18 +140,19 @@ const Halo::Plan &Halo::planFor(const std::vector<Piece> &Pieces) {
    std::vector<int> Key;
    for (const Piece &P : Pieces) {
       Key.push_back((int)P.Elem), Key.push_back(P.NT), Key.push_back(P.RowsSize), Key.push_back(P.K);
-      Key.push_back(P.Pitch);
-      OMEGA_REQUIRE(P.K == Pieces[0].K && P.Pitch == Pieces[0].Pitch && P.Pitch >= P.K,
-                    "Halo: arrays exchanged together must have the same number of levels and row pitch");
+      Key.push_back(P.Pitch), Key.push_back(P.ElemBytes);
+      OMEGA_REQUIRE(P.K == Pieces[0].K && P.Pitch == Pieces[0].Pitch && P.Pitch >= P.K && P.ElemBytes == Pieces[0].ElemBytes,
+                    "Halo: arrays exchanged together must have the same number of levels, row pitch and element size");
+      OMEGA_REQUIRE(P.ElemBytes == 4 || P.ElemBytes == 8, "Halo: element size must be 4 or 8 bytes");
    }
    auto It = Plans.find(Key);
    if (It != Plans.end())
       return It->second;
    Plan Pl;
-   Pl.K = Pieces[0].K, Pl.Pitch = Pieces[0].Pitch;
+   Pl.K = Pieces[0].K, Pl.Pitch = Pieces[0].Pitch, Pl.ElemBytes = Pieces[0].ElemBytes;
    Pl.SendOff.assign(NNghbr, 0), Pl.RecvOff.assign(NNghbr, 0);
    Pl.SendBytes.assign(NNghbr, 0), Pl.RecvBytes.assign(NNghbr, 0);
-   const size_t RowBytes = (size_t)Pl.K * sizeof(Real);
+   const size_t RowBytes = (size_t)Pl.K * Pl.ElemBytes;
    auto Build            = [&](const std::vector<std::vector<I4>> *Lists, std::vector<size_t> &Off,
                     std::vector<size_t> &Bytes, const char *Nm, size_t &NRows) {
       std::vector<I4> Jobs;
@@ -190,7 +191,7 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
    OMEGA_REQUIRE(Transport != nullptr || Peer != nullptr, "Halo: no transport set for a multi-rank exchange");
    OMEGA_REQUIRE(!Pieces.empty() && Pieces.size() <= (size_t)HaloMaxPieces, "Halo: too many arrays in one exchange");
    const Plan &Pl        = planFor(Pieces);
-   const size_t RowBytes = (size_t)Pl.K * sizeof(Real);
+   const size_t RowBytes = (size_t)Pl.K * Pl.ElemBytes;
    ensureBuffers(Pl.NSendRows * RowBytes, Peer ? 0 : Pl.NRecvRows * RowBytes);
    if (Peer)
       OMEGA_REQUIRE(Pl.NRecvRows * RowBytes <= Peer->mailboxBytes(),
@@ -209,7 +210,7 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
    if (HaveLast)
       HIP_CHECK(hipStreamWaitEvent(S, EvLast, 0)); // the shared buffers are free once the previous exchange is done
    // pack: one launch for every neighbour and array (Halo.h:324-414)
-   launchHaloPackAll(static_cast<Real *>(SendBuf->Ptr), B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, Pl.Pitch, S);
+   launchHaloPackAll(SendBuf->Ptr, B, Pl.SendJobs.Ptr, Pl.NSendRows, Pl.K, Pl.Pitch, Pl.ElemBytes, S);
    const int Err = Peer ? Peer->put(NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
                                     Pl.RemoteOff.data(), S)
                         : Transport(TransportCtx, NNghbr, NeighborList.data(), SendPtrs.data(), Pl.SendBytes.data(),
@@ -217,7 +218,7 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
    if (Err != 0)
       return -1;
    // unpack: one launch (Halo.h:566-653)
-   launchHaloUnpackAll(B, reinterpret_cast<const Real *>(RecvBase), Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, S);
+   launchHaloUnpackAll(B, RecvBase, Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, Pl.ElemBytes, S);
    if (Peer && Peer->release(NNghbr, NeighborList.data(), S) != 0)
       return -1;
    HIP_CHECK(hipEventRecord(EvLast, S));
@@ -232,6 +233,20 @@ I4 Halo::exchangeFullArrayHalo(const Array3DReal &A, MeshElement E, hipStream_t 
 }
 I4 Halo::exchangeRaw(Real *Ptr, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S) {
    return exchangePieces({Piece{Ptr, E, NT, RowsSize, K, Pitch > 0 ? Pitch : K}}, S);
+}
+I4 Halo::exchangeRawBytes(void *Ptr, int ElemBytes, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S) {
+   Piece P{Ptr, E, NT, RowsSize, K, Pitch > 0 ? Pitch : K};
+   P.ElemBytes = ElemBytes;
+   return exchangePieces({P}, S);
+}
+I4 Halo::exchangeFullArrayHalo(const Array1DI4 &A, MeshElement E, hipStream_t S) {
+   return exchangeRawBytes(A.Ptr, sizeof(I4), 1, A.Ext[0], 1, 1, E, S);
+}
+I4 Halo::exchangeFullArrayHalo(const Array2DI4 &A, MeshElement E, hipStream_t S) {
+   return exchangeRawBytes(A.Ptr, sizeof(I4), 1, A.Ext[0], A.Ext[1], A.Pitch, E, S);
+}
+I4 Halo::exchangeFullArrayHalo(const Array1DReal &A, MeshElement E, hipStream_t S) {
+   return exchangeRawBytes(A.Ptr, sizeof(Real), 1, A.Ext[0], 1, 1, E, S);
 }
 I4 Halo::exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT, hipStream_t S) {
    std::vector<Piece> P{Piece{H.Ptr, OnCell, 1, H.Ext[0], H.Ext[1], H.Pitch},

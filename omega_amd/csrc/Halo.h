@@ -67,14 +67,22 @@ class Halo : public Registry<Halo> {
    I4 exchangeFullArrayHalo(const Array3DReal &A, MeshElement E, hipStream_t S);
    /// caller-owned raw device array [NT][RowsSize][Pitch] of which K values per row are levels
    I4 exchangeRaw(Real *Ptr, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S);
+   /// the same for the reference's other element types (Halo.h:304-760 packs I4 / I8 / R4 / R8 arrays of rank 1-5): an
+   /// array of ElemBytes-byte values (4 or 8), [NT][RowsSize][Pitch]; rank 1 is NT = 1, K = Pitch = 1; ranks 4 and 5
+   /// fold their leading extents into NT (the element index is always the second-to-last, Halo.h:418-470)
+   I4 exchangeRawBytes(void *Ptr, int ElemBytes, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S);
+   I4 exchangeFullArrayHalo(const Array1DI4 &A, MeshElement E, hipStream_t S);
+   I4 exchangeFullArrayHalo(const Array2DI4 &A, MeshElement E, hipStream_t S);
+   I4 exchangeFullArrayHalo(const Array1DReal &A, MeshElement E, hipStream_t S);
    /// One aggregated message per neighbour: [h on cells][u on edges][tracers on cells].
    I4 exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT, hipStream_t S);
 
  private:
    struct Piece {
-      Real *Ptr;
+      void *Ptr;
       MeshElement Elem;
       int NT, RowsSize, K, Pitch; ///< Pitch: row pitch of the array in values (>= K)
+      int ElemBytes = 8;          ///< bytes per value (8: R8 / I8, 4: I4 / R4)
    };
    /// Everything about an exchange that does not depend on the array pointers: the job tables of the pack and
    /// the unpack kernel (one job = one row of K values: which piece, which row of its [NT*RowsSize][K] plane
@@ -82,7 +90,7 @@ class Halo : public Registry<Halo> {
    /// Message layout per neighbour = the reference's, piece after piece: Buf[(T*NList + I)*K + k]
    /// (Halo.h:344-351, 390-397).
    struct Plan {
-      int K = 0, Pitch = 0;
+      int K = 0, Pitch = 0, ElemBytes = 8;
       size_t NSendRows = 0, NRecvRows = 0;
       Array1DI4 SendJobs, RecvJobs; ///< [NRows][2] = (piece, row)
       std::vector<size_t> SendOff, RecvOff, SendBytes, RecvBytes; ///< per neighbour, bytes

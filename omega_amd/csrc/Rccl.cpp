@@ -68,7 +68,7 @@ int RcclComm::exchange(int N, const int *Peers, void *const *SendPtrs, const siz
       return 1;
    };
    for (int I = 0; I < N; ++I)
-      if (Peers[I] < 0 || Peers[I] >= NRanks || SendBytes[I] % sizeof(double) || RecvBytes[I] % sizeof(double)) {
+      if (Peers[I] < 0 || Peers[I] >= NRanks) {
          LastError = "RcclComm::exchange: bad peer or message size";
          return 1;
       }
@@ -79,10 +79,10 @@ int RcclComm::exchange(int N, const int *Peers, void *const *SendPtrs, const siz
    // inside a group the order only matters for matching several messages between the same pair of ranks
    for (int I = 0; I < N && R == ncclSuccess; ++I)
       if (RecvBytes[I])
-         R = ncclRecv(RecvPtrs[I], RecvBytes[I] / sizeof(double), ncclDouble, Peers[I], C, S);
+         R = ncclRecv(RecvPtrs[I], RecvBytes[I], ncclInt8, Peers[I], C, S);
    for (int I = 0; I < N && R == ncclSuccess; ++I)
       if (SendBytes[I])
-         R = ncclSend(SendPtrs[I], SendBytes[I] / sizeof(double), ncclDouble, Peers[I], C, S);
+         R = ncclSend(SendPtrs[I], SendBytes[I], ncclInt8, Peers[I], C, S);
    const ncclResult_t RE = ncclGroupEnd(); // always close the group
    if (R != ncclSuccess)
       return Fail("ncclSend/ncclRecv", R);

@@ -31,7 +31,7 @@ class RcclComm {
    I8 NExchanges = 0;         ///< grouped exchanges issued so far
 
    /// One grouped exchange: for every i < N receive RecvBytes[i] from Peers[i] into RecvPtrs[i] and send
-   /// SendBytes[i] from SendPtrs[i] to it, all on stream S (bytes are multiples of 8: the payload is doubles).
+   /// SendBytes[i] from SendPtrs[i] to it, all on stream S (messages travel as bytes: R8, I4, ... payloads alike).
    /// Returns 0, or a non-zero code with the RCCL error string in lastError().
    int exchange(int N, const int *Peers, void *const *SendPtrs, const size_t *SendBytes, void *const *RecvPtrs,
                 const size_t *RecvBytes, hipStream_t S);

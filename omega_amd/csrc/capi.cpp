@@ -642,6 +642,20 @@ int omg_halo_exchange(omg_halo *h, double *dev_array, int nt, int rows_size, int
    OMG_CATCH
 }
 
+int omg_halo_exchange_bytes(omg_halo *h, void *dev_array, int elem_bytes, int nt, int rows_size, int k, int row_pitch,
+                            int elem, void *stream) {
+   OMG_TRY
+   OMG_ARG(h && dev_array && (elem_bytes == 4 || elem_bytes == 8) && nt >= 1 && elem >= 0 && elem < 3 && k >= 1 &&
+           (row_pitch == 0 || row_pitch >= k));
+   if (h->H->exchangeRawBytes(dev_array, elem_bytes, nt, rows_size, k, row_pitch, (MeshElement)elem, (hipStream_t)stream) != 0)
+      OMEGA_ABORT("Halo::exchangeFullArrayHalo failed" + h->H->wireError());
+   OMG_CATCH
+}
+int omg_halo_exchange_i4(omg_halo *h, int32_t *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
+                         void *stream) {
+   return omg_halo_exchange_bytes(h, dev_array, 4, nt, rows_size, k, row_pitch, elem, stream);
+}
+
 // ---------------------------------------------------------------- HorzMesh
 int omg_mesh_create(const omg_decomp *d, int nvertlayers, int host_only, omg_mesh **out) {
    OMG_TRY

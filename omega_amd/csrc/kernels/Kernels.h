@@ -148,12 +148,13 @@ void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr,
 /// row j.  The job tables live on the device (Halo::Plan).
 constexpr int HaloMaxPieces = 4;
 struct HaloBases {
-   Real *P[HaloMaxPieces];
+   void *P[HaloMaxPieces];
 };
-/// (buffer rows are compact, K values; array rows have pitch Pitch)
-void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, hipStream_t S);
-void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch,
-                         hipStream_t S);
+/// (buffer rows are compact, K values of ElemBytes (4: I4 / R4, 8: R8 / I8) bytes each; array rows have pitch Pitch values)
+void launchHaloPackAll(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
+                       hipStream_t S);
+void launchHaloUnpackAll(const HaloBases &B, const void *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch,
+                         int ElemBytes, hipStream_t S);
 
 } // namespace OMEGA
 #endif

@@ -432,48 +432,55 @@ void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr,
 // plane stack of piece Jobs[2j].  threadIdx.x walks the level chunks of a row (coalesced on both sides),
 // threadIdx.y the rows of the workgroup.
 template <class T, bool Pack> __global__ void __launch_bounds__(256)
-haloCopyAllKernel(Real *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int K, int Pitch) {
+haloCopyAllKernel(T *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int Pitch) {
+   // (KV, Pitch: row length / row pitch in units of T)
    for (size_t J = (size_t)blockIdx.x * blockDim.y + threadIdx.y; J < NRows; J += (size_t)gridDim.x * blockDim.y) {
       const int Piece  = Jobs[2 * J];
       const size_t Row = (size_t)(unsigned)Jobs[2 * J + 1];
-      Real *A          = B.P[Piece] + Row * Pitch;
-      Real *Bf         = Buf + J * K;
+      T *A             = static_cast<T *>(B.P[Piece]) + Row * Pitch;
+      T *Bf            = Buf + J * KV;
       for (int Kv = threadIdx.x; Kv < KV; Kv += blockDim.x) {
          if (Pack)
-            reinterpret_cast<T *>(Bf)[Kv] = reinterpret_cast<const T *>(A)[Kv];
+            Bf[Kv] = A[Kv];
          else
-            reinterpret_cast<T *>(A)[Kv] = reinterpret_cast<const T *>(Bf)[Kv];
+            A[Kv] = Bf[Kv];
       }
    }
 }
-template <bool Pack>
-static void launchHaloCopyAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch,
-                              hipStream_t S) {
-   if (NRows == 0)
-      return;
-   const int W  = (K % 2 == 0 && Pitch % 2 == 0) ? 2 : 1;
-   const int KV = K / W;
-   int TX       = 1;
+template <class T, bool Pack>
+static void launchHaloCopyT(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int KV, int Pitch, hipStream_t S) {
+   int TX = 1;
    while (TX < KV && TX < 64)
       TX *= 2;
    const int TY  = 256 / TX;
    size_t Blocks = (NRows + TY - 1) / TY;
    if (Blocks > 8192)
       Blocks = 8192;
-   if (W == 2)
-      hipLaunchKernelGGL((haloCopyAllKernel<dv2, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, Buf, B, Jobs, NRows,
-                         KV, K, Pitch);
-   else
-      hipLaunchKernelGGL((haloCopyAllKernel<double, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, Buf, B, Jobs,
-                         NRows, KV, K, Pitch);
+   hipLaunchKernelGGL((haloCopyAllKernel<T, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, static_cast<T *>(Buf), B,
+                      Jobs, NRows, KV, Pitch);
    HIP_CHECK(hipGetLastError());
 }
-void launchHaloPackAll(Real *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, hipStream_t S) {
-   launchHaloCopyAll<true>(Buf, B, Jobs, NRows, K, Pitch, S);
+template <bool Pack>
+static void launchHaloCopyAll(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
+                              hipStream_t S) {
+   if (NRows == 0)
+      return;
+   // the widest unit that divides both the row length and the row pitch: 16, 8 or 4 bytes
+   const size_t RowB = (size_t)K * ElemBytes, PitchB = (size_t)Pitch * ElemBytes;
+   if (RowB % 16 == 0 && PitchB % 16 == 0)
+      launchHaloCopyT<dv2, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 16), (int)(PitchB / 16), S);
+   else if (RowB % 8 == 0 && PitchB % 8 == 0)
+      launchHaloCopyT<double, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 8), (int)(PitchB / 8), S);
+   else
+      launchHaloCopyT<int, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 4), (int)(PitchB / 4), S);
 }
-void launchHaloUnpackAll(const HaloBases &B, const Real *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch,
+void launchHaloPackAll(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
+                       hipStream_t S) {
+   launchHaloCopyAll<true>(Buf, B, Jobs, NRows, K, Pitch, ElemBytes, S);
+}
+void launchHaloUnpackAll(const HaloBases &B, const void *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
                          hipStream_t S) {
-   launchHaloCopyAll<false>(const_cast<Real *>(Buf), B, Jobs, NRows, K, Pitch, S);
+   launchHaloCopyAll<false>(const_cast<void *>(Buf), B, Jobs, NRows, K, Pitch, ElemBytes, S);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -153,6 +153,22 @@ def main():
                 host_exchange(arr if nt > 1 else arr[0], elem)
             assert np.array_equal(arr, ref), f"rank {a.rank}: halo exchange mismatch elem {elem} nt {nt}"
 
+    # the reference's other element types (HaloTest.cpp:41-100 runs I4 / I8 / R4 / R8, rank 1-5): I4 rank 1 (the global ids
+    # themselves), I4 rank 2 with an odd row length, R8 rank 1, I4 rank 3 -- through the same job-table kernels
+    if gpu:
+        for elem in (0, 1, 2):
+            for dtype, nt, k in ((np.int32, 1, 1), (np.int32, 1, 3), (np.float64, 1, 1), (np.int32, 2, 5), (np.float32, 1, 2)):
+                ref = np.zeros((nt, sizes[elem], k), dtype=dtype)
+                for t in range(nt):
+                    ref[t, : nall[elem], :] = ids[elem][: nall[elem], None] * 8 + t * 3 + np.arange(k)[None, :]
+                arr = ref.copy()
+                arr[:, owned[elem]: nall[elem], :] = -7
+                buf = oa.DeviceBuffer(arr)
+                halo.exchange(buf.ptr, nt, sizes[elem], k, elem, elem_bytes=arr.itemsize)
+                oa.device_synchronize()
+                got = buf.to_host()
+                assert np.array_equal(got, ref), f"rank {a.rank}: halo exchange mismatch elem {elem} {dtype.__name__} nt {nt} k {k}"
+
     # ---------------- (b) time stepping: partitioned run vs single-rank oracle ----------------
     okind = {"RungeKutta4": "rk4", "RungeKutta2": "rk2", "Forward-Backward": "fb"}[a.stepper]
     Mg = O.Mesh.single_rank(g, K)
@@ -216,7 +232,7 @@ def main():
     note = ""
     if wire is not None:
         info = wire.info()
-        assert info["status"] == 0 and info["exchanges"] >= 6 + a.steps, info
+        assert info["status"] == 0 and info["exchanges"] >= 6 + 15 + a.steps, info
         note = f", peer wire: {info['exchanges']} exchanges"
     dist.barrier()          # every rank's GPU work is complete (device_synchronize above): mailboxes may go
     if wire is not None:
