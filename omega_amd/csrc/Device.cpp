@@ -30,6 +30,7 @@ const OptionName OptionTable[] = {
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},
+    {"NarrowTables", &TuningOptions::NarrowTables},
     {"Graphs", &TuningOptions::Graphs},
 };
 } // namespace

@@ -425,9 +425,76 @@ void HorzMesh::buildCoefficientTables() {
    buildDel2Tables();
    buildCellL1Tables();
    buildBandLists((I4)NCellsHaloH.size());
+   buildNarrowTables();
    // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
    if (tuning().ForceGeneric == 1)
       W.PVChainOK = W.CellPVOK = W.CellPVFinalOK = W.Del2RingOK = W.Del2VertOK = W.CellL1OK = 0;
+}
+
+// ---- narrow tables (see HorzMesh.h: narrowView) ----
+namespace {
+// Dst[r][i][j] = Src[r][i][j] for i < W1n, j < W2n (Src is [Rows][W1][W2])
+template <class T>
+__global__ void narrowColsKernel(T *Dst, const T *Src, size_t Rows, int W1, int W2, int W1n, int W2n) {
+   const size_t N = Rows * (size_t)W1n * W2n;
+   for (size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x; I < N; I += (size_t)gridDim.x * blockDim.x) {
+      const size_t R = I / ((size_t)W1n * W2n);
+      const int Rem = (int)(I - R * (size_t)W1n * W2n), A = Rem / W2n, B = Rem - A * W2n;
+      Dst[I] = Src[(R * W1 + A) * W2 + B];
+   }
+}
+} // namespace
+
+void HorzMesh::buildNarrowTables() {
+   MeshView &W = View;
+   W.NWideCells = 0, W.WideCells = nullptr;
+   const int ME = MaxEdges;
+   std::vector<I4> Wide;
+   for (int C = 0; C < NCellsAll; ++C)
+      if (NEdgesOnCellH(C) == ME)
+         Wide.push_back(C);
+   WideCells = Array1DI4("WideCells", (int)std::max<size_t>(Wide.size(), 1));
+   if (!Wide.empty())
+      OMEGA::copyToDevice(WideCells.Ptr, Wide.data(), Wide.size() * sizeof(I4));
+   W.NWideCells = (I4)Wide.size(), W.WideCells = WideCells.Ptr;
+   HasNarrow = false;
+   // worth it (and possible) when the sweeps already run at MaxEdges-1 and every ring table is valid; the kernels are
+   // instantiated for 5..8 slots
+   if (!(tuning().NarrowTables != 0 && W.DomM1 && ME >= 6 && ME <= 8 && W.CellL1OK && W.CellPVOK && W.CellPVFinalOK &&
+         W.Del2RingOK && W.Del2VertOK))
+      return; // (no wide cell at all -- tables kept at a file's width by the option KeepMaxEdges -- is fine too)
+   const int MN = ME - 1;
+   Narrow       = View;
+   Narrow.MaxEdges = MN; // (MaxEdges2 and every per-edge / per-vertex table stay as they are: not cell-slot tables)
+   auto Cut = [&](auto *&Field, int Inner, int InnerNew) {
+      using T = std::remove_const_t<std::remove_pointer_t<std::remove_reference_t<decltype(Field)>>>;
+      const size_t Rows = (size_t)NCellsSize;
+      auto Buf          = std::make_shared<DeviceBuffer>(Rows * MN * InnerNew * sizeof(T));
+      const size_t N    = Rows * MN * InnerNew;
+      const unsigned Blocks = (unsigned)std::min<size_t>((N + 255) / 256, 65535);
+      hipLaunchKernelGGL(narrowColsKernel<T>, dim3(Blocks), dim3(256), 0, nullptr, static_cast<T *>(Buf->Ptr),
+                         const_cast<const T *>(Field), Rows, ME, Inner, MN, InnerNew);
+      HIP_CHECK(hipGetLastError());
+      NarrowBufs.push_back(Buf);
+      Field = static_cast<const T *>(Buf->Ptr);
+   };
+   MeshView &N = Narrow;
+   Cut(N.EdgesOnCell, 1, 1), Cut(N.NbrFlagOnCell, 1, 1), Cut(N.KECoefOnCell, 1, 1), Cut(N.DivCoefOnCell, 1, 1);
+   Cut(N.DvSignOnCell, 1, 1), Cut(N.Del2TrCoefOnCell, 1, 1), Cut(N.Del2TrCoefSOnCell, 1, 1), Cut(N.MaskDvSignOnCell, 1, 1);
+   Cut(N.Diff2CoefOnCell, 1, 1), Cut(N.Diff2CoefSOnCell, 1, 1), Cut(N.Diff4CoefOnCell, 1, 1), Cut(N.Diff4CoefSOnCell, 1, 1);
+   Cut(N.SpokeOnCell, 1, 1), Cut(N.VortSelOnCell, 1, 1), Cut(N.VertRingOnCell, 1, 1), Cut(N.RingVertOnCell, 1, 1);
+   Cut(N.PVRoleOnCell, 1, 1), Cut(N.RingSignOnCell, 1, 1), Cut(N.InvDcOnCell, 1, 1), Cut(N.Del2GradMaskSOnCell, 1, 1);
+   Cut(N.Del2CurlCoefOnCell, 1, 1), Cut(N.CellsOnCell, 1, 1), Cut(N.VerticesOnCell, 1, 1), Cut(N.EdgeSignOnCell, 1, 1);
+   Cut(N.KiteCoefOnCell, 3, 3), Cut(N.VortCoefOnCell, 3, 3), Cut(N.CellsOnEdgeOnCell, 2, 2);
+   Cut(N.PVWeightOnCell, ME - 1, MN - 1);
+   HIP_CHECK(hipDeviceSynchronize());
+   // valences as the narrow sweeps see them: MN is "MaxEdges" (the wide view's M1 list), MN-1 its M1 (the wide M2)
+   N.NRingCellsM0 = W.NRingCellsM1, N.RingCellsM0 = W.RingCellsM1;
+   N.NRingCellsM1 = W.NRingCellsM2, N.RingCellsM1 = W.RingCellsM2;
+   N.NRingCellsM2 = 0;
+   N.DomM1        = 0;
+   N.NWideCells   = 0; // (the list lives in the wide view)
+   HasNarrow      = true;
 }
 
 // Band / interior split of the local cells for overlapping a halo exchange with interior work

@@ -94,6 +94,9 @@ struct MeshView {
    I4 NRingCellsM0, NRingCellsM1, NRingCellsM2;  // cells of valence MaxEdges, MaxEdges-1, MaxEdges-2 (with regular edges)
    const I4 *RingCellsM0, *RingCellsM1, *RingCellsM2;
    I4 DomM1; ///< 1: most cells have MaxEdges-1 edges (a mesh of hexagons with a few heptagons): the full sweeps take that valence
+   // ---- narrow tables (HorzMesh::buildNarrowTables): the cells of the widest valence as a list ----
+   I4 NWideCells;          ///< cells with MaxEdges edges (wide view), 0 in the narrow view
+   const I4 *WideCells;
    // ---- vertex quantities evaluated from the cell side (valid when CellL1OK; HorzMesh::buildCellL1Tables) ----
    // Ring vertex r of cell c (shared by edge slots r and r+1) touches the cells {c, across slot r, across slot r+1}
    // and the edges {slot r, slot r+1, "spoke" = the edge between the two neighbours}.  A thread that already holds
@@ -160,6 +163,13 @@ class HorzMesh : public Registry<HorzMesh> {
    void setFVertex(const Real *HostValues /* NVerticesSize */);
 
    const MeshView &view() const { return View; }
+   /// The same mesh with every per-(cell, slot) table stored MaxEdges-1 wide (rows of the cells with MaxEdges edges are
+   /// truncated and must be skipped: view().WideCells lists them), or nullptr.  Built when most cells have MaxEdges-1
+   /// edges and every ring table is valid -- a real MPAS mesh: hexagons, 12+ pentagons, a few heptagons.  The fused RHS
+   /// then sweeps the 6-wide tables with the 6-slot kernels and runs the heptagons through list launches of the 7-slot
+   /// kernels on the wide tables (components/omega/src/base/Decomp.cpp:2043-2064: the reference compacts NEdgesOnCell
+   /// per cell, not per mesh).
+   const MeshView *narrowView() const { return HasNarrow ? &Narrow : nullptr; }
 
  private:
    void compactMaxEdges();
@@ -170,6 +180,11 @@ class HorzMesh : public Registry<HorzMesh> {
    void buildCoefficientTables();
 
    MeshView View{};
+   MeshView Narrow{};
+   bool HasNarrow = false;
+   void buildNarrowTables();
+   std::vector<std::shared_ptr<DeviceBuffer>> NarrowBufs; ///< the narrow copies of the per-(cell, slot) tables
+   Array1DI4 WideCells;
    // coefficient tables (device)
    Array1DReal InvAreaCell, InvDcEdge, InvDvEdge, InvDvEdgeDel2;
    Array2DReal DvSignOnCell, DivCoefOnCell, KECoefOnCell, MaskDvSignOnCell, Del2TrCoefOnCell, Diff2CoefOnCell,

@@ -134,7 +134,7 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
       EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
    return launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                          NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, nullptr,
-                         EdgeScratch.Ptr, &Stage);
+                         EdgeScratch.Ptr, &Stage, Mesh->narrowView());
 }
 
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
@@ -165,7 +165,7 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
       auto Launch        = [&]() {
          launchFusedRHS(Mesh->view(), NVertLayers, NTracers, P, Aux->ptrs(), LayerThicknessTend.Ptr,
                         NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
-                        EdgeScratch.Ptr);
+                        EdgeScratch.Ptr, nullptr, Mesh->narrowView());
       };
       // wind forcing reads the stress arrays through a non-tile kernel too, still plain launches: capturable
       if (UseGraphs && !Ev && !CustomThicknessTend && !CustomVelocityTend) {

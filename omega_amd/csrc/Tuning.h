@@ -29,6 +29,7 @@ struct TuningOptions {
    int ForceGeneric = 0; ///< clear every ring-table flag: all kernels in their generic form
    int KeepMaxEdges = 0; ///< keep the mesh file's maxEdges as the table width
    int DomValence   = 1; ///< full sweeps at the valence most cells have
+   int NarrowTables = 1; ///< hexagon-dominant meshes with heptagons: second, MaxEdges-1 wide set of cell tables
    // ---- HIP-graph replay: -1 = as each object's UseGraphs says, 0 = never, 1 = default on
    int Graphs = -1;
 };

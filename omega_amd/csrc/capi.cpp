@@ -694,6 +694,8 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
                                         {"DomM1", W.DomM1},
+                                        {"NWideCells", W.NWideCells},
+                                        {"NarrowTables", M.narrowView() ? 1 : 0},
                                         {"Del2RingOK", W.Del2RingOK},
                                         {"Del2VertOK", W.Del2VertOK},
                                         {"NBandCells", W.NBandCells},

@@ -195,13 +195,14 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
    const Real *H, *U, *Tr;
    Real *KE, *Div, *HTend, *Del2Tr;
    StageEpi E{}; // thickness stage update (EPI)
+   const int *List = nullptr; // optional cell list (the wide cells of a mesh with narrow tables: launchFusedT)
    struct Lds {
       Real *KEC, *DivC, *DvS, *D2T, *InvA;
-      int *Edge, *NbrF;
+      int *Edge, *NbrF, *N;
    };
    size_t ldsBytes(int Tile) const {
       return ldsRound8(sizeof(Real) * Tile * TME) * 4 + ldsRound8(sizeof(Real) * Tile) +
-             ldsRound8(sizeof(int) * Tile * TME) * 2;
+             ldsRound8(sizeof(int) * Tile * TME) * 2 + ldsRound8(sizeof(int) * Tile);
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
       LdsCarver C{Ptr};
@@ -213,11 +214,14 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
       L.InvA = C.take<Real>(Tile);
       L.Edge = C.take<int>(Tile * TME);
       L.NbrF = C.take<int>(Tile * TME);
+      L.N    = C.take<int>(Tile);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
+         const int Cl   = I / TME;
+         const int C    = List ? List[First + Cl] : First + Cl;
+         const size_t G = (size_t)C * TME + (I - Cl * TME);
          L.KEC[I]       = M.KECoefOnCell[G];
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.DvS[I]       = M.DvSignOnCell[G];
@@ -225,10 +229,16 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
          L.Edge[I]      = M.EdgesOnCell[G];
          L.NbrF[I]      = M.NbrFlagOnCell[G];
       }
-      for (int I = Tid; I < Cnt; I += NThr)
-         L.InvA[I] = M.InvAreaCell[First + I];
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int C = List ? List[First + I] : First + I;
+         L.InvA[I]   = M.InvAreaCell[C];
+         L.N[I]      = M.NEdgesOnCell[C];
+      }
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      if (L.N[Le] > TME)
+         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      const int ICell       = List ? List[IElem] : IElem;
       const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
       const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
       const Real InvA       = L.InvA[Le];
@@ -316,6 +326,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
    const Real *H, *U, *Tr;
    Real *KE, *Div, *HTend, *Del2Tr, *RelVortV, *InvThickV, *Partial;
    StageEpi E{}; // thickness stage update (EPI)
+   const int *List = nullptr; // optional cell list (the wide cells of a mesh with narrow tables: launchFusedT)
    struct Lds {
       Real *KEC, *DivC, *DvS, *D2T, *InvA, *Wt, *FV, *KC, *VC;
       int *Edge, *NbrF, *Spoke, *Sel, *Ring, *Role, *N;
@@ -348,15 +359,16 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
+         const int Cl = I / TME, Jl = I - Cl * TME;
+         const int C  = List ? List[First + Cl] : First + Cl;
+         const size_t G = (size_t)C * TME + Jl;
          L.KEC[I]       = M.KECoefOnCell[G];
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.DvS[I]       = M.DvSignOnCell[G];
          L.D2T[I]       = Fast ? M.Del2TrCoefSOnCell[G] : M.Del2TrCoefOnCell[G];
          // slot N of a cell with N < TME edges repeats slot 0 (its coefficients are zero, so it adds exact zeros to the
          // cell sums) -- the ring code below then finds "the slot after N-1" without a wrap-around select
-         const int Cl   = I / TME, Jl = I - Cl * TME;
-         const size_t G0 = (Jl == M.NEdgesOnCell[First + Cl]) ? (size_t)(First + Cl) * TME : G;
+         const size_t G0 = (Jl == M.NEdgesOnCell[C]) ? (size_t)C * TME : G;
          L.Edge[I]      = M.EdgesOnCell[G0];
          L.NbrF[I]      = M.NbrFlagOnCell[G0];
          L.Spoke[I]     = M.SpokeOnCell[G];
@@ -365,22 +377,32 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
          L.FV[I]        = M.FVertex[M.VertRingOnCell[G]];
          L.Role[I]      = M.PVRoleOnCell[G];
       }
-      for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
-         L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
+      for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
+         const int Cl = I / (TME * TM1);
+         const int C  = List ? List[First + Cl] : First + Cl;
+         L.Wt[I]      = M.PVWeightOnCell[(size_t)C * TME * TM1 + (I - Cl * TME * TM1)];
+      }
       for (int I = Tid; I < Cnt * TME * 3; I += NThr) {
-         L.KC[I] = M.KiteCoefOnCell[(size_t)First * TME * 3 + I];
-         L.VC[I] = M.VortCoefOnCell[(size_t)First * TME * 3 + I];
+         const int Cl   = I / (TME * 3);
+         const int C    = List ? List[First + Cl] : First + Cl;
+         const size_t G = (size_t)C * TME * 3 + (I - Cl * TME * 3);
+         L.KC[I]        = M.KiteCoefOnCell[G];
+         L.VC[I]        = M.VortCoefOnCell[G];
       }
       for (int I = Tid; I < Cnt; I += NThr) {
-         L.InvA[I] = M.InvAreaCell[First + I];
-         L.N[I]    = M.NEdgesOnCell[First + I];
+         const int C = List ? List[First + I] : First + I;
+         L.InvA[I]   = M.InvAreaCell[C];
+         L.N[I]      = M.NEdgesOnCell[C];
       }
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      const int N = L.N[Le];
+      if (N > TME)
+         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      const int ICell       = List ? List[IElem] : IElem;
       const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
       const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
       const Real InvA       = L.InvA[Le];
-      const int N           = L.N[Le];
       const unsigned OffS   = rowOff<T>(ICell, K, Kv);
       unsigned OffN[TME], OffE[TME];
       bool IsC0[TME];
@@ -654,11 +676,14 @@ template <int TME> struct Del2CellRingBody {
    int K;
    const Real *Div, *RelVort;
    Real *Del2Div;
+   const int *List = nullptr; // optional cell list (the wide cells of a mesh with narrow tables: launchFusedT)
    struct Lds {
       Real *DivC, *InvDc, *GradS, *CurlC;
-      int *Nbr, *Ring;
+      int *Nbr, *Ring, *N;
    };
-   size_t ldsBytes(int Tile) const { return ldsRound8(sizeof(Real) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile * TME) * 2; }
+   size_t ldsBytes(int Tile) const {
+      return ldsRound8(sizeof(Real) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile * TME) * 2 + ldsRound8(sizeof(int) * Tile);
+   }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
       LdsCarver C{Ptr};
       Lds L;
@@ -668,11 +693,14 @@ template <int TME> struct Del2CellRingBody {
       L.CurlC = C.take<Real>(Tile * TME);
       L.Nbr   = C.take<int>(Tile * TME);
       L.Ring  = C.take<int>(Tile * TME);
+      L.N     = C.take<int>(Tile);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const size_t G = (size_t)First * TME + I;
+         const int Cl   = I / TME;
+         const int C    = List ? List[First + Cl] : First + Cl;
+         const size_t G = (size_t)C * TME + (I - Cl * TME);
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.InvDc[I]     = M.InvDcOnCell[G];
          L.GradS[I]     = M.Del2GradMaskSOnCell[G];
@@ -680,8 +708,13 @@ template <int TME> struct Del2CellRingBody {
          L.Nbr[I]       = M.NbrFlagOnCell[G] & 0x3fffffff;
          L.Ring[I]      = M.VertRingOnCell[G];
       }
+      for (int I = Tid; I < Cnt; I += NThr)
+         L.N[I] = M.NEdgesOnCell[List ? List[First + I] : First + I];
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      if (L.N[Le] > TME)
+         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      const int ICell = List ? List[IElem] : IElem;
       T Dn[TME], Rv[TME];
 #pragma unroll
       for (int J = 0; J < TME; ++J) {
@@ -1465,6 +1498,8 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
       }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      if (L.N[Le] > TME)
+         return; // a cell wider than these tables: it has its own (list) launches on the wide tables
       const int ICell = List ? List[IElem] : IElem;
       const Real Grav = 9.80665; // TendencyTerms.h:176
       unsigned OffE[TME], OffN[TME];
@@ -1720,14 +1755,14 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
    const Real *H, *U, *Tr, *Del2Tr;
    Real *Tend;
    StageEpi E{};              // tracer stage update (EPI)
-   const int *List = nullptr; // EPI only: optional cell list (band / interior launches of an overlapped exchange)
+   const int *List = nullptr; // optional cell list (band / interior launches of an overlapped exchange; wide cells)
    struct Lds {
       Real *MDvS, *Df2, *Df4, *InvA;
-      int *Edge, *NbrF;
+      int *Edge, *NbrF, *N;
    };
    size_t ldsBytes(int Tile) const {
       return ldsRound8(sizeof(Real) * Tile * TME) * 3 + ldsRound8(sizeof(Real) * Tile) +
-             ldsRound8(sizeof(int) * Tile * TME) * 2;
+             ldsRound8(sizeof(int) * Tile * TME) * 2 + ldsRound8(sizeof(int) * Tile);
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
       LdsCarver C{Ptr};
@@ -1738,12 +1773,13 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
       L.InvA = C.take<Real>(Tile);
       L.Edge = C.take<int>(Tile * TME);
       L.NbrF = C.take<int>(Tile * TME);
+      L.N    = C.take<int>(Tile);
       return L;
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
          const int Le   = I / TME;
-         const int C    = (EPI && List) ? List[First + Le] : First + Le;
+         const int C    = List ? List[First + Le] : First + Le;
          const size_t G = (size_t)C * TME + (I - Le * TME);
          L.MDvS[I]      = M.MaskDvSignOnCell[G];
          L.Df2[I]       = Fast ? M.Diff2CoefSOnCell[G] : M.Diff2CoefOnCell[G];
@@ -1751,11 +1787,16 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
          L.Edge[I]      = M.EdgesOnCell[G];
          L.NbrF[I]      = M.NbrFlagOnCell[G];
       }
-      for (int I = Tid; I < Cnt; I += NThr)
-         L.InvA[I] = M.InvAreaCell[(EPI && List) ? List[First + I] : First + I];
+      for (int I = Tid; I < Cnt; I += NThr) {
+         const int C = List ? List[First + I] : First + I;
+         L.InvA[I]   = M.InvAreaCell[C];
+         L.N[I]      = M.NEdgesOnCell[C];
+      }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
-      const int ICell     = (EPI && List) ? List[IElem] : IElem;
+      if (L.N[Le] > TME)
+         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      const int ICell     = List ? List[IElem] : IElem;
       const bool TrUpwind = Fast ? false : (P.FluxTracerUpwind != 0);
       const bool AdvOn = Fast ? true : (P.TracerHorzAdvTendencyEnable != 0);
       const bool DiffOn = Fast ? true : (P.TracerDiffTendencyEnable != 0);
@@ -1888,7 +1929,13 @@ bool fusedRHSSupported(const MeshView &M, int K) {
 template <int TME, bool Fast, int ND = TME>
 static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
                          Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                         hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage) {
+                         hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage, const MeshView *Wide = nullptr) {
+   // Wide != nullptr: M is the mesh's NARROW view (cell tables TME wide) and *Wide the full-width one; the cells with
+   // TW = TME+1 edges (Wide->WideCells: the heptagons of a hexagon mesh) are skipped by every sweep over M and run
+   // through list launches of the TW-slot bodies on *Wide, level by level.
+   constexpr int TW       = TME < 8 ? TME + 1 : TME;
+   constexpr bool CanWide = ND == TME && TME < 8;
+   const I4 NWide         = (CanWide && Wide) ? Wide->NWideCells : 0;
    constexpr int NA     = ND == TME ? TME - 1 : TME;
    const I4 NMain       = ND == TME ? M.NRingCellsM0 : M.NRingCellsM1; // cells of the sweeps' valence
    const I4 NOther      = ND == TME ? M.NRingCellsM1 : M.NRingCellsM0; // cells of valence NA (list launches)
@@ -1925,7 +1972,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    FusedKernelNames[0]        = MergeL1 ? "" : "VortVertexBody";
    FusedKernelNames[1]        = MergeL1 ? "FusedCellL1PVBody" : "FusedCell1Body";
    if (!MergeL1)
-      launchVertexAuxState1(M, K, A, H, U, S, /*StoreNorm*/ !CellCentric, /*StoreInv*/ CellCentric);
+      launchVertexAuxState1(Wide ? *Wide : M, K, A, H, U, S, /*StoreNorm*/ !CellCentric, /*StoreInv*/ CellCentric);
    Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    bool Cell1Done = false;
@@ -1935,6 +1982,16 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          FusedCellL1PVBody<TME, Fast, EP, ND> B{M,  K,  NT,    P,      DoDel2Tr,        H,
                                             U,  Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
                                             A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
+         if constexpr (CanWide) {
+            if (NWide > 0) { // the wide cells' level-1 work rides along: same body, TW slots, wide tables, cell list
+               FusedCellL1PVBody<TW, Fast, EP, TW> Bw{*Wide, K,  NT,    P,      DoDel2Tr,        H,
+                                                       U,     Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
+                                                       A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
+               Bw.List = Wide->WideCells;
+               launchTileV(K, S, B, M.NCellsAll, Bw, NWide);
+               return;
+            }
+         }
          launchTile(B, M.NCellsAll, K, S);
       };
       if constexpr (Fast) {
@@ -1960,8 +2017,27 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                   A.Del2TracersCell};
       launchTile(B, M.NCellsAll, K, S);
    }
+   if constexpr (CanWide) {
+      if (NWide > 0 && !MergeL1) { // the wide cells' level-1 work (merged kernel: launched together with the sweep above)
+         auto WideL1 = [&](auto Epi) {
+            constexpr bool EP = decltype(Epi)::value;
+            FusedCell1Body<TW, Fast, EP> B{*Wide, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell,
+                                           HTend, A.Del2TracersCell, EH};
+            B.List = Wide->WideCells;
+            launchTile(B, NWide, K, S);
+         };
+         if constexpr (Fast) {
+            if (Stage)
+               WideL1(std::true_type{});
+            else
+               WideL1(std::false_type{});
+         } else {
+            WideL1(std::false_type{});
+         }
+      }
+   }
    if (P.WindForcingTendencyEnable)
-      launchEdgeAuxState1(M, A, P.WindInterpIsotropic, S);
+      launchEdgeAuxState1(Wide ? *Wide : M, A, P.WindInterpIsotropic, S);
    Pacer::stop("Tend:fused:L1", 2);
    // L2 (only the del4 term consumes it): replaces AuxState:edgeAuxState3 (Del2Edge), cellAuxState2, vertexAuxState2
    Pacer::start("Tend:fused:L2[AuxState:vertexAuxState2,cellAuxState2]", 2);
@@ -1969,12 +2045,23 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // independent sweeps share a launch (KernelCommon.h: tileKernel2); option Pair = 0 launches them one by one
    const int PairEnv = Tn.Pair;
    const bool PairL2        = PairEnv && P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.Del2VertOK;
+   bool WideL2Done          = false;
    FusedKernelNames[2] = FusedKernelNames[3] = "";
    if (PairL2) {
       FusedKernelNames[2] = "Del2CellRingBody+Del2VertexSelBody";
       Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
       Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
-      launchTile2(BC, M.NCellsAll, BV, M.NVerticesAll, K, S);
+      bool Launched = false;
+      if constexpr (CanWide) {
+         if (NWide > 0) {
+            Del2CellRingBody<TW> BW{*Wide, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+            BW.List = Wide->WideCells;
+            launchTileV(K, S, BC, M.NCellsAll, BV, M.NVerticesAll, BW, NWide);
+            Launched = WideL2Done = true;
+         }
+      }
+      if (!Launched)
+         launchTile2(BC, M.NCellsAll, BV, M.NVerticesAll, K, S);
    } else if (P.VelHyperDiffTendencyEnable) {
       FusedKernelNames[2] = M.Del2RingOK ? "Del2CellRingBody" : "FusedDel2CellBody";
       if (M.Del2RingOK) {
@@ -1996,6 +2083,13 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          launchTile(BV, M.NVerticesAll, K, S);
       }
    }
+   if constexpr (CanWide) {
+      if (NWide > 0 && P.VelHyperDiffTendencyEnable && !WideL2Done) { // (a narrow view implies the ring form)
+         Del2CellRingBody<TW> BC{*Wide, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+         BC.List = Wide->WideCells;
+         launchTile(BC, NWide, K, S);
+      }
+   }
    Pacer::stop("Tend:fused:L2", 2);
    // L3: replaces Tend:potientialVortHAdv, KEGrad, SSHGrad, velocityDiffusion, velocityHyperDiff, windForcing, bottomDrag,
    // AuxState:edgeAuxState4 (HTracersEdge) and Tend:tracerHorzAdv, tracerDiffusion, tracerHyperDiff
@@ -2011,6 +2105,11 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // the side-1 PV + velocity kernel and the tracer kernel are independent: their main sweeps share a launch
    const bool PairL3 = PairEnv && Fast && EdgeMode == 0 && M.CellPVOK && EdgeScratch && P.PVTendencyEnable &&
                        FuseFinalEnv && M.CellPVFinalOK && NT > 0 && NMain > 0;
+   // option FuseL3 = 0: the plain RHS keeps the paired launch too (A/B measurements)
+   const bool FuseL3 = PairL3 && Tn.FuseL3 && !Stage;
+   // narrow tables, plain RHS: the wide cells' level-3 work (one thread does velocity + tracers, as the sweep's) and the
+   // final pass of the other valence's list join the sweep's launch instead of being launches of their own
+   const bool FoldL3 = CanWide && NWide > 0 && FuseL3;
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
@@ -2032,6 +2131,13 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             CellPVBody<TME, Fast, 0, NM2> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                              M.RingCellsM2};
             launchTile(Bm, M.NRingCellsM2, K, S);
+         }
+         if constexpr (CanWide) {
+            if (NWide > 0 && !MergeL1) {
+               CellPVBody<TW, Fast, 0, TW> Bw{*Wide, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                              Wide->WideCells};
+               launchTile(Bw, NWide, K, S);
+            }
          }
          Mark(5);
          Marked5 = true;
@@ -2066,7 +2172,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                      launchTile(B1, M.NCellsAll, K, S);
                   }
                }
-               if (NOther > 0) {
+               if (NOther > 0 && !FoldL3) {
                   CellPVFinalBody<TME, NM1, EP> Bm{B1.M,       B1.K,   B1.P,    B1.H,       B1.U,
                                                    B1.RelVortV, B1.InvThickV, B1.Partial, B1.RelVort, B1.KE,
                                                    B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, OtherCells, EU};
@@ -2077,6 +2183,14 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                    B1.RelVortV, B1.InvThickV, B1.Partial, B1.RelVort, B1.KE,
                                                    B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, M.RingCellsM2, EU};
                   launchTile(Bm, M.NRingCellsM2, K, S);
+               }
+               if constexpr (CanWide) {
+                  if (NWide > 0 && !FoldL3) {
+                     CellPVFinalBody<TW, TW, EP> Bw{*Wide,      B1.K,   B1.P,    B1.H,       B1.U,
+                                                    B1.RelVortV, B1.InvThickV, B1.Partial, B1.RelVort, B1.KE,
+                                                    B1.Div,     B1.Del2Div, B1.Del2RelVort, B1.Tend, Wide->WideCells, EU};
+                     launchTile(Bw, NWide, K, S);
+                  }
                }
             };
             // the interior part of the split sweep, launched at the end of the L3 phase
@@ -2127,6 +2241,13 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 M.RingCellsM2};
                launchTile(Bm, M.NRingCellsM2, K, S);
             }
+            if constexpr (CanWide) {
+               if (NWide > 0) {
+                  CellPVBody<TW, Fast, 1, TW> Bw{*Wide, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                 Wide->WideCells};
+                  launchTile(Bw, NWide, K, S);
+               }
+            }
          }
       }
       if (!Finished) {
@@ -2149,6 +2270,16 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       if (M.NIrregularEdges > 0) {
          auto LaunchList = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
+            if constexpr (CanWide) {
+               if (Wide) { // (the chain tables are per edge and MaxEdges of the WIDE view wide)
+                  FusedEdgeChainBody<TW, Fast, EP, true> B{*Wide, K, P, H, U, A.RelVortVertex, A.InvThickVertex, nullptr,
+                                                           A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
+                                                           A.Del2RelVortVertex, A.NormalStressEdge, UTend,
+                                                           M.IrregularEdges, EU};
+                  launchTile(B, M.NIrregularEdges, K, S);
+                  return;
+               }
+            }
             FusedEdgeChainBody<TME, Fast, EP, true> B{M,
                                                       K,
                                                       P,
@@ -2199,12 +2330,27 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (!Marked5)
       Mark(5);
    Mark(6);
-   // option FuseL3 = 0: the plain RHS keeps the paired launch too (A/B measurements)
-   const int FuseL3Env = Tn.FuseL3;
-   const bool FuseL3          = PairL3 && FuseL3Env && !Stage;
    FusedKernelNames[6]        = FuseL3   ? "CellPVFinalTracerBody"
                                 : PairL3 ? "CellPVFinalBody+FusedCell3Body"
                                          : (NT > 0 ? "FusedCell3Body" : "");
+   if constexpr (CanWide) {
+      if (NWide > 0 && NT > 0 && !FoldL3) {
+         auto WideTr = [&](auto Epi) {
+            constexpr bool EP = decltype(Epi)::value;
+            FusedCell3Body<TW, Fast, EP> B{*Wide, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            B.List = Wide->WideCells;
+            launchTile(B, NWide, K, S);
+         };
+         if constexpr (Fast) {
+            if (Stage)
+               WideTr(std::true_type{});
+            else
+               WideTr(std::false_type{});
+         } else {
+            WideTr(std::false_type{});
+         }
+      }
+   }
    bool AfterBandCalled = false;
    if (PairL3) {
       if constexpr (Fast) {
@@ -2232,6 +2378,20 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                   CellPVFinalTracerBody<TME, ND> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                 A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                 A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
+                  if constexpr (CanWide) {
+                     if (FoldL3) {
+                        CellPVFinalTracerBody<TW, TW> BW{*Wide, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                         A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
+                                                         A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
+                        BW.List = Wide->WideCells;
+                        constexpr int NM1f = ND == TME ? TME - 1 : TME;
+                        CellPVFinalBody<TME, NM1f, false> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                              A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
+                                                              A.Del2DivCell, A.Del2RelVortVertex, UTend, OtherCells, EU};
+                        launchTileV(K, S, BF, M.NCellsAll, BW, NWide, Bm, NOther);
+                        return;
+                     }
+                  }
                   launchTile(BF, M.NCellsAll, K, S);
                   return;
                }
@@ -2295,10 +2455,30 @@ static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *Ed
 
 bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S, hipEvent_t *Ev,
-                    Real *EdgeScratch, const StageUpdate *Stage) {
+                    Real *EdgeScratch, const StageUpdate *Stage, const MeshView *Narrow) {
    const bool Fast = isDefaultTermSet(P);
    if (Stage && !stageFusedSupported(M, P, EdgeScratch))
       return false;
+   // narrow cell tables (HorzMesh::narrowView): the sweeps run the (MaxEdges-1)-slot kernels on them, the cells with
+   // MaxEdges edges go through list launches on M.  (Not with run-time option flags and 8 slots: the merged level-1
+   // kernel is not instantiated for that, and both widths must take the same level-1 structure.)
+   if (Narrow && tuning().NarrowTables != 0 && EdgeScratch && tuning().EdgeMode == 0 && (Fast || Narrow->MaxEdges <= 6)) {
+      switch (Narrow->MaxEdges) {
+#define OMEGA_NARROW_CASE(MN_)                                                                                     \
+   case MN_:                                                                                                       \
+      if (Fast)                                                                                                    \
+         launchFusedT<MN_, true>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage, &M); \
+      else                                                                                                         \
+         launchFusedT<MN_, false>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr, &M); \
+      return true;
+         OMEGA_NARROW_CASE(5)
+         OMEGA_NARROW_CASE(6)
+         OMEGA_NARROW_CASE(7)
+#undef OMEGA_NARROW_CASE
+      default:
+         break;
+      }
+   }
    // (the sweeps' valence: MaxEdges, or MaxEdges-1 where that is what most cells have -- default term set, ME >= 6)
 #define OMEGA_DISPATCH_DOM(ME_)                                                                                    \
    do {                                                                                                            \

@@ -394,5 +394,126 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
    HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Any number of INDEPENDENT sweeps in one launch (the generalisation of tileKernel2): body I owns the workgroups
+// [TileStart[I], TileStart[I+1]).  Used where a mesh needs list launches next to a full sweep -- the heptagons of a
+// hexagon mesh on the wide tables, the pentagons' ring instantiations -- so that a few hundred scattered cells ride
+// along with the big sweep instead of costing a launch (and an idle chip) each.  No tail split: the short list
+// workgroups at the end of the launch ARE the tail.  The bodies travel as kernel arguments (4 KiB in total).
+constexpr int MaxSweeps = 4;
+struct SweepPlan {
+   int N[MaxSweeps];             ///< elements of each sweep
+   int TileStart[MaxSweeps + 1]; ///< first workgroup of each sweep; [NBodies] = grid size
+};
+template <int I, class T, class B, class... Rest>
+__device__ __forceinline__ void runSweep(const SweepPlan &Pl, int KV, int Tile, unsigned char *Lds, const B &Body,
+                                         const Rest &...More) {
+   if ((int)blockIdx.x < Pl.TileStart[I + 1]) {
+      const int NTiles = Pl.TileStart[I + 1] - Pl.TileStart[I];
+      const int First  = xcdRemap(blockIdx.x - Pl.TileStart[I], NTiles) * Tile;
+      const int Cnt    = Pl.N[I] - First < Tile ? Pl.N[I] - First : Tile;
+      typename B::Lds L = Body.carve(Lds, Tile);
+      const int Tid     = threadIdx.y * blockDim.x + threadIdx.x;
+      if (Cnt > 0)
+         Body.stage(L, First, Cnt, Tid, blockDim.x * blockDim.y);
+      __syncthreads();
+      for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y) {
+            chunkFence<B>();
+            Body.template compute<T>(L, Le, First + Le, Kv);
+         }
+      return;
+   }
+   if constexpr (sizeof...(Rest) > 0)
+      runSweep<I + 1, T>(Pl, KV, Tile, Lds, More...);
+}
+template <class... Bs> struct MinWavesOf;
+template <class B> struct MinWavesOf<B> {
+   static constexpr int V = BodyMinWaves<B>::V;
+};
+template <class B, class... Bs> struct MinWavesOf<B, Bs...> {
+   static constexpr int V = BodyMinWaves<B>::V < MinWavesOf<Bs...>::V ? BodyMinWaves<B>::V : MinWavesOf<Bs...>::V;
+};
+template <class T, class... Bs>
+__global__ void __launch_bounds__(OMEGA_LB, MinWavesOf<Bs...>::V) tileKernelV(SweepPlan Pl, int KV, int Tile, Bs... Bodies) {
+   extern __shared__ __align__(16) unsigned char Lds[];
+   runSweep<0, T>(Pl, KV, Tile, Lds, Bodies...);
+}
+
+/// launchTileV(K, S, BodyA, NA, BodyB, NB, ...): the sweeps BodyX over [0, NX) in one launch (sweeps with N <= 0 get no
+/// workgroups).  All bodies must agree on the levels per thread.
+namespace detail {
+template <class B> inline void prepBody(B &Body, int K) {
+   Body.K = levelPitch(K);
+   if constexpr (BodyHasKLog<B>::V)
+      Body.KLog = K;
+}
+} // namespace detail
+template <class B0, class B1> void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N1) {
+   static_assert(BodyMaxW<B0>::V == BodyMaxW<B1>::V, "launchTileV: bodies must agree on the levels per thread");
+   static_assert(sizeof(B0) + sizeof(B1) + sizeof(SweepPlan) <= 3900, "launchTileV: kernel arguments exceed 4 KiB");
+   B0 X0 = A0;
+   B1 X1 = A1;
+   detail::prepBody(X0, K), detail::prepBody(X1, K);
+   const int Ns[2] = {N0 > 0 ? N0 : 0, N1 > 0 ? N1 : 0};
+   const int Ty0 = bodyMaxTY(X0), Ty1 = bodyMaxTY(X1);
+   Geom G = makeGeom(Ns[0] + Ns[1], K, BodyMaxW<B0>::V, X0.K, Ty0 > Ty1 ? Ty0 : Ty1);
+   SweepPlan Pl{};
+   Pl.TileStart[0] = 0;
+   for (int I = 0; I < 2; ++I) {
+      Pl.N[I]             = Ns[I];
+      Pl.TileStart[I + 1] = Pl.TileStart[I] + (Ns[I] + G.Tile - 1) / G.Tile;
+   }
+   if (Pl.TileStart[2] == 0)
+      return;
+   const size_t L0 = X0.ldsBytes(G.Tile), L1 = X1.ldsBytes(G.Tile), Lds = L0 > L1 ? L0 : L1;
+   const dim3 Grid(Pl.TileStart[2], G.TailSplit > 1 ? 1 : G.Grid.y, 1);
+   if constexpr (BodyMaxW<B0>::V >= 2) {
+      if (G.W == 2) {
+         hipLaunchKernelGGL((tileKernelV<dv2, B0, B1>), Grid, G.Block, Lds, S, Pl, G.KV, G.Tile, X0, X1);
+         HIP_CHECK(hipGetLastError());
+         return;
+      }
+   }
+   hipLaunchKernelGGL((tileKernelV<double, B0, B1>), Grid, G.Block, Lds, S, Pl, G.KV, G.Tile, X0, X1);
+   HIP_CHECK(hipGetLastError());
+}
+template <class B0, class B1, class B2>
+void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N1, const B2 &A2, int N2) {
+   static_assert(BodyMaxW<B0>::V == BodyMaxW<B1>::V && BodyMaxW<B0>::V == BodyMaxW<B2>::V,
+                 "launchTileV: bodies must agree on the levels per thread");
+   static_assert(sizeof(B0) + sizeof(B1) + sizeof(B2) + sizeof(SweepPlan) <= 3900, "launchTileV: kernel arguments exceed 4 KiB");
+   B0 X0 = A0;
+   B1 X1 = A1;
+   B2 X2 = A2;
+   detail::prepBody(X0, K), detail::prepBody(X1, K), detail::prepBody(X2, K);
+   const int Ns[3] = {N0 > 0 ? N0 : 0, N1 > 0 ? N1 : 0, N2 > 0 ? N2 : 0};
+   int Ty = bodyMaxTY(X0);
+   Ty     = bodyMaxTY(X1) > Ty ? bodyMaxTY(X1) : Ty;
+   Ty     = bodyMaxTY(X2) > Ty ? bodyMaxTY(X2) : Ty;
+   Geom G = makeGeom(Ns[0] + Ns[1] + Ns[2], K, BodyMaxW<B0>::V, X0.K, Ty);
+   SweepPlan Pl{};
+   Pl.TileStart[0] = 0;
+   for (int I = 0; I < 3; ++I) {
+      Pl.N[I]             = Ns[I];
+      Pl.TileStart[I + 1] = Pl.TileStart[I] + (Ns[I] + G.Tile - 1) / G.Tile;
+   }
+   if (Pl.TileStart[3] == 0)
+      return;
+   size_t Lds = X0.ldsBytes(G.Tile);
+   Lds        = X1.ldsBytes(G.Tile) > Lds ? X1.ldsBytes(G.Tile) : Lds;
+   Lds        = X2.ldsBytes(G.Tile) > Lds ? X2.ldsBytes(G.Tile) : Lds;
+   const dim3 Grid(Pl.TileStart[3], G.TailSplit > 1 ? 1 : G.Grid.y, 1);
+   if constexpr (BodyMaxW<B0>::V >= 2) {
+      if (G.W == 2) {
+         hipLaunchKernelGGL((tileKernelV<dv2, B0, B1, B2>), Grid, G.Block, Lds, S, Pl, G.KV, G.Tile, X0, X1, X2);
+         HIP_CHECK(hipGetLastError());
+         return;
+      }
+   }
+   hipLaunchKernelGGL((tileKernelV<double, B0, B1, B2>), Grid, G.Block, Lds, S, Pl, G.KV, G.Tile, X0, X1, X2);
+   HIP_CHECK(hipGetLastError());
+}
+
 } // namespace OMEGA
 #endif

@@ -97,7 +97,10 @@ struct StageUpdate {
 /// this mesh / option set; the caller then runs the plain RHS followed by the update kernels.
 bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                    hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr, const StageUpdate *Stage = nullptr);
+                    hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr, const StageUpdate *Stage = nullptr,
+                    const MeshView *Narrow = nullptr);
+/// Narrow: HorzMesh::narrowView() -- the per-(cell, slot) tables stored MaxEdges-1 wide; the sweeps then run the
+/// (MaxEdges-1)-slot kernels on them and the cells with MaxEdges edges (M.WideCells) go through list launches on M
 /// EdgeScratch: optional [NEdgesSize][K] work array for the cell-centric PV sums (faster path)
 
 // ---- reductions (base/Reductions.h): double-double local sums on the device ----

@@ -155,6 +155,19 @@ def test_paired_level3_launch_for_the_plain_rhs_in_a_child_process():
     assert " passed" in out and "failed" not in out
 
 
+def test_wide_tables_only_in_a_child_process():
+    """Option NarrowTables = 0: meshes of hexagons with a few heptagons keep ONE set of cell tables, 7 wide, and sweep
+    them with the 6-valent kernel instantiations (round 2's structure; what meshes whose ring tables are not all valid
+    still do).  Default: a second, 6-wide set for the sweeps + list launches of the 7-slot kernels for the heptagons."""
+    env = dict(os.environ, OMEGA_AMD_OPTIONS="NarrowTables=0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
+                        "fib1500 or fib300 or sphere_meshes_take_the_fast_paths"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert " passed" in out and "failed" not in out
+
+
 def test_four_ranks_one_gpu():
     """Four ranks (2 x 2 blocks of a 48 x 48 mesh: every rank has several neighbours, corner halos travel
     through two of them) on one GPU, overlapped exchanges."""

@@ -148,6 +148,9 @@ def test_sphere_meshes_take_the_fast_paths():
     assert P.mesh.get_int("MaxEdges") == 7 and P.mesh.get_int("Del2RingOK") == 1
     assert P.mesh.get_int("DomM1") == 1        # hexagons dominate a 7-wide mesh: the full sweeps take valence 6
     assert P.mesh.get_int("CellPVOK") == 1 and P.mesh.get_int("NIrregularEdges") == 0
+    # ... on a second, 6-wide set of cell tables, with the heptagons on list launches of the 7-slot kernels
+    assert 0 < P.mesh.get_int("NWideCells") < 0.1 * P.mesh.NCellsAll
+    assert P.mesh.get_int("NarrowTables") == (1 if oa.get_option("NarrowTables") else 0)
     P = _mk(("ico3pad8", 0, 0, 4, 1, {}))
     assert P.mesh.get_int("MaxEdgesFile") == 8 and P.mesh.get_int("CellPVOK") == 1
     if oa.get_option("KeepMaxEdges") == 1:   # (child run of tests/test_00_multirank_gpu.py)
