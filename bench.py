@@ -456,7 +456,7 @@ def main():
                     wl = pa[pa.index("--workload") + 1]
                 if pmc.get("kernel_source_sha") != sha or wl != args.workload:
                     continue
-                def bases(n):
+                def bases(n):     # "A<6, 6>+B<7, 7>" -> "A+B" (template arguments contain commas and, nested, '+' never)
                     return "+".join(x.split("<")[0].strip() for x in n.split("+"))
                 base = bases(name)
                 cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and bases(k) == base]

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Diagnostic PMC passes for the texture-addresser / L1 path of the RHS kernels (each pass in its own run, bounded by
-# timeout: a TA/TCP pass has aborted inside rocprofv3 on this image before).
+# Diagnostic PMC passes for the texture-addresser / L1 path of the RHS kernels: each pass in its own run with at most
+# two counters of one block (more than a block has slots for aborts rocprofv3 with signal 6), bounded by timeout.  A
+# pass that fails or times out ends the script with its log tail and a non-zero exit: nothing is swallowed.
 #   usage (through gpurun): bash tools/pmc_diag2.sh <tag> [bench.py args]
 set -o pipefail
 TAG=${1:?tag}; shift || true
@@ -11,7 +12,13 @@ ARGS="--steps 4 --warmup 1 --rk4-steps 0 --no-cpu-baseline $*"
 pass() { # name counters...
    n=$1; shift
    timeout -k 10 100 rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$n -o p -- python3 bench.py $ARGS > $OUT/${TAG}_$n.log 2>&1
-   echo "[diag2] pass $n rc=$?"
+   rc=$?
+   echo "[diag2] pass $n rc=$rc"
+   if [ $rc -ne 0 ]; then
+      echo "[diag2] pass $n FAILED (rc $rc; 124 = timeout): last lines of its log" >&2
+      tail -20 $OUT/${TAG}_$n.log >&2
+      exit $rc     # no further GPU step after a failed one
+   fi
 }
 # (at most two counters of one block per pass: more "exceeds the capabilities of the hardware" and rocprofv3 aborts)
 pass ta1 TA_BUSY_avr TA_BUFFER_TOTAL_CYCLES_sum GRBM_GUI_ACTIVE

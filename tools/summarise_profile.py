@@ -52,6 +52,9 @@ def short(name):
     if "tileKernel2<" in name:
         a = _template_args(name[name.index("tileKernel2<") + len("tileKernel2<"):])
         return "+".join(x.replace("OMEGA::", "") for x in a[:2])
+    if "tileKernelV<" in name:      # tileKernelV<T, A, B, ...>: any number of independent sweeps in one launch
+        a = _template_args(name[name.index("tileKernelV<") + len("tileKernelV<"):])
+        return "+".join(x.replace("OMEGA::", "") for x in a[1:])
     if "tileKernel<" in name:
         a = _template_args(name[name.index("tileKernel<") + len("tileKernel<"):])
         return a[0].replace("OMEGA::", "")
