@@ -27,6 +27,7 @@ const OptionName OptionTable[] = {
     {"MergeL1", &TuningOptions::MergeL1},
     {"Pair", &TuningOptions::Pair},
     {"FuseL3", &TuningOptions::FuseL3},
+    {"ChunkMajor", &TuningOptions::ChunkMajor},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},
