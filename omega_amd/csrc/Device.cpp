@@ -28,6 +28,7 @@ const OptionName OptionTable[] = {
     {"Pair", &TuningOptions::Pair},
     {"FuseL3", &TuningOptions::FuseL3},
     {"ChunkMajor", &TuningOptions::ChunkMajor},
+    {"Alternate", &TuningOptions::Alternate},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},

@@ -25,6 +25,7 @@ struct TuningOptions {
    int MergeL1   = 1; ///< vertex pass + side-0 PV sums inside the level-1 cell kernel
    int Pair      = 1; ///< independent sweeps share a launch
    int FuseL3    = 1; ///< plain RHS: both level-3 kernels in one thread
+   int Alternate  = 0; ///< 1: consecutive dependency levels sweep the mesh in opposite directions (measured: no gain)
    int ChunkMajor = 5; ///< private intermediates of the fused RHS in level-chunk-major layout [pitch/16][rows][16]:
                        ///< mask of 1 (cell-), 2 (edge-), 4 (vertex-located arrays); 0 = all [rows][pitch]; default 5 (measured best)
    // ---- mesh tables (read when a HorzMesh is constructed)

@@ -2014,6 +2014,14 @@ static void launchFusedT(const MeshView &MIn, int K, int NT, const TendParams &P
       if (Ev)
          (void)hipEventRecord(Ev[I], S);
    };
+   // every dependency level sweeps in the opposite direction to the one before it (KernelCommon.h: sweepDirection)
+   auto Flip = [&]() {
+      if (tuning().Alternate)
+         sweepDirection() ^= 1;
+      else
+         sweepDirection() = 0;
+   };
+   Flip();
    // L1: replaces AuxState:vertexAuxState1, cellAuxState1, edgeAuxState1/2 (flux thickness), cellAuxState4 (Del2Tracers),
    // Tend:thicknessFluxDiv and the cell-0 half of Tend:potientialVortHAdv
    Pacer::start("Tend:fused:L1[AuxState:vertexAuxState1,cellAuxState1,edgeAuxState2,cellAuxState4;Tend:thicknessFluxDiv]", 2);
@@ -2097,6 +2105,7 @@ static void launchFusedT(const MeshView &MIn, int K, int NT, const TendParams &P
    if (P.WindForcingTendencyEnable)
       launchEdgeAuxState1(Wide ? *Wide : M, A, P.WindInterpIsotropic, S);
    Pacer::stop("Tend:fused:L1", 2);
+   Flip();
    // L2 (only the del4 term consumes it): replaces AuxState:edgeAuxState3 (Del2Edge), cellAuxState2, vertexAuxState2
    Pacer::start("Tend:fused:L2[AuxState:vertexAuxState2,cellAuxState2]", 2);
    Mark(2);
@@ -2149,6 +2158,7 @@ static void launchFusedT(const MeshView &MIn, int K, int NT, const TendParams &P
       }
    }
    Pacer::stop("Tend:fused:L2", 2);
+   Flip();
    // L3: replaces Tend:potientialVortHAdv, KEGrad, SSHGrad, velocityDiffusion, velocityHyperDiff, windForcing, bottomDrag,
    // AuxState:edgeAuxState4 (HTracersEdge) and Tend:tracerHorzAdv, tracerDiffusion, tracerHyperDiff
    Pacer::start("Tend:fused:L3[Tend:potientialVortHAdv,KEGrad,SSHGrad,velocityDiffusion,velocityHyperDiff,tracerHorzAdv,"

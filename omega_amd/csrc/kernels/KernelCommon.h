@@ -218,12 +218,14 @@ template <class B> struct BodyMaxW<B, decltype((void)B::MaxW)> {
 #endif
 template <class Body, class T>
 __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
-    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit) {
+    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit, int Rev) {
    extern __shared__ __align__(16) unsigned char Lds[];
    // level chunks of this workgroup: C0, C0 + CS, ...  (whole tile: gridDim.y-way split; tail tile: one chunk each)
    int TileId, C0 = blockIdx.y, CS = gridDim.y;
    if ((int)blockIdx.x < NFull) {
       TileId = xcdRemap(blockIdx.x, NFull);
+      if (Rev) // (sweepDirection: this sweep walks the elements from the end, see launchTile)
+         TileId = NFull - 1 - TileId;
    } else {
       const int Bt = blockIdx.x - NFull;
       TileId       = NFull + Bt / TailSplit;
@@ -257,12 +259,13 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
 template <class BA, class BB, class T>
 __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<BB>::V ? BodyMinWaves<BA>::V
                                                                                        : BodyMinWaves<BB>::V))
-    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit) {
+    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit, int Rev) {
    extern __shared__ __align__(16) unsigned char Lds[];
    const int Tid  = threadIdx.y * blockDim.x + threadIdx.x;
    const int NThr = blockDim.x * blockDim.y;
    if ((int)blockIdx.x < NTilesA) {
-      const int First = xcdRemap(blockIdx.x, NTilesA) * Tile;
+      const int Ta    = xcdRemap(blockIdx.x, NTilesA);
+      const int First = (Rev ? NTilesA - 1 - Ta : Ta) * Tile;
       const int Cnt   = NA - First < Tile ? NA - First : Tile;
       typename BA::Lds L = A.carve(Lds, Tile);
       if (Cnt > 0)
@@ -283,6 +286,8 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       int TileId, C0 = blockIdx.y, CS = gridDim.y;
       if (Bb_ < NFullB) {
          TileId = xcdRemap(Bb_, NFullB);
+         if (Rev)
+            TileId = NFullB - 1 - TileId;
       } else {
          TileId = NFullB + (Bb_ - NFullB) / TailSplit;
          C0     = (Bb_ - NFullB) % TailSplit;
@@ -328,9 +333,17 @@ template <class B> struct BodyHasKLog<B, decltype((void)std::declval<B &>().KLog
 /// sets to the row pitch of the arrays (levelPitch(K) for the library's own arrays; Pitch >= K for caller-owned
 /// ones, e.g. compact raw arrays of the C ABI); bodies that also need the level COUNT (bottom level of the drag
 /// term) declare `int KLog`.
+/// Direction of the sweeps launched from now on (launchFusedT flips it between dependency levels): a sweep that walks
+/// the elements in the opposite direction to the one before it starts on what that one touched last -- the part of
+/// its inputs most likely to still sit in the 256 MiB memory-side cache.  Results do not depend on the order.
+inline int &sweepDirection() {
+   static thread_local int Rev = 0;
+   return Rev;
+}
 template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t S, int Pitch = -1) {
    if (N <= 0)
       return;
+   const int Rev = sweepDirection();
    Body B = B0;
    B.K    = Pitch > 0 ? Pitch : levelPitch(K);
    if constexpr (BodyHasKLog<Body>::V)
@@ -339,12 +352,12 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
    const size_t Lds = B.ldsBytes(G.Tile);
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit);
+         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit);
+   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev);
    HIP_CHECK(hipGetLastError());
 }
 
@@ -384,13 +397,13 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
    if constexpr (BodyMaxW<BA>::V >= 2) {
       if (G.W == 2) {
          hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
-                            TailSplit);
+                            TailSplit, sweepDirection());
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
    hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
-                      TailSplit);
+                      TailSplit, sweepDirection());
    HIP_CHECK(hipGetLastError());
 }
 
@@ -404,13 +417,15 @@ constexpr int MaxSweeps = 4;
 struct SweepPlan {
    int N[MaxSweeps];             ///< elements of each sweep
    int TileStart[MaxSweeps + 1]; ///< first workgroup of each sweep; [NBodies] = grid size
+   int Rev;                      ///< walk every sweep from its end (sweepDirection)
 };
 template <int I, class T, class B, class... Rest>
 __device__ __forceinline__ void runSweep(const SweepPlan &Pl, int KV, int Tile, unsigned char *Lds, const B &Body,
                                          const Rest &...More) {
    if ((int)blockIdx.x < Pl.TileStart[I + 1]) {
       const int NTiles = Pl.TileStart[I + 1] - Pl.TileStart[I];
-      const int First  = xcdRemap(blockIdx.x - Pl.TileStart[I], NTiles) * Tile;
+      const int Tl     = xcdRemap(blockIdx.x - Pl.TileStart[I], NTiles);
+      const int First  = (Pl.Rev ? NTiles - 1 - Tl : Tl) * Tile;
       const int Cnt    = Pl.N[I] - First < Tile ? Pl.N[I] - First : Tile;
       typename B::Lds L = Body.carve(Lds, Tile);
       const int Tid     = threadIdx.y * blockDim.x + threadIdx.x;
@@ -459,6 +474,7 @@ template <class B0, class B1> void launchTileV(int K, hipStream_t S, const B0 &A
    const int Ty0 = bodyMaxTY(X0), Ty1 = bodyMaxTY(X1);
    Geom G = makeGeom(Ns[0] + Ns[1], K, BodyMaxW<B0>::V, X0.K, Ty0 > Ty1 ? Ty0 : Ty1);
    SweepPlan Pl{};
+   Pl.Rev          = sweepDirection();
    Pl.TileStart[0] = 0;
    for (int I = 0; I < 2; ++I) {
       Pl.N[I]             = Ns[I];
@@ -493,6 +509,7 @@ void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N
    Ty     = bodyMaxTY(X2) > Ty ? bodyMaxTY(X2) : Ty;
    Geom G = makeGeom(Ns[0] + Ns[1] + Ns[2], K, BodyMaxW<B0>::V, X0.K, Ty);
    SweepPlan Pl{};
+   Pl.Rev          = sweepDirection();
    Pl.TileStart[0] = 0;
    for (int I = 0; I < 3; ++I) {
       Pl.N[I]             = Ns[I];
