@@ -325,6 +325,29 @@ def test_manufactured_tendencies_match_the_oracle(fused):
     assert np.abs(P.tend.get(0)[: m.NCellsOwned] - hT[: m.NCellsOwned]).max() > 1e-6
 
 
+def test_custom_tendency_hooks_see_a_materialised_auxiliary_state():
+    """The fused RHS keeps its intermediates private; a custom tendency hook receives the AuxiliaryState and may read it
+    (reference: computeAllTendencies fills it before the hooks run, Tendencies.cpp:591, 288-291, 416-419): when a hook is
+    installed the library runs AuxiliaryState::computeAll first, so the reference's arrays hold the current state."""
+    P = _mk((16, 16, 30e3, 6, 1, {}))
+    seen = {}
+
+    def hook(tend, h, u, nall, nsize, k, pitch, t, stream):
+        oa.device_synchronize()
+        seen["KE"] = P.aux.get("KineticEnergyCell").copy()
+        seen["Del2"] = P.aux.get("Del2Edge").copy()
+
+    P.tend.set_custom_tendency(0, hook)
+    try:
+        P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+        oa.device_synchronize()
+    finally:
+        P.tend.set_custom_tendency(0, None)
+    P.oracle.compute_all_aux(P.h, P.u, P.tr)
+    check("KineticEnergyCell in the hook", seen["KE"], P.oracle.aux["KineticEnergyCell"], P.mesh.NCellsOwned)
+    check("Del2Edge in the hook", seen["Del2"], P.oracle.aux["Del2Edge"], P.mesh.NEdgesOwned)
+
+
 def test_manufactured_solution_converges_through_the_gpu_path():
     """RK4 on the GPU with the custom tendencies (stage times from the stepper): second-order
     convergence to the exact solution, and the same numbers as the oracle run to 1e-12."""
