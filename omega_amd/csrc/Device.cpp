@@ -27,7 +27,6 @@ const OptionName OptionTable[] = {
     {"MergeL1", &TuningOptions::MergeL1},
     {"Pair", &TuningOptions::Pair},
     {"FuseL3", &TuningOptions::FuseL3},
-    {"ChunkMajor", &TuningOptions::ChunkMajor},
     {"Alternate", &TuningOptions::Alternate},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},

@@ -117,10 +117,6 @@ struct MeshView {
    // that own anything a neighbour receives); InteriorCells: the other owned cells.  Ascending order.
    I4 NBandCells, NInteriorCells;
    const I4 *BandCells, *InteriorCells;
-   // ---- layout of the fused RHS's private intermediates (set per launch by launchFusedRHS; FusedKernels.hip: offI) ----
-   // byte offset of (row, level group Kv) = row * IRS<space> + chunkTerm(Kv, ICS<space>): row-major [rows][pitch] has
-   // IRS = pitch * 8 and ICS = 128; level-chunk-major [pitch/16][rows][16] has IRS = 128 and ICS = NXxSize * 128
-   unsigned IRSCell, IRSEdge, IRSVertex, ICSCell, ICSEdge, ICSVertex;
 };
 
 class HorzMesh : public Registry<HorzMesh> {

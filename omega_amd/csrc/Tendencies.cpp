@@ -1,7 +1,6 @@
 // Tendencies.cpp -- see Tendencies.h.
 #include "Tendencies.h"
 #include "Pacer.h"
-#include "Tuning.h"
 
 namespace OMEGA {
 
@@ -37,41 +36,6 @@ int Tendencies::collectKernelTimes(double *MsSum) {
    }
    TimingEvents.clear();
    return N;
-}
-
-AuxPtrs Tendencies::fusedPtrs(const AuxiliaryState *Aux) {
-   if (!Work.KE.Ptr) {
-      const int NC = Mesh->NCellsSize, NV = Mesh->NVerticesSize, K = NVertLayers;
-      Work.KE          = Array2DReal::levels("FusedKE", NC, K);
-      Work.Div         = Array2DReal::levels("FusedDiv", NC, K);
-      Work.Del2Div     = Array2DReal::levels("FusedDel2Div", NC, K);
-      Work.RelVort     = Array2DReal::levels("FusedRelVort", NV, K);
-      Work.InvThick    = Array2DReal::levels("FusedInvThick", NV, K);
-      Work.Del2RelVort = Array2DReal::levels("FusedDel2RelVort", NV, K);
-      Work.Del2Tr      = Array3DReal::levels("FusedDel2Tr", NTracers > 0 ? NTracers : 1, NC, K);
-   }
-   AuxPtrs A           = Aux->ptrs();
-   A.KineticEnergyCell = Work.KE.Ptr, A.VelocityDivCell = Work.Div.Ptr, A.Del2DivCell = Work.Del2Div.Ptr;
-   A.RelVortVertex = Work.RelVort.Ptr, A.InvThickVertex = Work.InvThick.Ptr, A.Del2RelVortVertex = Work.Del2RelVort.Ptr;
-   A.Del2TracersCell = Work.Del2Tr.Ptr;
-   return A;
-}
-
-bool Tendencies::fusedLayout(const TendParams &P, hipStream_t S) {
-   const bool CM  = fusedChunkMajor(Mesh->view(), NVertLayers, P, EdgeScratch.Ptr);
-   const int Mask = CM ? (tuning().ChunkMajor & 7) : 0;
-   if (Work.ChunkMajor >= 0 && Work.ChunkMajor != Mask) {
-      auto Zero = [&](auto &A) {
-         size_t Cnt = 1;
-         for (size_t I = 0; I + 1 < sizeof(A.Ext) / sizeof(A.Ext[0]); ++I)
-            Cnt *= (size_t)A.Ext[I];
-         deviceFill0(A.Ptr, Cnt * (size_t)A.Pitch * sizeof(Real), S);
-      };
-      Zero(Work.KE), Zero(Work.Div), Zero(Work.Del2Div), Zero(Work.RelVort), Zero(Work.InvThick), Zero(Work.Del2RelVort);
-      Zero(Work.Del2Tr), Zero(EdgeScratch);
-   }
-   Work.ChunkMajor = Mask;
-   return CM;
 }
 
 TendParams Tendencies::paramsFor(const AuxiliaryState *Aux) const {
@@ -168,12 +132,9 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
                  "Tendencies: bad time level");
    if (!EdgeScratch.Ptr)
       EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
-   const TendParams P = paramsFor(Aux);
-   const AuxPtrs AF   = fusedPtrs(Aux);
-   const bool CM      = fusedLayout(P, S);
-   return launchFusedRHS(Mesh->view(), NVertLayers, NTracers, P, AF, LayerThicknessTend.Ptr,
+   return launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                          NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, nullptr,
-                         EdgeScratch.Ptr, &Stage, Mesh->narrowView(), CM);
+                         EdgeScratch.Ptr, &Stage, Mesh->narrowView());
 }
 
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
@@ -201,18 +162,16 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
          Ev = TimingEvents.back().data();
       }
       const TendParams P = paramsFor(Aux);
-      const AuxPtrs AF   = fusedPtrs(Aux);
-      const bool CM      = fusedLayout(P, S);
       auto Launch        = [&]() {
-         launchFusedRHS(Mesh->view(), NVertLayers, NTracers, P, AF, LayerThicknessTend.Ptr,
+         launchFusedRHS(Mesh->view(), NVertLayers, NTracers, P, Aux->ptrs(), LayerThicknessTend.Ptr,
                         NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
-                        EdgeScratch.Ptr, nullptr, Mesh->narrowView(), CM);
+                        EdgeScratch.Ptr, nullptr, Mesh->narrowView());
       };
       // wind forcing reads the stress arrays through a non-tile kernel too, still plain launches: capturable
       if (UseGraphs && !Ev && !CustomThicknessTend && !CustomVelocityTend) {
          GraphCache::Key Key;
          GraphCache::add(Key, LayerThick.Ptr), GraphCache::add(Key, NormVel.Ptr), GraphCache::add(Key, TracerArray.Ptr);
-         GraphCache::add(Key, Aux), GraphCache::add(Key, P), GraphCache::add(Key, S), GraphCache::add(Key, (int)CM);
+         GraphCache::add(Key, Aux), GraphCache::add(Key, P), GraphCache::add(Key, S);
          Graphs.run(Key, S, Launch);
       } else {
          Launch();

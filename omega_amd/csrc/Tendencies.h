@@ -74,28 +74,13 @@ class Tendencies : public Registry<Tendencies> {
 
    const HorzMesh *Mesh;
    int NVertLayers, NTracers;
-   /// The fused RHS keeps its intermediates private; custom tendency hooks receive the AuxiliaryState and may read it
-   /// (reference: computeAllTendencies computes the auxiliary state first, Tendencies.cpp:591): with this on (default)
-   /// AuxiliaryState::computeAll runs before the hooks are called.
+   /// The fused RHS never materialises the edge-located auxiliary arrays; custom tendency hooks receive the
+   /// AuxiliaryState and may read it (reference: computeAllTendencies computes the auxiliary state first,
+   /// Tendencies.cpp:591): with this on (default) AuxiliaryState::computeAll runs before the hooks are called.
    bool MaterialiseAuxForCustom = true;
 
  private:
    Array2DReal EdgeScratch; ///< running PV sums of the fused RHS (allocated on first use)
-   /// Private intermediates of the fused RHS (allocated on first use): what it passes from one dependency level to
-   /// the next -- KE, Div, Del2Div on cells; RelVort, 1/LayerThickVertex, Del2RelVort on vertices; Del2Tracers -- lives
-   /// here, not in the AuxiliaryState arrays, so that its layout is the library's own business (level-chunk-major
-   /// [pitch/16][rows][16] where the kernels support it; FusedKernels.hip: offI).  AuxiliaryState::computeAll and the
-   /// history output materialise the reference's arrays with the reference's layout whenever they are asked for.
-   struct FusedWork {
-      Array2DReal KE, Div, Del2Div, RelVort, InvThick, Del2RelVort;
-      Array3DReal Del2Tr;
-      int ChunkMajor = -1; ///< layout of the last evaluation (-1: none yet)
-   } Work;
-   /// the layout this evaluation uses; re-zeroes the private arrays when it differs from the previous one (the zero
-   /// sentinel rows sit at other addresses)
-   bool fusedLayout(const TendParams &P, hipStream_t S);
-   /// the AuxiliaryState's pointers with the private intermediates in place of its arrays
-   AuxPtrs fusedPtrs(const AuxiliaryState *AuxState);
    bool TimingOn = false;
    bool WarnedUnfused = false;
    std::vector<std::vector<hipEvent_t>> TimingEvents;

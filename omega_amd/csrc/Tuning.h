@@ -26,8 +26,6 @@ struct TuningOptions {
    int Pair      = 1; ///< independent sweeps share a launch
    int FuseL3    = 1; ///< plain RHS: both level-3 kernels in one thread
    int Alternate  = 0; ///< 1: consecutive dependency levels sweep the mesh in opposite directions (measured: no gain)
-   int ChunkMajor = 5; ///< private intermediates of the fused RHS in level-chunk-major layout [pitch/16][rows][16]:
-                       ///< mask of 1 (cell-), 2 (edge-), 4 (vertex-located arrays); 0 = all [rows][pitch]; default 5 (measured best)
    // ---- mesh tables (read when a HorzMesh is constructed)
    int ForceGeneric = 0; ///< clear every ring-table flag: all kernels in their generic form
    int KeepMaxEdges = 0; ///< keep the mesh file's maxEdges as the table width

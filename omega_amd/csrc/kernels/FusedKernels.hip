@@ -155,19 +155,6 @@ __device__ __forceinline__ void stageApply(const StageEpi &E, unsigned Off, T Te
 template <class T> __device__ __forceinline__ unsigned rowOff(int Row, int K, int Kv) {
    return ((unsigned)Row * (unsigned)K + (unsigned)Kv * (unsigned)VecW<T>::W) * 8u;
 }
-/// Private intermediates of the fused RHS (KE, Div, Del2Div, RelVort, 1/LayerThickVertex, Del2RelVort, Del2Tracers, the
-/// running PV sums) may be stored level-chunk-major, [pitch/16][rows][16 levels]: the 16-level piece of a row that one
-/// workgroup step touches is then a 128-byte line NEXT TO the pieces of the neighbouring rows, so a tile reads / writes
-/// contiguous kilobytes instead of one line every `pitch * 8` bytes (tools/probes/layout.hip: 5.4 against 5.05 TB/s for
-/// a pure streaming kernel of this shape).  One formula serves both layouts (MeshView::IRS / ICS*, set per launch):
-///    byte offset(row, Kv) = row * IRS + chunkTerm(Kv, ICS)
-/// with IRS = pitch * 8, ICS = 128 for [rows][pitch] and IRS = 128, ICS = NXxSize * 128 for the chunk-major form.
-/// The arrays that cross the boundary (state, tracers, tendencies) always are [rows][pitch]: rowOff.
-template <class T> __device__ __forceinline__ unsigned chunkTerm(int Kv, unsigned CS) {
-   constexpr int PC = 16 / VecW<T>::W; // level groups per 16-level chunk
-   return (unsigned)(Kv / PC) * CS + (unsigned)(Kv % PC) * (8u * VecW<T>::W);
-}
-__device__ __forceinline__ unsigned offI(int Row, unsigned RS, unsigned CT) { return (unsigned)Row * RS + CT; }
 /// make a wave-uniform pointer provably scalar (SGPR pair) so gathers use the
 /// `saddr + 32-bit voffset` form instead of per-lane 64-bit pointers
 __device__ __forceinline__ const Real *uniformPtr(const Real *P) {
@@ -390,17 +377,24 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
          L.FV[I]        = M.FVertex[M.VertRingOnCell[G]];
          L.Role[I]      = M.PVRoleOnCell[G];
       }
-      for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
-         const int Cl = I / (TME * TM1);
-         const int C  = List ? List[First + Cl] : First + Cl;
-         L.Wt[I]      = M.PVWeightOnCell[(size_t)C * TME * TM1 + (I - Cl * TME * TM1)];
-      }
-      for (int I = Tid; I < Cnt * TME * 3; I += NThr) {
-         const int Cl   = I / (TME * 3);
-         const int C    = List ? List[First + Cl] : First + Cl;
-         const size_t G = (size_t)C * TME * 3 + (I - Cl * TME * 3);
-         L.KC[I]        = M.KiteCoefOnCell[G];
-         L.VC[I]        = M.VortCoefOnCell[G];
+      if (!List) { // a sweep: the tile's rows are one contiguous piece of every table
+         for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
+            L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
+         for (int I = Tid; I < Cnt * TME * 3; I += NThr) {
+            L.KC[I] = M.KiteCoefOnCell[(size_t)First * TME * 3 + I];
+            L.VC[I] = M.VortCoefOnCell[(size_t)First * TME * 3 + I];
+         }
+      } else {
+         for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
+            const int Cl = I / (TME * TM1);
+            L.Wt[I]      = M.PVWeightOnCell[(size_t)List[First + Cl] * TME * TM1 + (I - Cl * TME * TM1)];
+         }
+         for (int I = Tid; I < Cnt * TME * 3; I += NThr) {
+            const int Cl   = I / (TME * 3);
+            const size_t G = (size_t)List[First + Cl] * TME * 3 + (I - Cl * TME * 3);
+            L.KC[I]        = M.KiteCoefOnCell[G];
+            L.VC[I]        = M.VortCoefOnCell[G];
+         }
       }
       for (int I = Tid; I < Cnt; I += NThr) {
          const int C = List ? List[First + I] : First + I;
@@ -417,9 +411,6 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
       const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
       const Real InvA       = L.InvA[Le];
       const unsigned OffS   = rowOff<T>(ICell, K, Kv);
-      // offsets into the private intermediates (offI): cell / edge / vertex chunk terms of this level group
-      const unsigned CTc = chunkTerm<T>(Kv, M.ICSCell), CTe = chunkTerm<T>(Kv, M.ICSEdge), CTv = chunkTerm<T>(Kv, M.ICSVertex);
-      const unsigned OffSi = offI(ICell, M.IRSCell, CTc);
       unsigned OffN[TME], OffE[TME];
       bool IsC0[TME];
       T Ue[TME], Hn[TME], Usp[TME];
@@ -452,8 +443,8 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
             DivTmp -= L.DivC[Le * TME + J] * Ue[J];
             HDivTmp -= L.DvS[Le * TME + J] * Flux[J] * Ue[J] * InvA;
          }
-         stnt<T>(KE, OffSi, KETmp);
-         stnt<T>(Div, OffSi, DivTmp);
+         stnt<T>(KE, OffS, KETmp);
+         stnt<T>(Div, OffS, DivTmp);
          T HT = splat<T>(0.0);
          if (ThickOn)
             HT -= HDivTmp;
@@ -485,7 +476,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
             const T Inv        = 1. / LayerThickVertex;
             { // the cell that stores the vertex (bit 4) writes; the other lanes' stores are switched off, not branched around
                const bool Own      = (Sel >> 4) & 1;
-               const unsigned OffV = offI(L.Ring[Le * TME + R], M.IRSVertex, CTv);
+               const unsigned OffV = rowOff<T>(L.Ring[Le * TME + R], K, Kv);
                stoIf<T>(Own, RelVortV, OffV, RelVortTmp);
                stoIf<T>(Own, InvThickV, OffV, Inv);
             }
@@ -520,7 +511,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
                   const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
                   Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Ue[Kk] * NormVort;
                }
-               sto<T>(Partial, offI(L.Edge[Le * TME + I], M.IRSEdge, CTe), Acc);
+               sto<T>(Partial, OffE[I], Acc);
             }
          }
       }
@@ -556,7 +547,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
                       Fast ? T(Tn[Q][J] - Ts[Q]) : T(pick(IsC0[J], Tn[Q][J], Ts[Q]) - pick(IsC0[J], Ts[Q], Tn[Q][J]));
                   Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
                }
-               stntIf<T>(Valid, uniformPtr(Del2Tr + (Valid ? Lt + Q : Lt) * CStride), OffSi, Tmp * InvA);
+               stntIf<T>(Valid, uniformPtr(Del2Tr + (Valid ? Lt + Q : Lt) * CStride), OffS, Tmp * InvA);
             }
          }
       }
@@ -714,9 +705,11 @@ template <int TME> struct Del2CellRingBody {
    }
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
-         const int Cl   = I / TME;
-         const int C    = List ? List[First + Cl] : First + Cl;
-         const size_t G = (size_t)C * TME + (I - Cl * TME);
+         size_t G = (size_t)First * TME + I;
+         if (List) {
+            const int Cl = I / TME;
+            G            = (size_t)List[First + Cl] * TME + (I - Cl * TME);
+         }
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.InvDc[I]     = M.InvDcOnCell[G];
          L.GradS[I]     = M.Del2GradMaskSOnCell[G];
@@ -731,15 +724,13 @@ template <int TME> struct Del2CellRingBody {
       if (L.N[Le] > TME)
          return; // a cell wider than these tables: it has its own (list) launch on the wide tables
       const int ICell = List ? List[IElem] : IElem;
-      // (this kernel only touches private intermediates: offI everywhere)
-      const unsigned CTc = chunkTerm<T>(Kv, M.ICSCell), CTv = chunkTerm<T>(Kv, M.ICSVertex);
       T Dn[TME], Rv[TME];
 #pragma unroll
       for (int J = 0; J < TME; ++J) {
-         Dn[J] = ldo<T>(Div, offI(L.Nbr[Le * TME + J], M.IRSCell, CTc));
-         Rv[J] = ldo<T>(RelVort, offI(L.Ring[Le * TME + J], M.IRSVertex, CTv));
+         Dn[J] = ldo<T>(Div, rowOff<T>(L.Nbr[Le * TME + J], K, Kv));
+         Rv[J] = ldo<T>(RelVort, rowOff<T>(L.Ring[Le * TME + J], K, Kv));
       }
-      const unsigned OffS = offI(ICell, M.IRSCell, CTc);
+      const unsigned OffS = rowOff<T>(ICell, K, Kv);
       const T Ds          = ldo<T>(Div, OffS);
       T Tmp               = splat<T>(0.0);
 #pragma unroll
@@ -792,14 +783,13 @@ struct Del2VertexSelBody {
       }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IVertex, int Kv) const {
-      const unsigned CTc = chunkTerm<T>(Kv, M.ICSCell), CTv = chunkTerm<T>(Kv, M.ICSVertex);
       T D[3], Rn[3];
 #pragma unroll
       for (int J = 0; J < 3; ++J) {
-         D[J]  = ldo<T>(Div, offI(L.Cell[Le * 3 + J], M.IRSCell, CTc));
-         Rn[J] = ldo<T>(RelVort, offI(L.NbrV[Le * 3 + J], M.IRSVertex, CTv));
+         D[J]  = ldo<T>(Div, rowOff<T>(L.Cell[Le * 3 + J], K, Kv));
+         Rn[J] = ldo<T>(RelVort, rowOff<T>(L.NbrV[Le * 3 + J], K, Kv));
       }
-      const unsigned OffS = offI(IVertex, M.IRSVertex, CTv);
+      const unsigned OffS = rowOff<T>(IVertex, K, Kv);
       const T Rs          = ldo<T>(RelVort, OffS);
       T Tmp               = splat<T>(0.0);
 #pragma unroll
@@ -1070,10 +1060,7 @@ template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEd
       const bool WindOn = Fast ? false : (P.WindForcingTendencyEnable != 0);
       const bool DragOn = Fast ? false : (P.BottomDragTendencyEnable != 0);
       const unsigned OffC0 = rowOff<T>(L.C0[Le], K, Kv), OffC1 = rowOff<T>(L.C1[Le], K, Kv);
-      // private intermediates (offI): every vertex array this kernel reads, KE / Div / Del2Div on the two cells
-      const unsigned CTc = chunkTerm<T>(Kv, M.ICSCell), CTv = chunkTerm<T>(Kv, M.ICSVertex);
-      const unsigned OffC0i = offI(L.C0[Le], M.IRSCell, CTc), OffC1i = offI(L.C1[Le], M.IRSCell, CTc);
-      const unsigned OffV0 = offI(L.V0[Le], M.IRSVertex, CTv), OffV1 = offI(L.V1[Le], M.IRSVertex, CTv);
+      const unsigned OffV0 = rowOff<T>(L.V0[Le], K, Kv), OffV1 = rowOff<T>(L.V1[Le], K, Kv);
       const Real InvDc = L.InvDc[Le], InvDv = L.InvDv[Le];
       const T H0 = ldo<T>(H, OffC0), H1 = ldo<T>(H, OffC1);
       T TendV = splat<T>(0.0);
@@ -1093,7 +1080,7 @@ template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEd
             bool First[TM1];
 #pragma unroll
             for (int J = 0; J < TME; ++J) {
-               const unsigned Off = offI(L.ChV[BV + J], M.IRSVertex, CTv);
+               const unsigned Off = rowOff<T>(L.ChV[BV + J], K, Kv);
                normVort<T>(L.FCh[BV + J], Off, QR[J], QF[J]);
             }
 #pragma unroll
@@ -1117,18 +1104,18 @@ template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEd
          TendV += L.Mask[Le] * VortTmp;
       }
       if (KEOn)
-         TendV -= L.Mask[Le] * (ldo<T>(KE, OffC1i) - ldo<T>(KE, OffC0i)) * InvDc;
+         TendV -= L.Mask[Le] * (ldo<T>(KE, OffC1) - ldo<T>(KE, OffC0)) * InvDc;
       if (SSHOn) {
          const T Ssh0 = H0 - L.BD0[Le], Ssh1 = H1 - L.BD1[Le];
          TendV -= L.MaskGrav[Le] * (Ssh1 - Ssh0) * InvDc;
       }
       if (D2On) {
-         const T Del2U = ((ldo<T>(Div, OffC1i) - ldo<T>(Div, OffC0i)) * InvDc -
+         const T Del2U = ((ldo<T>(Div, OffC1) - ldo<T>(Div, OffC0)) * InvDc -
                           (ldo<T>(RelVort, OffV1) - ldo<T>(RelVort, OffV0)) * InvDv);
          TendV += L.C2[Le] * Del2U;
       }
       if (D4On) {
-         const T Del2U = (P.DivFactor * (ldo<T>(Del2Div, OffC1i) - ldo<T>(Del2Div, OffC0i)) * InvDc -
+         const T Del2U = (P.DivFactor * (ldo<T>(Del2Div, OffC1) - ldo<T>(Del2Div, OffC0)) * InvDc -
                           (ldo<T>(Del2RelVort, OffV1) - ldo<T>(Del2RelVort, OffV0)) * InvDv);
          TendV -= L.C4[Le] * Del2U;
       }
@@ -1139,7 +1126,6 @@ template <int TME, bool Fast, bool EPI = false, bool INV = false> struct FusedEd
          setc(TendV, 0, getc(TendV, 0) + L.Mask[Le] * InvThickEdge * NormalStress[IEdge] / P.Density0);
       }
       if (DragOn && (Kv + 1) * W >= KLog) {
-         // (run-time option flags: never launched with the chunk-major layout, KE is [rows][pitch] here)
          const int KBot          = KLog - 1;
          const int Comp          = KBot - Kv * W;
          const Real VelNormEdge  = sqrt(KE[(size_t)L.C0[Le] * K + KBot] + KE[(size_t)L.C1[Le] * K + KBot]);
@@ -1238,7 +1224,7 @@ template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
             OffE[J]     = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
             Uj[J]       = ldo<T>(U, OffE[J]);
             Hn[J]       = ldo<T>(H, rowOff<T>(F & 0x3fffffff, K, Kv));
-            const unsigned OffV = offI(L.Ring[Le * TME + J], M.IRSVertex, chunkTerm<T>(Kv, M.ICSVertex));
+            const unsigned OffV = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
             const T Iv          = ldo<T>(InvThickV, OffV);
             QR[J]               = ldo<T>(RelVortV, OffV) * Iv; // VorticityAuxVars.h:50-53
             QF[J]               = L.FV[Le * TME + J] * Iv;
@@ -1261,17 +1247,16 @@ template <int TME, bool Fast, int Side, int NR = TME> struct CellPVBody {
       for (int I = 0; I < N; ++I) {
          if (L.Role[Le * TME + I] != Side + 1)
             continue;
-         const unsigned OffP = offI(L.Edge[Le * TME + I], M.IRSEdge, chunkTerm<T>(Kv, M.ICSEdge));
          T Acc = splat<T>(0.0);
          if (Side == 1)
-            Acc = ldo<T>(Partial, OffP);
+            Acc = ldo<T>(Partial, OffE[I]);
 #pragma unroll
          for (int J = 1; J < N; ++J) {
             const int Kk     = (I + J) % N;
             const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
             Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Uj[Kk] * NormVort;
          }
-         sto<T>(Partial, OffP, Acc);
+         sto<T>(Partial, OffE[I], Acc);
       }
    }
 };
@@ -1364,10 +1349,6 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
       unsigned OffE[N], OffN[N], OffV[N];
       T Uj[N], Flux[N], QRe[N], QFe[N], Hn[N];
       const unsigned OffS = rowOff<T>(ICell, K, Kv);
-      // private intermediates (offI): the vertex arrays are all private, so OffV is in their layout; KE / Div / Del2Div
-      // and the running PV sums get their offsets from the LDS tables where they are used
-      const unsigned CTc = chunkTerm<T>(Kv, M.ICSCell), CTe = chunkTerm<T>(Kv, M.ICSEdge), CTv = chunkTerm<T>(Kv, M.ICSVertex);
-      const unsigned OffSi = offI(ICell, M.IRSCell, CTc);
       const T Hs          = ldo<T>(H, OffS);
       {
          T QR[N], QF[N];
@@ -1375,7 +1356,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
          for (int J = 0; J < N; ++J) {
             OffE[J] = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
             OffN[J] = rowOff<T>(L.NbrF[Le * TME + J] & 0x3fffffff, K, Kv);
-            OffV[J] = offI(L.Ring[Le * TME + J], M.IRSVertex, CTv);
+            OffV[J] = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
             Uj[J]   = ldo<T>(U, OffE[J]);
             Hn[J]   = ldo<T>(H, OffN[J]);
             const T Iv = ldo<T>(InvThickV, OffV[J]);
@@ -1394,7 +1375,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
       T Acc[N];
 #pragma unroll
       for (int I = 0; I < N; ++I)
-         Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, offI(L.Edge[Le * TME + I], M.IRSEdge, CTe));
+         Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, OffE[I]);
 #pragma unroll
       for (int I = 0; I < N; ++I) {
          if (L.Role[Le * TME + I] != 2)
@@ -1413,7 +1394,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
          Rv[J] = ldo<T>(RelVort, OffV[J]);
          R2[J] = ldo<T>(Del2RelVort, OffV[J]);
       }
-      const T KEs = ldo<T>(KE, OffSi), DivS = ldo<T>(Div, OffSi), D2S = ldo<T>(Del2Div, OffSi);
+      const T KEs = ldo<T>(KE, OffS), DivS = ldo<T>(Div, OffS), D2S = ldo<T>(Del2Div, OffS);
       const T Ssh1 = Hs - L.BDs[Le];
 #pragma unroll
       for (int I = 0; I < N; ++I) {
@@ -1422,21 +1403,20 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
             continue;
          const int Im     = (I + N - 1) % N;
          const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
-         const unsigned OffNi = offI(L.NbrF[Li] & 0x3fffffff, M.IRSCell, CTc);
          StagePre<T> PreU{};
          if (EPI)
             PreU = stagePre<T, true>(E, OffE[I]);
          T TendV = splat<T>(0.0);
          TendV += Acc[I]; // EdgeMask is 1 on a regular edge
-         TendV -= (KEs - ldo<T>(KE, OffNi)) * InvDc;
+         TendV -= (KEs - ldo<T>(KE, OffN[I])) * InvDc;
          const T Ssh0 = Hn[I] - L.BDn[Li];
          TendV -= Grav * (Ssh1 - Ssh0) * InvDc;
          {
-            const T Del2U = ((DivS - ldo<T>(Div, OffNi)) * InvDc - (Rv[I] - Rv[Im]) * InvDvS);
+            const T Del2U = ((DivS - ldo<T>(Div, OffN[I])) * InvDc - (Rv[I] - Rv[Im]) * InvDvS);
             TendV += L.C2[Li] * Del2U;
          }
          {
-            const T Del2U = (P.DivFactor * (D2S - ldo<T>(Del2Div, OffNi)) * InvDc - (R2[I] - R2[Im]) * InvDvS);
+            const T Del2U = (P.DivFactor * (D2S - ldo<T>(Del2Div, OffN[I])) * InvDc - (R2[I] - R2[Im]) * InvDvS);
             TendV -= L.C4[Li] * Del2U;
          }
          if (!EPI || E.StoreTend)
@@ -1534,9 +1514,6 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
       unsigned OffE[TME], OffN[TME];
       T Uj[TME], Hn[TME];
       const unsigned OffS = rowOff<T>(ICell, K, Kv);
-      // private intermediates (offI), as in CellPVFinalBody
-      const unsigned CTc = chunkTerm<T>(Kv, M.ICSCell), CTe = chunkTerm<T>(Kv, M.ICSEdge), CTv = chunkTerm<T>(Kv, M.ICSVertex);
-      const unsigned OffSi = offI(ICell, M.IRSCell, CTc);
       const T Hs          = ldo<T>(H, OffS);
 #pragma unroll
       for (int J = 0; J < TME; ++J) {
@@ -1560,7 +1537,7 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
             T QR[N], QF[N];
 #pragma unroll
             for (int J = 0; J < N; ++J) {
-               OffV[J]    = offI(L.Ring[Le * TME + J], M.IRSVertex, CTv);
+               OffV[J]    = rowOff<T>(L.Ring[Le * TME + J], K, Kv);
                const T Iv = ldo<T>(InvThickV, OffV[J]);
                QR[J]      = ldo<T>(RelVortV, OffV[J]) * Iv;
                QF[J]      = L.FV[Le * TME + J] * Iv;
@@ -1578,7 +1555,7 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
          T Acc[N];
 #pragma unroll
          for (int I = 0; I < N; ++I)
-            Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, offI(L.Edge[Le * TME + I], M.IRSEdge, CTe));
+            Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, OffE[I]);
 #pragma unroll
          for (int I = 0; I < N; ++I) {
             if (L.Role[Le * TME + I] != 2)
@@ -1596,7 +1573,7 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
             Rv[J] = ldo<T>(RelVort, OffV[J]);
             R2[J] = ldo<T>(Del2RelVort, OffV[J]);
          }
-         const T KEs = ldo<T>(KE, OffSi), DivS = ldo<T>(Div, OffSi), D2S = ldo<T>(Del2Div, OffSi);
+         const T KEs = ldo<T>(KE, OffS), DivS = ldo<T>(Div, OffS), D2S = ldo<T>(Del2Div, OffS);
          const T Ssh1 = Hs - L.BDs[Le];
 #pragma unroll
          for (int I = 0; I < N; ++I) {
@@ -1605,8 +1582,7 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
                continue;
             const int Im     = (I + N - 1) % N;
             const Real InvDc = L.InvDc[Li], InvDvS = L.InvDvS[Li];
-            const unsigned OffNi = offI(L.NbrF[Li] & 0x3fffffff, M.IRSCell, CTc);
-            const T KEnI = ldo<T>(KE, OffNi), DivNI = ldo<T>(Div, OffNi), D2NI = ldo<T>(Del2Div, OffNi);
+            const T KEnI = ldo<T>(KE, OffN[I]), DivNI = ldo<T>(Div, OffN[I]), D2NI = ldo<T>(Del2Div, OffN[I]);
             T TendV = splat<T>(0.0);
             TendV += Acc[I];
             TendV -= (KEs - KEnI) * InvDc;
@@ -1642,10 +1618,10 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
 #pragma unroll
             for (int J = 0; J < TME; ++J) {
                Tn[Q][J] = ldoIf<T>(Valid, TrL, OffN[J]);
-               Dn[Q][J] = ldoIf<T>(Valid, D2L, offI(L.NbrF[Le * TME + J] & 0x3fffffff, M.IRSCell, CTc)); // (private: offI)
+               Dn[Q][J] = ldoIf<T>(Valid, D2L, OffN[J]);
             }
             Ts[Q] = ldoIf<T>(Valid, TrL, OffS);
-            Ds[Q] = ldoIf<T>(Valid, D2L, OffSi);
+            Ds[Q] = ldoIf<T>(Valid, D2L, OffS);
          }
 #pragma unroll
          for (int Q = 0; Q < TU; ++Q) {
@@ -1849,8 +1825,6 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
       }
       const T Hs = ldo<T>(H, OffS);
       const size_t CStride = (size_t)M.NCellsSize * K;
-      const unsigned CTc   = chunkTerm<T>(Kv, M.ICSCell); // Del2Tracers is a private intermediate (offI)
-      const unsigned OffSi = offI(ICell, M.IRSCell, CTc);
       // stage update (EPI): thicknesses this cell's tracer update divides / multiplies by
       T EpCurH = Hs, EpDivH = Hs;
       if (EPI) { // (both asked for with the gathers above; the first is switched off where the stage does not read it)
@@ -1867,10 +1841,10 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
 #pragma unroll
          for (int J = 0; J < TME; ++J) {
             Tn[J] = ldo<T>(TrL, OffN[J]);
-            Dn[J] = HypOn ? ldo<T>(D2L, offI(L.NbrF[Le * TME + J] & 0x3fffffff, M.IRSCell, CTc)) : splat<T>(0.0);
+            Dn[J] = HypOn ? ldo<T>(D2L, OffN[J]) : splat<T>(0.0);
          }
          const T Ts = ldo<T>(TrL, OffS);
-         const T Ds = HypOn ? ldo<T>(D2L, OffSi) : splat<T>(0.0);
+         const T Ds = HypOn ? ldo<T>(D2L, OffS) : splat<T>(0.0);
          // stage update operands (EPI), asked for with the gathers instead of after the arithmetic; switched off
          // through the offset in the stages that do not read them
          Real *NextL = nullptr;
@@ -1962,32 +1936,9 @@ bool fusedRHSSupported(const MeshView &M, int K) {
 /// cells have one edge fewer than the widest (hexagons with a few heptagons).  NA = the other of the two; cells of
 /// valence NA and TME-2 go through list launches.
 template <int TME, bool Fast, int ND = TME>
-static void launchFusedT(const MeshView &MIn, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
+static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
                          Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
-                         hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage, const MeshView *WideIn = nullptr,
-                         bool ChunkMajor = false) {
-   // layout of the private intermediates for this evaluation (offI): both views carry it to every body
-   MeshView M = MIn, WideL{};
-   const MeshView *Wide = nullptr;
-   {
-      const unsigned PitchB = (unsigned)levelPitch(K) * 8u;
-      auto SetLayout        = [&](MeshView &V) {
-         // (option ChunkMajor is a mask: 1 cell-, 2 edge-, 4 vertex-located intermediates; 7 / any value without the low
-         // three bits clear = all)
-         const int Mask = ChunkMajor ? tuning().ChunkMajor : 0;
-         const bool Cc = Mask & 1, Ce = Mask & 2, Cv = Mask & 4;
-         V.IRSCell = Cc ? 128u : PitchB, V.IRSEdge = Ce ? 128u : PitchB, V.IRSVertex = Cv ? 128u : PitchB;
-         V.ICSCell   = Cc ? (unsigned)V.NCellsSize * 128u : 128u;
-         V.ICSEdge   = Ce ? (unsigned)V.NEdgesSize * 128u : 128u;
-         V.ICSVertex = Cv ? (unsigned)V.NVerticesSize * 128u : 128u;
-      };
-      SetLayout(M);
-      if (WideIn) {
-         WideL = *WideIn;
-         SetLayout(WideL);
-         Wide = &WideL;
-      }
-   }
+                         hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage, const MeshView *Wide = nullptr) {
    // Wide != nullptr: M is the mesh's NARROW view (cell tables TME wide) and *Wide the full-width one; the cells with
    // TW = TME+1 edges (Wide->WideCells: the heptagons of a hexagon mesh) are skipped by every sweep over M and run
    // through list launches of the TW-slot bodies on *Wide, level by level.
@@ -2514,16 +2465,6 @@ static void launchFusedT(const MeshView &MIn, int K, int NT, const TendParams &P
    Pacer::stop("Tend:fused:L3", 2);
 }
 
-/// Level-chunk-major intermediates (offI) need every kernel that touches them to be one of the converted bodies: the
-/// default term set on a mesh that takes the merged level-1 kernel, the ring-form del2 kernels and the fused final
-/// pass -- the structure every generated and every culled mesh runs.  Anything else keeps [rows][pitch].
-bool fusedChunkMajor(const MeshView &M, int K, const TendParams &P, const Real *EdgeScratch) {
-   const TuningOptions &Tn = tuning();
-   return (Tn.ChunkMajor & 7) != 0 && isDefaultTermSet(P) && Tn.EdgeMode == 0 && Tn.MergeL1 != 0 && Tn.FuseFinal != 0 && EdgeScratch &&
-          M.CellPVOK && M.CellL1OK && M.CellPVFinalOK && M.Del2RingOK && M.Del2VertOK && levelPitch(K) % 16 == 0 &&
-          M.MaxEdges >= 5 && M.MaxEdges <= 8;
-}
-
 /// does the stage-fused variant cover this mesh / option set?  (same conditions launchFusedT checks
 /// on its way to CellPVFinalBody)
 static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *EdgeScratch) {
@@ -2533,9 +2474,8 @@ static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *Ed
 
 bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S, hipEvent_t *Ev,
-                    Real *EdgeScratch, const StageUpdate *Stage, const MeshView *Narrow, bool ChunkMajor) {
+                    Real *EdgeScratch, const StageUpdate *Stage, const MeshView *Narrow) {
    const bool Fast = isDefaultTermSet(P);
-   OMEGA_REQUIRE(!ChunkMajor || fusedChunkMajor(M, K, P, EdgeScratch), "launchFusedRHS: chunk-major layout not available here");
    if (Stage && !stageFusedSupported(M, P, EdgeScratch))
       return false;
    // narrow cell tables (HorzMesh::narrowView): the sweeps run the (MaxEdges-1)-slot kernels on them, the cells with
@@ -2546,8 +2486,7 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
 #define OMEGA_NARROW_CASE(MN_)                                                                                     \
    case MN_:                                                                                                       \
       if (Fast)                                                                                                    \
-         launchFusedT<MN_, true>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage, &M,  \
-                                 ChunkMajor);                                                                      \
+         launchFusedT<MN_, true>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage, &M); \
       else                                                                                                         \
          launchFusedT<MN_, false>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr, &M); \
       return true;
@@ -2565,12 +2504,11 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
       if constexpr ((ME_) >= 6) {                                                                                  \
          if (M.DomM1) {                                                                                            \
             launchFusedT<ME_, true, (ME_)-1>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch,   \
-                                             Stage, nullptr, ChunkMajor);                                          \
+                                             Stage);                                                               \
             break;                                                                                                 \
          }                                                                                                         \
       }                                                                                                            \
-      launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage, nullptr,  \
-                              ChunkMajor);                                                                         \
+      launchFusedT<ME_, true>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage);          \
    } while (0)
 #define OMEGA_CASE(ME_)                                                                                            \
    case ME_:                                                                                                       \

@@ -98,11 +98,7 @@ struct StageUpdate {
 bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
                     Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
                     hipEvent_t *Ev = nullptr, Real *EdgeScratch = nullptr, const StageUpdate *Stage = nullptr,
-                    const MeshView *Narrow = nullptr, bool ChunkMajor = false);
-/// ChunkMajor: the intermediates in A (KE, Div, Del2Div, RelVort, InvThick, Del2RelVort, Del2Tracers) and EdgeScratch are
-/// stored [pitch/16][rows][16] for this evaluation; only where fusedChunkMajor() says so, and the arrays must hold zeros
-/// wherever the layout has its sentinel rows (Tendencies re-zeroes them when the layout changes)
-bool fusedChunkMajor(const MeshView &M, int K, const TendParams &P, const Real *EdgeScratch);
+                    const MeshView *Narrow = nullptr);
 /// Narrow: HorzMesh::narrowView() -- the per-(cell, slot) tables stored MaxEdges-1 wide; the sweeps then run the
 /// (MaxEdges-1)-slot kernels on them and the cells with MaxEdges edges (M.WideCells) go through list launches on M
 /// EdgeScratch: optional [NEdgesSize][K] work array for the cell-centric PV sums (faster path)

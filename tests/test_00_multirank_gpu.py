@@ -144,9 +144,9 @@ def test_unmerged_unpaired_kernel_structure_in_a_child_process():
 
 
 def test_paired_level3_launch_for_the_plain_rhs_in_a_child_process():
-    """Options FuseL3 = 0, ChunkMajor = 0 (the private intermediates as [rows][pitch], round 2's layout): the plain RHS runs CellPVFinalBody + FusedCell3Body as the paired launch the RK4 stages use
+    """Option FuseL3 = 0: the plain RHS runs CellPVFinalBody + FusedCell3Body as the paired launch the RK4 stages use
     (default: both in one thread, CellPVFinalTracerBody); same bits required."""
-    env = dict(os.environ, OMEGA_AMD_OPTIONS="FuseL3=0,ChunkMajor=0")
+    env = dict(os.environ, OMEGA_AMD_OPTIONS="FuseL3=0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
                         "compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500 or coast)"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)

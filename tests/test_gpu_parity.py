@@ -169,40 +169,6 @@ def test_generic_flags_follow_the_environment():
         assert P.mesh.get_int(flag) == want, flag
 
 
-@pytest.mark.parametrize("name", [(20, 24, 30e3, 80, 6, {}), ("fib1500_coast_ragged", 0, 0, 20, 2, {})], ids=["hex_K80", "fib_coast_K20"])
-def test_private_intermediates_survive_a_layout_switch(name):
-    """The fused RHS keeps its intermediates in private arrays, level-chunk-major [pitch/16][rows][16] where every kernel
-    of the evaluation supports it (option ChunkMajor, default 1), [rows][pitch] otherwise.  The zero sentinel rows sit at
-    different addresses in the two layouts: switching on a live Tendencies object must re-zero the arrays, and both
-    layouts must give the oracle's bits (RHS and an RK4 step: the stage-fused kernels read the same arrays)."""
-    P = _mk(name)
-    m = P.mesh
-    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
-    old = oa.get_option("ChunkMajor")
-    try:
-        for cm in (7, 0, 5, 2, 7, 0):
-            oa.set_option("ChunkMajor", cm)
-            P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
-            oa.device_synchronize()
-            check(f"hTend cm={cm}", P.tend.get(0), hT, m.NCellsOwned)
-            check(f"uTend cm={cm}", P.tend.get(1), uT, m.NEdgesOwned)
-            check(f"trTend cm={cm}", P.tend.get(2)[: name[4]], trT[: name[4]], m.NCellsOwned)
-        dt = 5.0 if isinstance(name[0], str) else 600.0
-        ost = P.oracle.make_state(P.h, P.u, P.tr)
-        st = oa.TimeStepper("RungeKutta4", dt, P.tend, P.aux, P.mesh, None, P.tracers)
-        for cm in (7, 0):
-            oa.set_option("ChunkMajor", cm)
-            st.do_step(P.state)
-            oa.device_synchronize()
-            P.oracle.step("rk4", ost, dt)
-            h, u = P.state.copy_to_host(0)
-            check(f"h cm={cm}", h, ost["h"][0], m.NCellsOwned)
-            check(f"u cm={cm}", u, ost["u"][0], m.NEdgesOwned)
-            check(f"tr cm={cm}", P.tracers.copy_to_host(0), ost["tr"][0], m.NCellsOwned)
-    finally:
-        oa.set_option("ChunkMajor", old)
-
-
 def test_group_tendencies_fb_path():
     """computeThicknessTendencies / computeTracerTendencies / computeVelocityTendencies
     (the ForwardBackward stepper's calls, Tendencies.cpp:488-575)."""

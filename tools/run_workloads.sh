@@ -8,7 +8,7 @@ WL=${*:-qu30 ec30to60 qu240 qu30_eighth ico7 orrs18to6_eighth ico8}
 mkdir -p gpurun_out
 for w in $WL; do
    extra=""
-   { [ "$w" = orrs18to6_eighth ] || [ "$w" = fib7 ]; } && extra="--rk4-steps 0"
+   case "$w" in orrs18to6_eighth|fib7|fib7_coast) extra="--rk4-steps 0";; esac
    timeout -k 10 900 python3 bench.py --workload $w --no-cpu-baseline $extra > gpurun_out/${TAG}_wl_$w.json 2> gpurun_out/${TAG}_wl_$w.err
    python3 - <<PY
 import json
