@@ -317,3 +317,58 @@ def test_mesh_file_with_a_coast_through_the_reader(_gpu, tmp_path):
     _check("hTend", tend.get(0), hT, mesh.NCellsOwned)
     _check("uTend", tend.get(1), uT, mesh.NEdgesOwned)
     _check("trTend", tend.get(2)[:NT], trT[:NT], mesh.NCellsOwned)
+
+
+def _random_coast_cases(n, seed=77):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        base = str(rng.choice(["hex20x16", "hex28x18", "ico3", "fib700", "hex24x20_pad8"]))
+        frac = float(rng.choice([0.03, 0.1, 0.25, 0.45, 0.6]))
+        K = int(rng.choice([1, 3, 16, 17, 40, 64]))
+        NT = int(rng.choice([0, 1, 3]))
+        raw, compact = bool(rng.integers(2)), bool(rng.integers(2))
+        cfg = {}
+        if i % 2:
+            for f in ("FluxThicknessUpwind", "FluxTracerUpwind", "VelHyperDiffTendencyEnable", "PVTendencyEnable",
+                      "TracerHyperDiffTendencyEnable", "BottomDragTendencyEnable"):
+                if rng.random() < 0.35:
+                    cfg[f] = int(not getattr(O.default_config(), f))
+        out.append((base, frac, int(rng.integers(1 << 30)), K, NT, raw, compact, cfg))
+    return out
+
+
+@gpu
+@pytest.mark.parametrize("case", _random_coast_cases(32), ids=lambda c: f"{c[0]}_land{int(100 * c[1])}_K{c[3]}_NT{c[4]}_{'raw' if c[5] else 'cull'}{'_compact' if c[6] else ''}_{len(c[7])}opts")
+def test_random_coasts(_gpu, case):
+    """Random land (3 ... 60 % of the cells, each cell independently: isolated ocean cells, one-cell channels, every
+    vertex and edge pattern a culler can leave), both boundary-edge conventions, holes kept or compacted, random level /
+    tracer counts and option sets: fused RHS and one RK4 step against the oracle, bit for bit on owned elements."""
+    base, frac, seed, K, NT, raw, compact, cfg = case
+    g0 = named_mesh(base)
+    keep = np.random.default_rng(seed).random(g0["nCells"]) >= frac
+    g = cull(g0, keep, first_cell_valid=not raw, compact_edges_on_edge=compact)
+    P = Problem(g, K, NT, config=cfg)
+    m = P.mesh
+    assert m.get_int("NIrregularEdges") >= int(g["boundaryEdge"].sum()) > 0
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    _check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+    _check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+    if NT:
+        _check("trTend", P.tend.get(2)[:NT], trT[:NT], m.NCellsOwned)
+    if not base.startswith("fib"):         # (a few very short edges: not a stable step at dt = 600 s)
+        hg, ug, trg = synthetic_state(g, K, NT)
+        P.u = to_local(zero_boundary_velocity(g, ug), P.edge_id, m.NEdgesSize)
+        P.state.copy_to_device(P.h, P.u, 0)
+        st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+        ost = P.oracle.make_state(P.h, P.u, P.tr)
+        st.do_step(P.state)
+        oa.device_synchronize()
+        P.oracle.step("rk4", ost, 600.0)
+        h, u = P.state.copy_to_host(0)
+        _check("h", h, ost["h"][0], m.NCellsOwned)
+        _check("u", u, ost["u"][0], m.NEdgesOwned)
+        if NT:
+            _check("tr", P.tracers.copy_to_host(0)[:NT], ost["tr"][0][:NT], m.NCellsOwned)
