@@ -31,7 +31,7 @@ PeerWire::PeerWire(int NRanks_, int Rank_, size_t MailboxBytes_)
    Status  = static_cast<int *>(St);
    *Status = 0;
    HIP_CHECK(hipDeviceSynchronize());
-   setTimeout(20.0);
+   setTimeout(60.0);
    PeerMailbox.assign(NRanks, nullptr);
    PeerFlags.assign(NRanks, nullptr);
    PeerMailboxBytes.assign(NRanks, 0);

@@ -62,7 +62,7 @@ class PeerWire {
    /// 0, or the sticky failure raised by a wait kernel that gave up (bit 0: "consumed" wait, bit 1: "arrived" wait)
    int status() const;
    const std::string &lastError() const { return LastError; }
-   /// how long a wait kernel spins before it gives up [s] (default 20)
+   /// how long a wait kernel spins before it gives up [s] (default 60)
    void setTimeout(double Seconds);
 
  private:
