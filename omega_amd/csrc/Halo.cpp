@@ -104,6 +104,8 @@ void Halo::usePeerWire(PeerWire *Wire) {
    OMEGA_REQUIRE(Wire != nullptr && Wire->connected(), "Halo::usePeerWire: the wire is not connected");
    OMEGA_REQUIRE(Wire->Rank == MyTask, "Halo::usePeerWire: the wire's rank is not this Halo's task");
    OMEGA_REQUIRE(NNghbr <= PeerWire::MaxPeers, "Halo::usePeerWire: too many neighbours");
+   OMEGA_REQUIRE(!Wire->Bound || Peer == Wire, "Halo::usePeerWire: this wire already serves another Halo");
+   Wire->Bound = true;
    for (I4 T : NeighborList)
       OMEGA_REQUIRE(T < Wire->NRanks, "Halo::usePeerWire: a neighbour task is outside the wire");
    Peer      = Wire;

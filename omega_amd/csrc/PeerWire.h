@@ -47,6 +47,8 @@ class PeerWire {
    /// the sense that every rank must call it before the first exchange; it does not communicate.
    void connect(const char *All);
    bool connected() const { return Connected; }
+   /// One wire serves ONE Halo (the exchange counter and the mailbox layout are that Halo's): set by Halo::usePeerWire
+   bool Bound = false;
 
    void *mailbox() const { return Mailbox; }
    size_t mailboxBytes() const { return MailboxBytes; }
