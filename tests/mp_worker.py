@@ -9,6 +9,7 @@ mode gpu: the full product path on the GPU -- C++ Halo::exchange* with HIP pack/
           share one GPU), against the same single-rank oracle.
 """
 import argparse
+import ctypes as C
 import os
 import sys
 
@@ -46,6 +47,9 @@ def main():
                     help="gpu mode: gloo = host-staged test wire (synchronises the stream); ipc = the library's PeerWire "
                          "(HIP IPC mailboxes + flag kernels, fully stream-ordered: exercises the event ordering of the "
                          "overlapped exchanges for real)")
+    ap.add_argument("--stress", type=int, default=0,
+                    help="gpu mode: this many back-to-back exchanges of changing data, alternating between two non-blocking "
+                         "streams, every one verified (flag / visibility races of a stream-ordered wire would show here)")
     ap.add_argument("--peer-timeout-test", action="store_true",
                     help="--wire ipc: rank 0 exchanges while the others never do: its wait kernel must give up after the "
                          "wire's time limit, raise the sticky status and make the next exchange fail loudly -- no hang")
@@ -169,6 +173,28 @@ def main():
                 got = buf.to_host()
                 assert np.array_equal(got, ref), f"rank {a.rank}: halo exchange mismatch elem {elem} {dtype.__name__} nt {nt} k {k}"
 
+    if gpu and a.stress > 0:
+        streams = [oa.Stream(), oa.Stream()]
+        elem, nt = 0, 2
+        base = np.zeros((nt, sizes[elem], K))
+        base[:, : nall[elem], :] = ids[elem][None, : nall[elem], None] * 3.0 + np.arange(K)[None, None, :]
+        bufs = [oa.DeviceBuffer(base.copy()) for _ in range(7)]   # one per exchange of a batch: nothing is reused before
+        for it in range(a.stress):                               # the batch has been synchronised and checked
+            b, st = bufs[it % 7], streams[it % 2]
+            ref = base + it
+            ref[:, nall[elem]:, :] = 0.0
+            arr = ref.copy()
+            arr[:, owned[elem]: nall[elem], :] = -1.0          # halo rows must come from the owners, every time
+            oa._chk(oa.lib().omg_copy_to_device(C.c_void_p(b.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+            halo.exchange(b.ptr, nt, sizes[elem], K, elem, stream=st)
+            if it % 7 == 6 or it == a.stress - 1:               # seven exchanges queue up, then all of them are checked
+                oa.device_synchronize()
+                for j in range(it - it % 7, it + 1):
+                    want = base + j
+                    want[:, nall[elem]:, :] = 0.0
+                    got = bufs[j % 7].to_host().reshape(want.shape)
+                    assert np.array_equal(got, want), f"rank {a.rank}: stress exchange {j} wrong"
+
     # ---------------- (b) time stepping: partitioned run vs single-rank oracle ----------------
     okind = {"RungeKutta4": "rk4", "RungeKutta2": "rk2", "Forward-Backward": "fb"}[a.stepper]
     Mg = O.Mesh.single_rank(g, K)
@@ -232,7 +258,7 @@ def main():
     note = ""
     if wire is not None:
         info = wire.info()
-        assert info["status"] == 0 and info["exchanges"] >= 6 + 15 + a.steps, info
+        assert info["status"] == 0 and info["exchanges"] >= 6 + 15 + a.steps + a.stress, info
         note = f", peer wire: {info['exchanges']} exchanges"
     dist.barrier()          # every rank's GPU work is complete (device_synchronize above): mailboxes may go
     if wire is not None:

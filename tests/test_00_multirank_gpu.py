@@ -69,6 +69,16 @@ def test_peer_wire_stream_ordered_exchanges(world, extra):
     assert all("OK" in o and "peer wire" in o for o in outs)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_wire_under_back_to_back_exchanges(world):
+    """150 exchanges of changing data queued back to back on two alternating non-blocking streams, every result
+    verified: the flag protocol (consumed / arrived counters, release stores, acquire loads on uncached memory) and the
+    reuse of the one mailbox per rank under pressure."""
+    outs = run_ranks("gpu", world, ["--wire", "ipc", "--stress", 150, "--halo-width", 4, "--nx", 48, "--ny", 48,
+                                    "--levels", 8, "--steps", 1], timeout=900)
+    assert all("OK" in o and "peer wire" in o for o in outs)
+
+
 def test_peer_wire_gives_up_on_a_silent_peer():
     """A rank whose neighbour never takes part in an exchange: the wait kernel leaves after the wire's time limit
     (every wave reaches its exit), the status is sticky and the next exchange fails with a message."""
