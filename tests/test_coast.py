@@ -372,3 +372,27 @@ def test_random_coasts(_gpu, case):
         _check("u", u, ost["u"][0], m.NEdgesOwned)
         if NT:
             _check("tr", P.tracers.copy_to_host(0)[:NT], ost["tr"][0][:NT], m.NCellsOwned)
+
+
+@gpu
+def test_qu30_sized_culled_mesh_at_full_size(_gpu):
+    """BASELINE configs[3] as the real mesh is: culled.  800 x 800 hexagons with 28 % land removed ("continents" + one-cell
+    islands: 459 955 cells, 14 910 boundary edges -- bench.py's qu30_coast workload), 80 levels, 6 tracers, numbered by
+    Decomp along the curve: fused RHS element by element against the oracle, fast paths on."""
+    import gc
+    g0 = planar_hex(800, 800, 30.0e3)
+    g = cull(g0, coast_mask(g0, "continents"))
+    del g0
+    P = Problem(g, 80, 6, local_order="curve")
+    m = P.mesh
+    for flag in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK", "Del2VertOK"):
+        assert m.get_int(flag) == 1, flag
+    assert m.get_int("NIrregularEdges") == int(g["boundaryEdge"].sum()) > 10000
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    _check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+    _check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+    _check("trTend", P.tend.get(2), trT, m.NCellsOwned)
+    del P
+    gc.collect()
