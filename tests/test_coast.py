@@ -260,6 +260,31 @@ def test_time_steppers_on_a_coast(_gpu, name, kind, okind, fuse):
 
 
 @gpu
+def test_fifty_rk4_steps_on_a_coast_stay_on_the_oracles_bits(_gpu):
+    """A longer run: 50 RK4 steps (dt = 600 s, 30 km cells, no flow through the coast) on a culled mesh -- the state is
+    still bit-identical to the oracle's at the end, and finite."""
+    g = named_mesh("hex32x24_coast_mixed")
+    K, NT = 6, 2
+    P = Problem(g, K, NT)
+    hg, ug, trg = synthetic_state(g, K, NT)
+    P.u = to_local(zero_boundary_velocity(g, ug), P.edge_id, P.mesh.NEdgesSize)
+    P.state.copy_to_device(P.h, P.u, 0)
+    st = oa.TimeStepper("RungeKutta4", 600.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    for _ in range(50):
+        st.do_step(P.state)
+        P.oracle.step("rk4", ost, 600.0)
+    oa.device_synchronize()
+    h, u = P.state.copy_to_host(0)
+    tr = P.tracers.copy_to_host(0)
+    m = P.mesh
+    assert np.isfinite(ost["h"][0]).all() and np.isfinite(ost["u"][0]).all() and (ost["h"][0][: m.NCellsOwned] > 0.5).all()
+    _check("h", h, ost["h"][0], m.NCellsOwned)
+    _check("u", u, ost["u"][0], m.NEdgesOwned)
+    _check("tr", tr, ost["tr"][0], m.NCellsOwned)
+
+
+@gpu
 def test_rk4_conserves_volume_and_tracer_content_in_a_closed_basin(_gpu):
     """RK4 on a culled mesh with u = 0 on the coast: total volume and tracer content (device double-double sums)
     are conserved to rounding over 5 steps."""
