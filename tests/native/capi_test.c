@@ -127,6 +127,57 @@ int main(int argc, char **argv) {
    if (t != 600.0)
       printf("FAIL: stepper time %g\n", t), ++fails;
 
+   /* round 3 entry points, from plain C: options instead of environment variables, the roctx timing level, a halo of
+      a one-rank decomposition (nothing travels; every element type must still return 0), a one-rank peer wire
+      (mailbox + flags allocated, exported, the rank's own handle block accepted by connect, attached to the halo) */
+   {
+      int v = -99;
+      OK(omg_get_option("MergeL1", &v));
+      if (v != 1)
+         printf("FAIL: option MergeL1 default %d\n", v), ++fails;
+      OK(omg_set_option("MergeL1", 0));
+      OK(omg_get_option("MergeL1", &v));
+      if (v != 0)
+         printf("FAIL: omg_set_option\n"), ++fails;
+      OK(omg_set_option("MergeL1", 1));
+      if (omg_set_option("NoSuchOption", 1) == 0)
+         printf("FAIL: unknown option accepted\n"), ++fails;
+      OK(omg_set_timing_level(2));
+      omg_halo *halo;
+      OK(omg_halo_create(decomp, &halo));
+      int nn = -1;
+      OK(omg_halo_num_neighbors(halo, &nn));
+      if (nn != 0)
+         printf("FAIL: one rank has %d neighbours\n", nn), ++fails;
+      size_t rows = 99;
+      OK(omg_halo_recv_rows(halo, 7, 1, 0, &rows));
+      if (rows != 0)
+         printf("FAIL: one rank receives %zu rows\n", rows), ++fails;
+      void *di4, *dr8;
+      OK(omg_device_malloc((size_t)ncs * 3 * sizeof(int32_t), &di4));
+      OK(omg_device_malloc((size_t)ncs * sizeof(double), &dr8));
+      OK(omg_halo_exchange_i4(halo, (int32_t *)di4, 1, ncs, 3, 0, 0, stream));       /* I4, rank 2 */
+      OK(omg_halo_exchange_bytes(halo, dr8, 8, 1, ncs, 1, 1, 0, stream));              /* R8, rank 1 */
+      omg_peer *pw;
+      char handle[OMG_PEER_HANDLE_BYTES];
+      OK(omg_peer_create(1, 0, 4096, &pw));
+      OK(omg_peer_local_handle(pw, handle));
+      OK(omg_peer_connect(pw, handle));
+      OK(omg_peer_set_timeout(pw, 5.0));
+      OK(omg_halo_use_peer(halo, pw));
+      OK(omg_halo_exchange(halo, (double *)dr8, 1, ncs, 1, 1, 0, stream));
+      int64_t nex = -1;
+      int st = -1;
+      OK(omg_peer_info(pw, &nex, &st));
+      if (st != 0)
+         printf("FAIL: peer wire status %d\n", st), ++fails;
+      OK(omg_stream_synchronize(stream));
+      OK(omg_halo_destroy(halo));
+      OK(omg_peer_destroy(pw));
+      OK(omg_device_free(di4));
+      OK(omg_device_free(dr8));
+   }
+
    OK(omg_stepper_destroy(stepper));
    OK(omg_tend_destroy(tend));
    OK(omg_aux_destroy(aux));
