@@ -1,6 +1,9 @@
 // Device.cpp -- HIP memory helpers and the error sink.
 #include "Base.h"
+#include "Pacer.h"
 #include "Tuning.h"
+
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <cctype>
 #include <cstdlib>
@@ -69,6 +72,23 @@ bool getTuningOption(const std::string &Name, int &Value) {
       }
    return false;
 }
+
+namespace Pacer {
+int &timingLevel() {
+   static int Level = 3;
+   return Level;
+}
+bool start(const char *Name, int Level) {
+   if (Level <= timingLevel())
+      roctxRangePushA(Name);
+   return true;
+}
+bool stop(const char * /*Name*/, int Level) {
+   if (Level <= timingLevel())
+      roctxRangePop();
+   return true;
+}
+} // namespace Pacer
 
 void abortError(const char *File, int Line, const std::string &Msg) {
    std::ostringstream OS;

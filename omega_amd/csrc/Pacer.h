@@ -10,26 +10,14 @@
 #ifndef OMEGA_AMD_PACER_H
 #define OMEGA_AMD_PACER_H
 
-#include <rocprofiler-sdk-roctx/roctx.h>
-
 namespace OMEGA {
 namespace Pacer {
 
+// (defined in Device.cpp: code that includes this header links libomega_amd only, not the roctx library)
 /// timers above this level are not emitted (reference: Pacer::setTimingLevel, Pacer.cpp:138-150)
-inline int &timingLevel() {
-   static int Level = 3;
-   return Level;
-}
-inline bool start(const char *Name, int Level = 0) {
-   if (Level <= timingLevel())
-      roctxRangePushA(Name);
-   return true;
-}
-inline bool stop(const char * /*Name*/, int Level = 0) {
-   if (Level <= timingLevel())
-      roctxRangePop();
-   return true;
-}
+int &timingLevel();
+bool start(const char *Name, int Level = 0);
+bool stop(const char *Name, int Level = 0);
 /// scoped start / stop
 struct Range {
    int Level;

@@ -18,6 +18,9 @@
 #include "OceanState.h"
 #include "Tendencies.h"
 #include "TimeStepper.h"
+#include "Pacer.h"
+#include "PeerWire.h"
+#include "Tuning.h"
 
 #include <cmath>
 #include <cstdio>
@@ -146,6 +149,25 @@ int main(int argc, char **argv) {
       Array2DReal Hc;
       State->getLayerThickness(Hc, 0);
       CHECK(DefHalo->exchangeFullArrayHalo(Hc, OnCell, S) == 0 && State->exchangeHalo(0, S) == 0, "exchangeFullArrayHalo");
+      // (round 3) the reference's other element types by the same name, the timer ranges and the options of this build
+      {
+         Array1DI4 Ids("Ids", DefMesh->NCellsSize);
+         Array2DI4 Pairs("Pairs", DefMesh->NEdgesSize, 2);
+         Array1DReal Depth("Depth", DefMesh->NCellsSize);
+         CHECK(DefHalo->exchangeFullArrayHalo(Ids, OnCell, S) == 0 && DefHalo->exchangeFullArrayHalo(Pairs, OnEdge, S) == 0 &&
+                   DefHalo->exchangeFullArrayHalo(Depth, OnCell, S) == 0,
+               "exchangeFullArrayHalo for Array1DI4 / Array2DI4 / Array1DReal");
+         Pacer::Range Timer("boundary_test:customRange", 1); // the reference's Pacer::start / stop as a roctx range
+         int V = -1;
+         CHECK(getTuningOption("NarrowTables", V) && V == 1 && !setTuningOption("NoSuchOption", 1), "tuning options");
+         CHECK(DefMesh->narrowView() == nullptr && DefMesh->view().NWideCells >= 0,
+               "narrowView: a mesh of hexagons stored 6 wide needs no second table set");
+         PeerWire Wire(1, 0, 4096);
+         char Handle[PeerWire::HandleBytes];
+         Wire.localHandle(Handle);
+         Wire.connect(Handle);
+         CHECK(Wire.connected() && Wire.status() == 0 && Wire.mailboxBytes() >= 4096, "PeerWire: one-rank wire");
+      }
 
       // HorzOperators functor object
       {
