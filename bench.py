@@ -48,6 +48,7 @@ WORKLOADS = {
     "fib7": (0, -163842, 0.0, 80, 6, "spherical Voronoi mesh of a relaxed Fibonacci lattice, 163842 cells (pentagons, "
                                      "hexagons AND heptagons: maxEdges 7 with valence 6 dominant, as real MPAS meshes), 80L, 6 tracers"),
     "ico6": (0, 6, 0.0, 60, 2, "spherical icosahedral Voronoi mesh, 40962 cells (12 pentagons), 60L, 2 tracers"),
+    "ico5": (0, 5, 0.0, 60, 2, "QU240-sized ON THE SPHERE: icosahedral Voronoi mesh, 10242 cells (12 pentagons), 60L, 2 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
     # culled meshes (land removed the way MPAS ocean meshes are: omega_amd/meshgen.py cull / coast_mask "continents")
     "qu30_coast": (800, 800, 30.0e3, 80, 6, "QU30-sized CULLED planar mesh: 800x800 hexagons with 28 % land removed "

@@ -30,6 +30,7 @@ const OptionName OptionTable[] = {
     {"MergeL1", &TuningOptions::MergeL1},
     {"Pair", &TuningOptions::Pair},
     {"FuseL3", &TuningOptions::FuseL3},
+    {"FoldLists", &TuningOptions::FoldLists},
     {"Alternate", &TuningOptions::Alternate},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},

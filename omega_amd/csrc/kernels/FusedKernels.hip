@@ -2128,7 +2128,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    const bool FuseL3 = PairL3 && Tn.FuseL3 && !Stage;
    // narrow tables, plain RHS: the wide cells' level-3 work (one thread does velocity + tracers, as the sweep's) and the
    // final pass of the other valence's list join the sweep's launch instead of being launches of their own
-   const bool FoldL3 = CanWide && NWide > 0 && FuseL3;
+   // (measured on a QU240-sized sphere, 12 pentagons: their final-pass list inside the sweep's launch: RHS 109 -> 102 us;
+   // the same for the stage pair, as a third body, and the side-0 list folded into the level-2 launch: both slower)
+   const bool FoldL3 = FuseL3 && ((CanWide && NWide > 0) || (NOther > 0 && Tn.FoldLists != 0));
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
@@ -2398,7 +2400,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                 A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
                   if constexpr (CanWide) {
-                     if (FoldL3) {
+                     if (FoldL3 && NWide > 0) {
                         CellPVFinalTracerBody<TW, TW> BW{*Wide, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                          A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                          A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
@@ -2410,6 +2412,14 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                         launchTileV(K, S, BF, M.NCellsAll, BW, NWide, Bm, NOther);
                         return;
                      }
+                  }
+                  if (FoldL3) { // (no wide cells: the sweep and the other valence's final pass)
+                     constexpr int NM1f = ND == TME ? TME - 1 : TME;
+                     CellPVFinalBody<TME, NM1f, false> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                           A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
+                                                           A.Del2DivCell, A.Del2RelVortVertex, UTend, OtherCells, EU};
+                     launchTileV(K, S, BF, M.NCellsAll, Bm, NOther);
+                     return;
                   }
                   launchTile(BF, M.NCellsAll, K, S);
                   return;
