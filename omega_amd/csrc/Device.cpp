@@ -31,6 +31,7 @@ const OptionName OptionTable[] = {
     {"Pair", &TuningOptions::Pair},
     {"FuseL3", &TuningOptions::FuseL3},
     {"FoldLists", &TuningOptions::FoldLists},
+    {"InlineOther", &TuningOptions::InlineOther},
     {"Alternate", &TuningOptions::Alternate},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},

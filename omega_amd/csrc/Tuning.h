@@ -25,6 +25,7 @@ struct TuningOptions {
    int MergeL1   = 1; ///< vertex pass + side-0 PV sums inside the level-1 cell kernel
    int Pair      = 1; ///< independent sweeps share a launch
    int FuseL3    = 1; ///< plain RHS: both level-3 kernels in one thread
+   int InlineOther = 1; ///< merged level-1 kernel: side-0 PV sums of the cells with one edge fewer inside the sweep
    int FoldLists = 1; ///< plain RHS: the other valence's final-pass cell list joins the level-3 sweep's launch
    int Alternate  = 0; ///< 1: consecutive dependency levels sweep the mesh in opposite directions (measured: no gain)
    // ---- mesh tables (read when a HorzMesh is constructed)

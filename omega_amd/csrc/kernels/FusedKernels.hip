@@ -315,7 +315,10 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
 #ifndef OMEGA_L1PV_MINW
 #define OMEGA_L1PV_MINW OMEGA_CELL_MINW
 #endif
-template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1PVBody {
+/// INLO: cells with NR - 1 edges (the pentagons of a hexagon mesh) do their side-0 sums here as well, with the ring code
+/// instantiated a second time, instead of through a list launch of CellPVBody (12 pentagons on a QU240-sized sphere:
+/// that launch was 9 % of the RHS).  Only instantiated for meshes that have such cells.
+template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false> struct FusedCellL1PVBody {
    static constexpr int MinWaves = OMEGA_L1PV_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    static constexpr int TM1      = TME - 1;
@@ -487,33 +490,40 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME> struct FusedCellL1
       // ---- side-0 half of PotentialVortHAdvOnEdge: exactly CellPVBody<TME, Fast, 0, NR> ----
       // (NR = the valence of most cells: MaxEdges, or MaxEdges-1 on a mesh of hexagons with a few heptagons; the other
       // valences go through the list launches of CellPVBody)
-      if (N == NR) {
-         bool Any = false;
+      auto Side0 = [&](auto RingSize) {
+         constexpr int NRr = decltype(RingSize)::value; // this cell's valence; table strides stay TME
+         bool Any          = false;
 #pragma unroll
-         for (int J = 0; J < NR; ++J)
+         for (int J = 0; J < NRr; ++J)
             Any |= L.Role[Le * TME + J] == 1;
          if (Any) {
             T QRe[TME], QFe[TME];
 #pragma unroll
-            for (int J = 0; J < NR; ++J) {
-               const int Jm = (J + NR - 1) % NR;
+            for (int J = 0; J < NRr; ++J) {
+               const int Jm = (J + NRr - 1) % NRr;
                QRe[J]       = 0.5 * (QR[Jm] + QR[J]);
                QFe[J]       = 0.5 * (QF[Jm] + QF[J]);
             }
 #pragma unroll
-            for (int I = 0; I < NR; ++I) {
+            for (int I = 0; I < NRr; ++I) {
                if (L.Role[Le * TME + I] != 1)
                   continue;
                T Acc = splat<T>(0.0);
 #pragma unroll
-               for (int J = 1; J < NR; ++J) {
-                  const int Kk     = (I + J) % NR;
+               for (int J = 1; J < NRr; ++J) {
+                  const int Kk     = (I + J) % NRr;
                   const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
                   Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Ue[Kk] * NormVort;
                }
                sto<T>(Partial, OffE[I], Acc);
             }
          }
+      };
+      if (N == NR) {
+         Side0(std::integral_constant<int, NR>{});
+      } else if constexpr (INLO && NR >= 5) {
+         if (N == NR - 1)
+            Side0(std::integral_constant<int, NR - 1>{});
       }
       // ---- TracerAuxVars::computeVarsOnCells: exactly FusedCell1Body ----
       if (DoDel2Tr) {
@@ -1993,10 +2003,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    Mark(1);
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    bool Cell1Done = false;
+   // the merged kernel can take the side-0 sums of the cells with one edge fewer than the sweep's valence along (INLO)
+   const bool InlineOther = MergeL1 && ND == TME && NOther > 0 && Tn.InlineOther != 0;
    if (MergeL1) {
-      auto LaunchL1 = [&](auto Epi) {
-         constexpr bool EP = decltype(Epi)::value;
-         FusedCellL1PVBody<TME, Fast, EP, ND> B{M,  K,  NT,    P,      DoDel2Tr,        H,
+      auto LaunchL1x = [&](auto Epi, auto Inl) {
+         constexpr bool EP = decltype(Epi)::value, IL = decltype(Inl)::value && ND == TME;
+         FusedCellL1PVBody<TME, Fast, EP, ND, IL> B{M,  K,  NT,    P,      DoDel2Tr,        H,
                                             U,  Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
                                             A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
          if constexpr (CanWide) {
@@ -2010,6 +2022,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             }
          }
          launchTile(B, M.NCellsAll, K, S);
+      };
+      auto LaunchL1 = [&](auto Epi) {
+         if (InlineOther)
+            LaunchL1x(Epi, std::true_type{});
+         else
+            LaunchL1x(Epi, std::false_type{});
       };
       if constexpr (Fast) {
          if (Stage)
@@ -2142,8 +2160,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          CellPVBody<TME, Fast, 0, ND> B0{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch};
          if (NMain > 0 && !MergeL1) // (merged: done by the L1 kernel; only the rarer valences remain)
             launchTile(B0, M.NCellsAll, K, S);
-         FusedKernelNames[4] = (!MergeL1 || NOther > 0 || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVBody<side 0>" : "";
-         if (NOther > 0) {
+         FusedKernelNames[4] =
+             (!MergeL1 || (NOther > 0 && !InlineOther) || (TME >= 6 && M.NRingCellsM2 > 0)) ? "CellPVBody<side 0>" : "";
+         if (NOther > 0 && !InlineOther) {
             CellPVBody<TME, Fast, 0, NM1> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                              OtherCells};
             launchTile(Bm, NOther, K, S);
