@@ -45,7 +45,7 @@ void refineBisection(const Graph &Gr, std::vector<I4> &Part, const std::vector<I
    // Fiduccia-Mattheyses style refinement of the bisection: passes of single-cell moves with the best gain first,
    // sizes kept within +-Tol of the target, each pass rolled back to its best prefix
    const size_t Target = NLeft, Total = Cells.size();
-   const size_t Tol    = std::max<size_t>(1, Total / 200); // half a percent per bisection level
+   const size_t Tol    = std::max<size_t>(1, Total / 1000); // a tenth of a percent per bisection level
    auto Gain           = [&](I4 C) {
       int Same = 0, Other = 0;
       for (int J = 0; J < Gr.ME; ++J) {
@@ -302,7 +302,7 @@ void partitionGraph(const GlobalMeshDesc &G, I4 NParts, std::vector<I4> &CellTas
    std::vector<I8> Size(NParts, 0);
    for (I4 C = 0; C < G.NCells; ++C)
       ++Size[CellTask[C]];
-   const I8 MaxSize = (I8)((double)G.NCells / NParts * 1.03) + 1, MinSize = (I8)((double)G.NCells / NParts * 0.97);
+   const I8 MaxSize = (I8)((double)G.NCells / NParts * 1.01) + 1, MinSize = (I8)((double)G.NCells / NParts * 0.99);
    for (int Pass = 0; Pass < 4; ++Pass) {
       I8 Moved = 0;
       for (I4 C = 0; C < G.NCells; ++C) {
