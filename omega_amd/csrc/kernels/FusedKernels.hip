@@ -2149,6 +2149,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // (measured on a QU240-sized sphere, 12 pentagons: their final-pass list inside the sweep's launch: RHS 109 -> 102 us;
    // the same for the stage pair, as a third body, and the side-0 list folded into the level-2 launch: both slower)
    const bool FoldL3 = FuseL3 && ((CanWide && NWide > 0) || (NOther > 0 && Tn.FoldLists != 0));
+   // plain RHS, one table width: the irregular-edge list (coast lines; the masked rim of a partition's halo) joins the
+   // sweep's launch too (an eighth of the QU30-sized mesh with its halo: one launch of ~10 us less per RHS)
+   const bool FoldChain = FuseL3 && !Wide && M.NIrregularEdges > 0 && Tn.FoldLists != 0;
    if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
@@ -2307,7 +2310,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                 UTend};
          launchTile(BF, M.NEdgesAll, K, S);
       }
-      if (M.NIrregularEdges > 0) {
+      if (M.NIrregularEdges > 0 && !FoldChain) {
          auto LaunchList = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
             if constexpr (CanWide) {
@@ -2432,12 +2435,22 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                         return;
                      }
                   }
-                  if (FoldL3) { // (no wide cells: the sweep and the other valence's final pass)
+                  if (FoldL3 || FoldChain) { // (no wide cells: the sweep, the other valence's final pass, the irregular edges)
                      constexpr int NM1f = ND == TME ? TME - 1 : TME;
                      CellPVFinalBody<TME, NM1f, false> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                            A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
                                                            A.Del2DivCell, A.Del2RelVortVertex, UTend, OtherCells, EU};
-                     launchTileV(K, S, BF, M.NCellsAll, Bm, NOther);
+                     FusedEdgeChainBody<TME, Fast, false, true> Bc{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, nullptr,
+                                                                   A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
+                                                                   A.Del2RelVortVertex, A.NormalStressEdge, UTend,
+                                                                   M.IrregularEdges, EU};
+                     const int NO = FoldL3 ? NOther : 0, NC = FoldChain ? M.NIrregularEdges : 0;
+                     if (NO > 0 && NC > 0)
+                        launchTileV(K, S, BF, M.NCellsAll, Bm, NO, Bc, NC);
+                     else if (NC > 0)
+                        launchTileV(K, S, BF, M.NCellsAll, Bc, NC);
+                     else
+                        launchTileV(K, S, BF, M.NCellsAll, Bm, NO);
                      return;
                   }
                   launchTile(BF, M.NCellsAll, K, S);
