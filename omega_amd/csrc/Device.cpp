@@ -33,6 +33,8 @@ const OptionName OptionTable[] = {
     {"FoldLists", &TuningOptions::FoldLists},
     {"InlineOther", &TuningOptions::InlineOther},
     {"Alternate", &TuningOptions::Alternate},
+    {"SendBand", &TuningOptions::SendBand},
+    {"BandOnComm", &TuningOptions::BandOnComm},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},

@@ -518,17 +518,32 @@ void HorzMesh::buildBandLists(I4 HaloWidth) {
          }
       Front.swap(Next);
    }
-   std::vector<I4> Band, Inter;
+   std::vector<I4> Band, Inter, Send;
    for (I4 C = 0; C < NCellsAll; ++C)
       (Dist[C] >= 0 ? Band : Inter).push_back(C);
+   // halo cells that finish an owned edge (see HorzMesh.h: BandSendCells)
+   std::vector<char> OnOwnedEdge(NCellsAll, 0);
+   for (I4 E = 0; E < NEdgesOwned; ++E)
+      for (int J = 0; J < 2; ++J) {
+         const I4 C = CellsOnEdgeH(E, J);
+         if (C >= NCellsOwned && C < NCellsAll)
+            OnOwnedEdge[C] = 1;
+      }
+   for (I4 C : Band)
+      if (C < NCellsOwned || OnOwnedEdge[C])
+         Send.push_back(C);
    BandCells     = Array1DI4("BandCells", (int)std::max<size_t>(Band.size(), 1));
    InteriorCells = Array1DI4("InteriorCells", (int)std::max<size_t>(Inter.size(), 1));
    if (!Band.empty())
       OMEGA::copyToDevice(BandCells.Ptr, Band.data(), Band.size() * sizeof(I4));
    if (!Inter.empty())
       OMEGA::copyToDevice(InteriorCells.Ptr, Inter.data(), Inter.size() * sizeof(I4));
+   BandSendCells = Array1DI4("BandSendCells", (int)std::max<size_t>(Send.size(), 1));
+   if (!Send.empty())
+      OMEGA::copyToDevice(BandSendCells.Ptr, Send.data(), Send.size() * sizeof(I4));
    W.NBandCells = (I4)Band.size(), W.NInteriorCells = (I4)Inter.size();
    W.BandCells = BandCells.Ptr, W.InteriorCells = InteriorCells.Ptr;
+   W.NBandSendCells = (I4)Send.size(), W.BandSendCells = BandSendCells.Ptr;
 }
 
 // Ring form of the velocity-del2 stencils (see HorzMesh.h).  Works for any mesh whose
@@ -826,6 +841,7 @@ void HorzMesh::buildCellPV() {
    const int DomEnv = tuning().DomValence;
    W.DomM1 = (DomEnv != 0 && ME >= 6 && CellsM1.size() > CellsM0.size()) ? 1 : 0;
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
+   W.NIrregularOwned = (I4)(std::lower_bound(Irregular.begin(), Irregular.end(), NEdgesOwned) - Irregular.begin());
    W.RingVertOnCell = RingVertOnCell.Ptr, W.PVRoleOnCell = PVRoleOnCell.Ptr, W.PVWeightOnCell = PVWeightOnCell.Ptr;
    W.EdgeRegular = EdgeRegular.Ptr, W.IrregularEdges = IrregularEdges.Ptr;
 }

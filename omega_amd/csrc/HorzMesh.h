@@ -84,6 +84,7 @@ struct MeshView {
    // edges from 4*MaxEdges+1 gathers.  Side 0 sums start from zero, side 1 sums continue from the
    // stored side 0 value: the additions happen in the reference's order.
    I4 CellPVOK, CellPVFinalOK, NIrregularEdges;
+   I4 NIrregularOwned;             // how many of them are owned edges (the list is ascending: they come first)
    const I4 *RingVertOnCell;       // [C][ME] vertex shared by edge slots k and k+1 (cyclic)
    const Real *RingSignOnCell;     // [C][ME] +1 if ring vertex k is VerticesOnEdge(e_k,1) (and k-1 is (e_k,0)), -1 if reversed
    const I4 *PVRoleOnCell;         // [C][ME] 0 none, 1 this cell is cell 0 of a regular edge, 2 cell 1
@@ -117,6 +118,12 @@ struct MeshView {
    // that own anything a neighbour receives); InteriorCells: the other owned cells.  Ascending order.
    I4 NBandCells, NInteriorCells;
    const I4 *BandCells, *InteriorCells;
+   // BandSendCells: BandCells without the halo cells that finish nothing a neighbour receives -- the owned band cells
+   // plus the halo cells on an owned edge (the cell-centric velocity kernels finish an edge in the thread of its
+   // second cell).  A stage whose output is exchanged right away needs its last dependency level on these and on the
+   // interior only: every other local value is about to be overwritten by the exchange.
+   I4 NBandSendCells;
+   const I4 *BandSendCells;
 };
 
 class HorzMesh : public Registry<HorzMesh> {
@@ -191,7 +198,7 @@ class HorzMesh : public Registry<HorzMesh> {
        Diff4CoefOnCell, KiteCoefOnVertex, VortCoefOnVertex, Del2TrCoefSOnCell, Diff2CoefSOnCell, Diff4CoefSOnCell;
    DeviceArray<I4, 3> CellsOnEdgeOnCell, PVStencil;
    Array2DReal RingSignOnCell;
-   Array1DI4 RingCellsM0, RingCellsM1, RingCellsM2, BandCells, InteriorCells;
+   Array1DI4 RingCellsM0, RingCellsM1, RingCellsM2, BandCells, InteriorCells, BandSendCells;
    void buildBandLists(I4 HaloWidth);
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;

@@ -293,6 +293,8 @@ RungeKutta4Stepper::~RungeKutta4Stepper() {
       (void)hipEventDestroy(EvBand);
    if (EvDone)
       (void)hipEventDestroy(EvDone);
+   if (EvFork)
+      (void)hipEventDestroy(EvFork);
    if (CommStream)
       (void)hipStreamDestroy(CommStream);
 }
@@ -303,12 +305,20 @@ void RungeKutta4Stepper::startExchangeThunk(void *Job) {
 }
 // Called by the RHS launcher between the band and the interior part of a stage: everything a neighbour
 // receives is final on stream S.  Pack, send / receive and unpack run on the communication stream.
+void RungeKutta4Stepper::ensureCommStream() {
+   if (CommStream)
+      return;
+   // the highest priority the device offers: the band launches and the pack / unpack kernels on this stream are
+   // small and everything else waits for them, the interior launch next to them fills the GPU for much longer
+   int Least = 0, Greatest = 0;
+   HIP_CHECK(hipDeviceGetStreamPriorityRange(&Least, &Greatest));
+   HIP_CHECK(hipStreamCreateWithPriority(&CommStream, hipStreamNonBlocking, Greatest));
+   HIP_CHECK(hipEventCreateWithFlags(&EvBand, hipEventDisableTiming));
+   HIP_CHECK(hipEventCreateWithFlags(&EvDone, hipEventDisableTiming));
+   HIP_CHECK(hipEventCreateWithFlags(&EvFork, hipEventDisableTiming));
+}
 void RungeKutta4Stepper::startExchange(const ExchangeJob &Job) {
-   if (!CommStream) {
-      HIP_CHECK(hipStreamCreate(&CommStream));
-      HIP_CHECK(hipEventCreateWithFlags(&EvBand, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&EvDone, hipEventDisableTiming));
-   }
+   ensureCommStream();
    Pacer::Range Timer(Job.Provis ? "RK4:haloExchProvis" : "RK4:haloExch", 3);
    HIP_CHECK(hipEventRecord(EvBand, Job.S));
    HIP_CHECK(hipStreamWaitEvent(CommStream, EvBand, 0));
@@ -365,6 +375,9 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
          else
             Job.H = NextH, Job.U = NextU, Job.Tr = &NextTr, Job.Provis = false;
          Su.AfterBand = &RungeKutta4Stepper::startExchangeThunk, Su.AfterBandCtx = &Job;
+         Su.HaloOutputsReplaced = 1; // Prov (stage 1) / Next (last stage): every halo element arrives with the exchange
+         ensureCommStream();
+         Su.BandStream = CommStream, Su.BandReady = EvFork; // the band launches go where the exchange follows them
       }
       bool Ok;
       if (Stage == 0) {

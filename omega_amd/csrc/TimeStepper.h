@@ -137,7 +137,8 @@ class RungeKutta4Stepper : public TimeStepper {
    bool StageFusedKnownGood = false; ///< a direct (un-captured) stage-fused step has succeeded on this configuration
    // overlapped exchange: communication stream, "band is final" and "halo is in place" events
    hipStream_t CommStream = nullptr;
-   hipEvent_t EvBand = nullptr, EvDone = nullptr;
+   hipEvent_t EvBand = nullptr, EvDone = nullptr, EvFork = nullptr;
+   void ensureCommStream();
    bool ExchangePending = false;
    struct ExchangeJob {
       RungeKutta4Stepper *Self;

@@ -28,6 +28,8 @@ struct TuningOptions {
    int InlineOther = 1; ///< merged level-1 kernel: side-0 PV sums of the cells with one edge fewer inside the sweep
    int FoldLists = 1; ///< plain RHS: the other valence's final-pass cell list joins the level-3 sweep's launch
    int Alternate  = 0; ///< 1: consecutive dependency levels sweep the mesh in opposite directions (measured: no gain)
+   int SendBand   = 1; ///< overlapped RK4 stages: the level-3 kernels skip the halo cells whose results the exchange replaces
+   int BandOnComm = 1; ///< overlapped RK4 stages: the band launches run on the communication stream, next to the interior ones
    // ---- mesh tables (read when a HorzMesh is constructed)
    int ForceGeneric = 0; ///< clear every ring-table flag: all kernels in their generic form
    int KeepMaxEdges = 0; ///< keep the mesh file's maxEdges as the table width

@@ -693,12 +693,14 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"CellL1OK", W.CellL1OK},
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
+                                        {"NIrregularOwned", W.NIrregularOwned},
                                         {"DomM1", W.DomM1},
                                         {"NWideCells", W.NWideCells},
                                         {"NarrowTables", M.narrowView() ? 1 : 0},
                                         {"Del2RingOK", W.Del2RingOK},
                                         {"Del2VertOK", W.Del2VertOK},
                                         {"NBandCells", W.NBandCells},
+                                        {"NBandSendCells", W.NBandSendCells},
                                         {"NInteriorCells", W.NInteriorCells}};
       auto Jt = D.find(name);
       if (Jt != D.end()) {

@@ -1990,6 +1990,23 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // the vertex kernel stores RelVort and 1/LayerThickVertex; the two normalised vorticities are rebuilt from
    // them where they are consumed; without the cell-centric tables the edge kernels read the reference's arrays
    const TuningOptions &Tn = tuning();
+   // the band of an overlapped stage: without the halo cells whose results the exchange replaces (Kernels.h)
+   const bool SendOnly =
+       Tn.SendBand && Stage && Stage->AfterBand && Stage->HaloOutputsReplaced && !Stage->StoreTend && M.NBandSendCells > 0;
+   const I4 *const BandList = SendOnly ? M.BandSendCells : M.BandCells;
+   const int NBandList      = SendOnly ? M.NBandSendCells : M.NBandCells;
+   // the stream of the band launches (Kernels.h: StageUpdate::BandStream); forked from S at the first use
+   bool BandForked = false;
+   auto BandS      = [&]() -> hipStream_t {
+      if (!(Stage && Stage->BandStream && Stage->BandReady && Tn.BandOnComm))
+         return S;
+      if (!BandForked) {
+         HIP_CHECK(hipEventRecord(Stage->BandReady, S));
+         HIP_CHECK(hipStreamWaitEvent(Stage->BandStream, Stage->BandReady, 0));
+         BandForked = true;
+      }
+      return Stage->BandStream;
+   };
    const int EdgeModeV     = Tn.EdgeMode;
    const bool CellCentric     = EdgeModeV == 0 && M.CellPVOK && EdgeScratch;
    // vertex pass and side-0 PV sums inside the L1 cell kernel (option MergeL1 = 0: the three separate kernels)
@@ -2209,8 +2226,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 EU};
                if (NMain > 0 && !PairL3) { // (paired: launched together with the tracer kernel below)
                   if (Overlap) {
-                     B1.List = M.BandCells;
-                     launchTile(B1, M.NBandCells, K, S);
+                     B1.List = BandList;
+                     launchTile(B1, NBandList, K, BandS());
                   } else {
                      launchTile(B1, M.NCellsAll, K, S);
                   }
@@ -2310,7 +2327,10 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                 UTend};
          launchTile(BF, M.NEdgesAll, K, S);
       }
-      if (M.NIrregularEdges > 0 && !FoldChain) {
+      // (a stage whose halo outputs the exchange replaces: the owned irregular edges -- a coast -- only, not the masked
+      // edges of the halo rim)
+      const int NIrr = SendOnly ? M.NIrregularOwned : M.NIrregularEdges;
+      if (NIrr > 0 && !FoldChain) {
          auto LaunchList = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
             if constexpr (CanWide) {
@@ -2319,7 +2339,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                            A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                            A.Del2RelVortVertex, A.NormalStressEdge, UTend,
                                                            M.IrregularEdges, EU};
-                  launchTile(B, M.NIrregularEdges, K, S);
+                  launchTile(B, NIrr, K, S);
                   return;
                }
             }
@@ -2339,7 +2359,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                 UTend,
                                                 M.IrregularEdges,
                                                 EU};
-            launchTile(B, M.NIrregularEdges, K, S);
+            launchTile(B, NIrr, K, S);
          };
          if (Stage)
             LaunchList(std::true_type{});
@@ -2458,8 +2478,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                }
             }
             if (EP && Stage && Stage->AfterBand && M.NBandCells > 0) {
-               B1.List = B3.List = M.BandCells;
-               launchTile2(B1, M.NBandCells, B3, M.NBandCells, K, S);
+               B1.List = B3.List = BandList;
+               launchTile2(B1, NBandList, B3, NBandList, K, BandS());
                Stage->AfterBand(Stage->AfterBandCtx); // u, h and the tracers of every sent element are final
                AfterBandCalled = true;
                B1.List = B3.List = M.InteriorCells;
@@ -2479,8 +2499,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          if (Stage) {
             FusedCell3Body<TME, true, true> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
             if (Stage->AfterBand && M.NBandCells > 0) {
-               B.List = M.BandCells;
-               launchTile(B, M.NBandCells, K, S);
+               B.List = BandList;
+               launchTile(B, NBandList, K, BandS());
                Stage->AfterBand(Stage->AfterBandCtx); // u, h and the tracers of every sent element are final
                AfterBandCalled = true;
                if (LaunchFinalInterior)

@@ -92,6 +92,19 @@ struct StageUpdate {
    /// kernels continue over InteriorCells while the messages travel.
    void (*AfterBand)(void *) = nullptr;
    void *AfterBandCtx        = nullptr;
+   /// Set together with AfterBand when the exchange started there delivers EVERY halo element of EVERY array this
+   /// stage writes that is read again before the next such exchange (RK4: stage 1 writes Prov -- exchanged now -- and
+   /// Next, whose halo nobody reads before the end-of-step exchange replaces it; the last stage writes Next only).
+   /// The kernels that finish u and the tracers then skip the halo cells that finish nothing owned here
+   /// (MeshView::BandSendCells instead of BandCells).  Ignored when StoreTend is set: stored tendencies keep their
+   /// halo values.
+   int HaloOutputsReplaced = 0;
+   /// Optional (both or none): the band part is launched on BandStream -- the stepper's communication stream, on
+   /// which the exchange follows in stream order -- after everything queued on S so far (BandReady is recorded on S
+   /// and waited for there).  The interior part on S then shares the GPU with the band launch, which is too small to
+   /// fill it, instead of waiting for it.  The two parts write disjoint elements and read only the stage's inputs.
+   hipStream_t BandStream = nullptr;
+   hipEvent_t BandReady   = nullptr;
 };
 /// Returns false (nothing launched) when Stage != nullptr and the stage-fused kernels do not cover
 /// this mesh / option set; the caller then runs the plain RHS followed by the update kernels.

@@ -217,6 +217,10 @@ def main():
             # make sure this mesh has both, or the test would not exercise it
             nb, ni = P.mesh.get_int("NBandCells"), P.mesh.get_int("NInteriorCells")
             assert nb > 0 and (ni > 0 or g["nCells"] <= 24 * 24), (nb, ni)
+            # ... and the stages whose output is exchanged right away leave out the halo cells that finish nothing
+            # owned here (MeshView::BandSendCells): fewer cells than the band, at least the owned band cells
+            ns = P.mesh.get_int("NBandSendCells")
+            assert nb - (m.NCellsAll - m.NCellsOwned) <= ns < nb, (ns, nb, m.NCellsOwned, m.NCellsAll)
         user_stream = oa.Stream() if a.user_stream else None   # hipStreamNonBlocking: no implicit ordering with stream 0
         for _ in range(a.steps):
             st.do_step(P.state, stream=user_stream)
@@ -255,6 +259,11 @@ def main():
     assert np.array_equal(h[:nc], gh), f"rank {a.rank}: h differs from the single-rank run (max {np.abs(h[:nc]-gh).max()})"
     assert np.array_equal(u[:ne], gu), f"rank {a.rank}: u differs from the single-rank run (max {np.abs(u[:ne]-gu).max()})"
     assert np.array_equal(tr[:NT, :nc], gtr[:NT]), f"rank {a.rank}: tracers differ from the single-rank run"
+    # the halo after the end-of-step exchange: the owners' values, on every layer
+    na, nea = m.NCellsAll, m.NEdgesAll
+    assert np.array_equal(h[nc:na], stg["h"][0][P.cell_id[nc:na] - 1]), f"rank {a.rank}: halo h differs after the step"
+    assert np.array_equal(u[ne:nea], stg["u"][0][P.edge_id[ne:nea] - 1]), f"rank {a.rank}: halo u differs after the step"
+    assert np.array_equal(tr[:NT, nc:na], stg["tr"][0][:NT, P.cell_id[nc:na] - 1]), f"rank {a.rank}: halo tracers differ"
     note = ""
     if wire is not None:
         info = wire.info()
