@@ -35,6 +35,7 @@ const OptionName OptionTable[] = {
     {"Alternate", &TuningOptions::Alternate},
     {"SendBand", &TuningOptions::SendBand},
     {"BandOnComm", &TuningOptions::BandOnComm},
+    {"ShrinkSweeps", &TuningOptions::ShrinkSweeps},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},

@@ -367,6 +367,17 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
       Array2DReal OutH, OutU;
       Out->getLayerThickness(OutH, CurLevel), Out->getNormalVelocity(OutU, CurLevel);
       Su.ProvH = OutH.Ptr, Su.ProvU = OutU.Ptr, Su.ProvTr = ProvT[Stage % 2]->Ptr;
+      // How far the sweeps of this stage have to go (halo layers are prefixes of the local numbering).  An evaluation
+      // reaches two cells far (the del4 terms), so with the input valid on every layer:
+      //  * a stage whose output is exchanged at once (overlapped: stage 1, last) is read on owned elements only: level 3
+      //    runs on the send band + interior (below), level 1 through layer 2 (level 2 keeps its full sweeps);
+      //  * the stage before it (0, 2) feeds that evaluation: tracers through layer 2, and every edge of those cells --
+      //    finished in the thread of the edge's second cell -- through layer 3.  Only at HaloWidth >= 4, where these
+      //    layers are valid at all; at the reference's default 3 the outer layers' values enter the next evaluation as
+      //    they are (RungeKutta4Stepper.cpp:107 "depends on halo width"), so nothing is left out there.
+      const int HaloW = (int)Mesh->NCellsHaloH.size();
+      if (Exchanges && HaloW >= 4 && (Stage == 0 || Stage == 2))
+         Su.NCellsTr = Mesh->NCellsHaloH(1), Su.NCellsVel = Mesh->NCellsHaloH(2);
       if (Overlap && (Stage == 1 || Stage == NStages - 1)) {
          // this stage's output is exchanged next: the provisional state before stage 2 (:107-113), the
          // new state at the end of the step (:130-131)
@@ -376,6 +387,8 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
             Job.H = NextH, Job.U = NextU, Job.Tr = &NextTr, Job.Provis = false;
          Su.AfterBand = &RungeKutta4Stepper::startExchangeThunk, Su.AfterBandCtx = &Job;
          Su.HaloOutputsReplaced = 1; // Prov (stage 1) / Next (last stage): every halo element arrives with the exchange
+         if (HaloW >= 3)
+            Su.NCellsL1 = Mesh->NCellsHaloH(1);
          ensureCommStream();
          Su.BandStream = CommStream, Su.BandReady = EvFork; // the band launches go where the exchange follows them
       }

@@ -30,6 +30,7 @@ struct TuningOptions {
    int Alternate  = 0; ///< 1: consecutive dependency levels sweep the mesh in opposite directions (measured: no gain)
    int SendBand   = 1; ///< overlapped RK4 stages: the level-3 kernels skip the halo cells whose results the exchange replaces
    int BandOnComm = 1; ///< overlapped RK4 stages: the band launches run on the communication stream, next to the interior ones
+   int ShrinkSweeps = 1; ///< RK4 stages sweep only as many halo layers as the rank still reads (StageUpdate::NCellsL1 ...)
    // ---- mesh tables (read when a HorzMesh is constructed)
    int ForceGeneric = 0; ///< clear every ring-table flag: all kernels in their generic form
    int KeepMaxEdges = 0; ///< keep the mesh file's maxEdges as the table width

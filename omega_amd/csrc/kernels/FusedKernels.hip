@@ -1995,6 +1995,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
        Tn.SendBand && Stage && Stage->AfterBand && Stage->HaloOutputsReplaced && !Stage->StoreTend && M.NBandSendCells > 0;
    const I4 *const BandList = SendOnly ? M.BandSendCells : M.BandCells;
    const int NBandList      = SendOnly ? M.NBandSendCells : M.NBandCells;
+   // sweep lengths of a stage (Kernels.h: StageUpdate::NCellsL1 / NCellsVel / NCellsTr)
+   auto SweepLen = [&](I4 Want) {
+      return (Tn.ShrinkSweeps && Stage && !Stage->StoreTend && Want > 0 && Want < M.NCellsAll) ? Want : M.NCellsAll;
+   };
+   const int NSweepL1 = SweepLen(Stage ? Stage->NCellsL1 : 0), NSweepVel = SweepLen(Stage ? Stage->NCellsVel : 0),
+             NSweepTr = SweepLen(Stage ? Stage->NCellsTr : 0);
    // the stream of the band launches (Kernels.h: StageUpdate::BandStream); forked from S at the first use
    bool BandForked = false;
    auto BandS      = [&]() -> hipStream_t {
@@ -2034,11 +2040,11 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                                        U,     Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
                                                        A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
                Bw.List = Wide->WideCells;
-               launchTileV(K, S, B, M.NCellsAll, Bw, NWide);
+               launchTileV(K, S, B, NSweepL1, Bw, NWide);
                return;
             }
          }
-         launchTile(B, M.NCellsAll, K, S);
+         launchTile(B, NSweepL1, K, S);
       };
       auto LaunchL1 = [&](auto Epi) {
          if (InlineOther)
@@ -2229,7 +2235,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                      B1.List = BandList;
                      launchTile(B1, NBandList, K, BandS());
                   } else {
-                     launchTile(B1, M.NCellsAll, K, S);
+                     launchTile(B1, EP ? NSweepVel : M.NCellsAll, K, S);
                   }
                }
                if (NOther > 0 && !FoldL3) {
@@ -2485,7 +2491,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                B1.List = B3.List = M.InteriorCells;
                launchTile2(B1, M.NInteriorCells, B3, M.NInteriorCells, K, S);
             } else {
-               launchTile2(B1, M.NCellsAll, B3, M.NCellsAll, K, S);
+               launchTile2(B1, EP ? NSweepVel : M.NCellsAll, B3, EP ? NSweepTr : M.NCellsAll, K, S);
             }
          };
          if (Stage)
@@ -2508,7 +2514,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                B.List = M.InteriorCells;
                launchTile(B, M.NInteriorCells, K, S);
             } else {
-               launchTile(B, M.NCellsAll, K, S);
+               launchTile(B, NSweepTr, K, S);
             }
             Done = true;
          }

@@ -105,6 +105,11 @@ struct StageUpdate {
    /// fill it, instead of waiting for it.  The two parts write disjoint elements and read only the stage's inputs.
    hipStream_t BandStream = nullptr;
    hipEvent_t BandReady   = nullptr;
+   /// Sweep lengths (0 = all local cells; the local numbering is owned, halo layer 1, 2, ... so a prefix is "through
+   /// layer i"): how far the merged level-1 kernel (NCellsL1) and the level-3 velocity / tracer kernels (NCellsVel,
+   /// NCellsTr) have to go for everything this rank still reads of the stage's results.  Set by the stepper from the
+   /// halo layer bounds; ignored when StoreTend is set.
+   I4 NCellsL1 = 0, NCellsVel = 0, NCellsTr = 0;
 };
 /// Returns false (nothing launched) when Stage != nullptr and the stage-fused kernels do not cover
 /// this mesh / option set; the caller then runs the plain RHS followed by the update kernels.

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--stepper", default="RungeKutta4")
     ap.add_argument("--halo-width", type=int, default=3)
     ap.add_argument("--no-del4", action="store_true", help="disable the two radius-2 (del4) terms")
+    ap.add_argument("--eddy-diff4", type=float, default=0.0,
+                    help="EddyDiff4 (Default.yml: 0 with the term enabled): non-zero makes the tracers' radius-2 term count")
     ap.add_argument("--no-overlap", action="store_true", help="RK4 (gpu mode): exchange after the stage instead of overlapped")
     ap.add_argument("--user-stream", action="store_true",
                     help="gpu mode: step on a non-blocking stream created with omg_stream_create instead of the default stream")
@@ -74,6 +76,8 @@ def main():
     if gpu:
         oa.device_init(0)
     cfg = {"VelHyperDiffTendencyEnable": 0, "TracerHyperDiffTendencyEnable": 0} if a.no_del4 else {}
+    if a.eddy_diff4:
+        cfg["EddyDiff4"] = a.eddy_diff4
     P = Problem(g, K, NT, nparts=a.world, rank=a.rank, device=gpu, config=cfg, halo_width=a.halo_width,
                 local_order=a.local_order, partition=a.partition)
     m = P.mesh

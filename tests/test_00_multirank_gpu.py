@@ -59,6 +59,11 @@ def test_two_ranks_one_gpu(extra):
     (4, ["--halo-width", 4, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 6, "--no-overlap"]),
     (5, ["--halo-width", 4, "--nx", 60, "--ny", 48, "--levels", 4, "--tracers", 3, "--partition", "graph",
          "--local-order", "curve"]),
+    # EddyDiff4 != 0 (Default.yml has the term enabled with coefficient 0): the tracers' radius-2 term then reaches two
+    # halo layers far, which the sweep lengths of the RK4 stages (StageUpdate::NCellsTr) have to cover
+    (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 3, "--eddy-diff4", 1.0e11]),
+    (4, ["--halo-width", 4, "--mesh", "ico4", "--levels", 3, "--tracers", 2, "--eddy-diff4", 1.0e11, "--partition", "graph",
+         "--local-order", "curve"]),
 ])
 def test_peer_wire_stream_ordered_exchanges(world, extra):
     """The same runs over the library's OTHER wire (PeerWire: HIP IPC mailboxes, device-to-device copies and flag

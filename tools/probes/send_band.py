@@ -3,7 +3,7 @@ replaces (option SendBand, MeshView::BandSendCells).
 
 ONE process plays one rank of an N-part decomposition of the workload mesh; the wire is replaced by a function that
 moves nothing (the halo then keeps whatever the receive buffers hold -- the STATE of this probe is meaningless, its
-kernel sequence and sizes are exactly the rank's).  RK4 steps are timed with the options SendBand and BandOnComm on and off, alternating.
+kernel sequence and sizes are exactly the rank's).  RK4 steps are timed with the options SendBand, BandOnComm and ShrinkSweeps on and off, alternating.
 
    python tools/probes/send_band.py [--parts 8] [--rank 0] [--nx 680] [--levels 80] [--tracers 6] [--steps 6] [--rounds 4]
 """
@@ -56,12 +56,13 @@ def main():
     stream = oa.Stream()
     stepper = oa.TimeStepper("RungeKutta4", 600.0, tend, aux, mesh, halo, tracers)
     stepper.set_option("OverlapHaloExchange", True)
-    configs = {"send_band+band_on_comm": (1, 1), "send_band": (1, 0), "full_band": (0, 0), "full_band+band_on_comm": (0, 1)}
+    configs = {"all": (1, 1, 1), "send_band+band_on_comm": (1, 1, 0), "send_band": (1, 0, 0), "full_band": (0, 0, 0)}
     res = {k: [] for k in configs}
     for rnd in range(a.rounds):
-        for name, (sb, bc) in configs.items():
+        for name, (sb, bc, sh) in configs.items():
             oa.set_option("SendBand", sb)
             oa.set_option("BandOnComm", bc)
+            oa.set_option("ShrinkSweeps", sh)
             state.copy_to_device(h, u, 0)
             tracers.copy_to_device(tr, 0)
             stepper.do_step(state, stream=stream)
@@ -73,6 +74,7 @@ def main():
             res[name].append(round(1e3 * (time.perf_counter() - t0) / a.steps, 4))
     oa.set_option("SendBand", 1)
     oa.set_option("BandOnComm", 1)
+    oa.set_option("ShrinkSweeps", 1)
     base = min(res["full_band"])
     out = {"probe": "send_band", "parts": a.parts, "rank": a.rank, "cells_global": int(g["nCells"]), "levels": K, "tracers": NT,
            "halo_width": a.halo_width,
