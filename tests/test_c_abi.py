@@ -110,7 +110,8 @@ def test_options_api():
     import omega_amd as oa
     import pytest
     for name, default in (("MergeL1", 1), ("Pair", 1), ("FuseL3", 1), ("ForceGeneric", 0), ("KeepMaxEdges", 0),
-                          ("DomValence", 1), ("NarrowTables", 1), ("Graphs", -1), ("TX", 0), ("ChunkSplit", -1)):
+                          ("DomValence", 1), ("NarrowTables", 1), ("Graphs", -1), ("TX", 0), ("ChunkSplit", -1),
+                          ("SendBand", 1), ("BandOnComm", 1), ("ShrinkSweeps", 1), ("FoldLists", 1), ("InlineOther", 1)):
         if not __import__("os").environ.get("OMEGA_AMD_OPTIONS"):
             assert oa.get_option(name) == default, name
         old = oa.get_option(name)
