@@ -127,6 +127,10 @@ def main():
     ap.add_argument("--allow-host-staged", action="store_true",
                     help="permit --backend gloo: messages staged through host memory (a correctness rig, not a measurement "
                          "of the halo wire)")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed: before the W warm-up steps (and before the RK4 warm-up step) the GPU runs this workload's "
+                         "own RHS for this long, so that a short timed region does not start inside the power-management "
+                         "transient that follows a load step (tools/probes/step_ramp.py); 0 = off")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--halo-width", type=int, default=0,
                     help="0 = 4 for N > 1 (partition-independent results with the del4 terms: two RHS evaluations per "
@@ -242,7 +246,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def settle():
+        """Untimed.  A GPU that goes from idle to this load runs its first ~ 25 ms of kernels up to 12 % slower (a hump in
+        the per-evaluation times, not a ramp: tools/probes/step_ramp.py, profiles/r03_probe_step_ramp.json); a timed
+        region of K x 0.7 ms -- one rank of an 8-way run -- would sit inside it, one of K x 5 ms would not notice.  So
+        the device is kept under the workload's own load for --settle-ms before the W warm-up steps.  Nothing of the
+        timed region changes: still W untimed steps, then exactly K timed ones between the brackets."""
+        n, t0 = 0, time.perf_counter()
+        while args.settle_ms > 0 and (time.perf_counter() - t0) * 1e3 < args.settle_ms:
+            for _ in range(4):
+                tend.compute_all_tendencies(state, aux, tracers, stream=stream)
+            oa.device_synchronize()
+            n += 4
+        return n
+
     # ------------------------------------------------ RHS: W warm-up + K timed steps
+    settle_evals = settle()
     for _ in range(args.warmup):
         tend.compute_all_tendencies(state, aux, tracers, stream=stream)
     barrier()
@@ -252,8 +271,12 @@ def main():
     for _ in range(args.steps):
         tend.compute_all_tendencies(state, aux, tracers, stream=stream)
     ev1.record(stream)
-    barrier()
+    # closing bracket: this rank's K steps are done (device synchronised) -> its elapsed time; then the barrier; the
+    # job's time is the MAX over ranks (allmax below).  The barrier's own latency (a gloo round over the side channel)
+    # is not part of anybody's K steps.
+    oa.device_synchronize()
     wall_rhs = time.perf_counter() - t_start
+    barrier()
     dev_ms = ev0.elapsed_ms(ev1)
     graph_stats = tend.graph_stats()
     # per-kernel durations for the roofline: HIP events between the launches, in a second pass of the same K steps
@@ -365,12 +388,16 @@ def main():
             stepper.set_option("FuseStageUpdates", not args.no_fuse_stages)
             stepper.set_option("OverlapHaloExchange", overlap)
             stepper.do_step(state, stream=stream)  # warm-up (allocations, RCCL connections)
+            settle()                                # the wire set-up above left the GPU idle for seconds
+            stepper.do_step(state, stream=stream)
             barrier()
             t1 = time.perf_counter()
             for _ in range(nrk):
                 stepper.do_step(state, stream=stream)
+            oa.device_synchronize()
+            t_local = time.perf_counter() - t1
             barrier()
-            t_rk4 = allmax(time.perf_counter() - t1) / nrk
+            t_rk4 = allmax(t_local) / nrk
             sypd = (args.dt / t_rk4) / 365.0
             hh, _ = state.copy_to_host(0)
             if not np.isfinite(hh[: mesh.NCellsOwned]).all():
@@ -504,6 +531,8 @@ def main():
                                                    "row-major" if args.block == 1 else f"blocked{args.block}")
                                         + ", local numbering by Decomp: " + args.local_order,
                           "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1),
+                          "untimed_settle": {"ms": args.settle_ms, "rhs_evaluations": settle_evals,
+                                             "why": "load step -> ~25 ms power-management transient (profiles/r03_probe_step_ramp.json)"},
                           "hip_graph": graph_stats},
                "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
                        "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
