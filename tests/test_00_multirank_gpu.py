@@ -183,6 +183,19 @@ def test_wide_tables_only_in_a_child_process():
     assert " passed" in out and "failed" not in out
 
 
+@pytest.mark.parametrize("options", ["SendBand=0,BandOnComm=0,ShrinkSweeps=0", "SendBand=1,BandOnComm=0,ShrinkSweeps=0",
+                                     "SendBand=0,BandOnComm=1,ShrinkSweeps=1"])
+def test_rk4_stages_without_the_halo_shortcuts(options, monkeypatch):
+    """Options SendBand / BandOnComm / ShrinkSweeps off: every kernel of every RK4 stage sweeps all local cells and the
+    band launches stay on the compute stream (round 2's structure) -- the same bits, on both wires."""
+    monkeypatch.setenv("OMEGA_AMD_OPTIONS", options)
+    base = ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 3, "--eddy-diff4", 1.0e11]
+    outs = run_ranks("gpu", 2, [*base, "--wire", "ipc"], timeout=900)
+    assert all("OK" in o and "peer wire" in o for o in outs)
+    outs = run_ranks("gpu", 2, base, timeout=900)
+    assert all("OK" in o for o in outs)
+
+
 def test_four_ranks_one_gpu():
     """Four ranks (2 x 2 blocks of a 48 x 48 mesh: every rank has several neighbours, corner halos travel
     through two of them) on one GPU, overlapped exchanges."""
