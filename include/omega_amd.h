@@ -239,8 +239,10 @@ int omg_halo_exchange_i4(omg_halo *h, int32_t *dev_array, int nt, int rows_size,
 /* ---- Measurement / test options (omega_amd/csrc/Tuning.h).  The library never reads the environment: every switch that
  *      changes the kernel structure or the tile geometry is set through this call.  Defaults are what production
  *      runs.  Names: W TX TY Sweeps ChunkSplit TailSplit (tile geometry); EdgeMode FuseFinal MergeL1 Pair FuseL3
- *      (structure of the fused RHS; read at every launch); ForceGeneric KeepMaxEdges DomValence (mesh tables; read when
- *      a HorzMesh is created); Graphs (-1 per object, 0 never, 1 default on).  Unknown names fail.
+ *      FoldLists InlineOther Alternate (structure of the fused RHS; read at every launch); SendBand BandOnComm
+ *      ShrinkSweeps (what a rank leaves out inside an RK4 step; read at every stage); ForceGeneric KeepMaxEdges
+ *      DomValence NarrowTables (mesh tables; read when a HorzMesh is created); Graphs (-1 per object, 0 never, 1 default
+ *      on).  Unknown names fail.
  *      omg_set_timing_level: roctx ranges named after the reference's Pacer timers ("Tend:...", "AuxState:...",
  *      "RK4:haloExch"; share/pacer/Pacer.cpp:138-200) are emitted for timers up to this level (default 3 = all). ---- */
 int omg_set_option(const char *name, int value);
