@@ -842,6 +842,9 @@ void HorzMesh::buildCellPV() {
    W.DomM1 = (DomEnv != 0 && ME >= 6 && CellsM1.size() > CellsM0.size()) ? 1 : 0;
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
    W.NIrregularOwned = (I4)(std::lower_bound(Irregular.begin(), Irregular.end(), NEdgesOwned) - Irregular.begin());
+   // (Decomp: NEdgesHalo(i) = edges of the cells through halo layer i; the numbering is ascending in the layers)
+   const I4 InnerEdges = NEdgesHaloH.size() >= 3 ? NEdgesHaloH(2) : NEdgesAll;
+   W.NIrregularInner   = (I4)(std::lower_bound(Irregular.begin(), Irregular.end(), InnerEdges) - Irregular.begin());
    W.RingVertOnCell = RingVertOnCell.Ptr, W.PVRoleOnCell = PVRoleOnCell.Ptr, W.PVWeightOnCell = PVWeightOnCell.Ptr;
    W.EdgeRegular = EdgeRegular.Ptr, W.IrregularEdges = IrregularEdges.Ptr;
 }

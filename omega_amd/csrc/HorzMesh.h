@@ -85,6 +85,7 @@ struct MeshView {
    // stored side 0 value: the additions happen in the reference's order.
    I4 CellPVOK, CellPVFinalOK, NIrregularEdges;
    I4 NIrregularOwned;             // how many of them are owned edges (the list is ascending: they come first)
+   I4 NIrregularInner;             // ... are edges of cells through halo layer 2 (= all of them below HaloWidth 3)
    const I4 *RingVertOnCell;       // [C][ME] vertex shared by edge slots k and k+1 (cyclic)
    const Real *RingSignOnCell;     // [C][ME] +1 if ring vertex k is VerticesOnEdge(e_k,1) (and k-1 is (e_k,0)), -1 if reversed
    const I4 *PVRoleOnCell;         // [C][ME] 0 none, 1 this cell is cell 0 of a regular edge, 2 cell 1

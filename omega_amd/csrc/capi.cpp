@@ -694,6 +694,7 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"CellPVFinalOK", W.CellPVFinalOK},
                                         {"NIrregularEdges", W.NIrregularEdges},
                                         {"NIrregularOwned", W.NIrregularOwned},
+                                        {"NIrregularInner", W.NIrregularInner},
                                         {"DomM1", W.DomM1},
                                         {"NWideCells", W.NWideCells},
                                         {"NarrowTables", M.narrowView() ? 1 : 0},

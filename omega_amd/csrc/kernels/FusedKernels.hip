@@ -2335,7 +2335,8 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       }
       // (a stage whose halo outputs the exchange replaces: the owned irregular edges -- a coast -- only, not the masked
       // edges of the halo rim)
-      const int NIrr = SendOnly ? M.NIrregularOwned : M.NIrregularEdges;
+      // (... and a stage whose velocity sweep stops after halo layer 3 finishes the edges of the cells through layer 2)
+      const int NIrr = SendOnly ? M.NIrregularOwned : (NSweepVel < M.NCellsAll ? M.NIrregularInner : M.NIrregularEdges);
       if (NIrr > 0 && !FoldChain) {
          auto LaunchList = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
