@@ -444,6 +444,8 @@ def main():
                 return [oa.global_sum_dd(p) for p in parts]
             a, b = checksum(True), checksum(False)
             overlap_check = {"overlapped_equals_sequential": a == b, "checksums_h_u_tracers": a}
+            if a != b:
+                overlap_check["sequential_checksums_h_u_tracers"] = b
             if a != b:   # the SYPD above was measured on an exchange that does not reproduce the sequential one
                 rk4_error = "overlapped and sequential halo exchanges give different states (see rk4.overlap_check)"
                 sypd = None

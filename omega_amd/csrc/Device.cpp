@@ -106,6 +106,12 @@ DeviceBuffer::DeviceBuffer(size_t B) : Bytes(B) {
       B = 8;
    HIP_CHECK(hipMalloc(&Ptr, B));
    HIP_CHECK(hipMemset(Ptr, 0, B)); // Kokkos views are zero-initialised; the sentinel rows rely on it
+   // hipMemset of device memory returns before its fill kernel (queued on the null stream) has run, and work on a
+   // non-blocking stream is not ordered after the null stream: an array allocated right before its first use -- the
+   // stepper's provisional state at the first step, a halo buffer at the first exchange -- could be zeroed AFTER the
+   // first kernels had written it (seen as NaNs in one of five 4-rank runs sharing a GPU).  Allocation is set-up work:
+   // wait for the fill here.
+   HIP_CHECK(hipStreamSynchronize(nullptr));
 }
 DeviceBuffer::~DeviceBuffer() {
    if (Ptr)

@@ -26,6 +26,7 @@ PeerWire::PeerWire(int NRanks_, int Rank_, size_t MailboxBytes_)
    Flags = static_cast<unsigned long long *>(F);
    HIP_CHECK(hipMemset(Mailbox, 0, MailboxBytes));
    HIP_CHECK(hipMemset(Flags, 0, 2 * (size_t)NRanks * sizeof(unsigned long long)));
+   HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills have run before any peer can see these buffers (Device.cpp)
    void *St = nullptr;
    HIP_CHECK(hipHostMalloc(&St, sizeof(int), hipHostMallocMapped));
    Status  = static_cast<int *>(St);

@@ -125,3 +125,26 @@ def test_repeated_evaluations_are_bitwise_deterministic(P):
         assert np.array_equal(a, b)
     P.state.copy_to_device(P.h, P.u, 0)
     P.tracers.copy_to_device(P.tr, 0)
+
+
+def test_arrays_allocated_right_before_their_first_use_on_a_non_blocking_stream(P):
+    """The zero fill of a fresh device array is queued on the null stream, and work on a hipStreamNonBlocking stream is
+    not ordered after the null stream: objects created right before their first use (here: the tendency arrays and the
+    fused RHS's private intermediates, ~ 3 GB at this size; in a model run: the RK4 stepper's provisional state at the
+    first step) must not be zeroed after the first kernels have written them.  (Found by a 4-rank bench rehearsal on one
+    GPU: NaNs in one of five runs; Device.cpp: DeviceBuffer.)"""
+    if P.NT > 8:
+        pytest.skip("one size is enough (host copies of 37 tracer tendencies are 11 GB)")
+    s = oa.Stream()
+    for _ in range(3):
+        tend = oa.Tendencies(P.mesh, P.K, P.NT, oa.default_config())
+        tend.compute_all_tendencies(P.state, P.aux, P.tracers, stream=s)   # queued while the fills could still be running
+        oa.device_synchronize()
+        first = [tend.get(0), tend.get(1)]
+        tend.compute_all_tendencies(P.state, P.aux, P.tracers, stream=s)
+        oa.device_synchronize()
+        again = [tend.get(0), tend.get(1)]
+        assert np.abs(first[1]).max() > 0
+        for a, b in zip(first, again):
+            assert np.array_equal(a, b)
+        del tend
