@@ -131,6 +131,9 @@ def main():
                     help="untimed: before the W warm-up steps (and before the RK4 warm-up step) the GPU runs this workload's "
                          "own RHS for this long, so that a short timed region does not start inside the power-management "
                          "transient that follows a load step (tools/probes/step_ramp.py); 0 = off")
+    ap.add_argument("--rk4-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the stepping part (wire set-up, RK4 steps, cross-check) may take before rank 0 prints "
+                         "the record with rk4.error set and the run ends non-zero; 0 = wait for ever")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--halo-width", type=int, default=0,
                     help="0 = 4 for N > 1 (partition-independent results with the del4 terms: two RHS evaluations per "
@@ -293,6 +296,116 @@ def main():
     n_cells_global = g["nCells"]
     cell_levels = n_cells_global * K
     value = cell_levels / (wall_rhs / args.steps)
+
+    # ------------------------------------------------ roofline of the dominant kernel (rank 0's view)
+    roofline = None
+    if ktimes:
+        name, ms = max(ktimes, key=lambda kv: kv[1])
+        local_cell_levels = mesh.NCellsAll * K  # every launch sweeps owned + halo elements
+        ach = algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels / (ms * 1e-3) / 1e9
+        # RHS-level figure: B_staged over the device time of one evaluation in the TIMED region (HIP events around it on
+        # the launch stream); the sum of the per-kernel events of the second pass is reported next to it
+        rhs_ms = dev_ms / args.steps
+        kernels_sum_ms = sum(m for _, m in ktimes)
+        rhs_ach = algorithmic_bytes_per_cell_level(NT) * local_cell_levels / (rhs_ms * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, gfx950 correction applied).  Only a file
+        # measured on exactly the kernel sources that run here (hash recorded in the file) and on this workload
+        # counts; otherwise traffic is null rather than stale.
+        traffic = traffic_src = None
+        if N == 1 and not args.unfused:
+            import glob
+            from tools.summarise_profile import kernel_source_sha
+            sha = kernel_source_sha()
+            for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+                with open(pmc_file) as fh:
+                    pmc = json.load(fh)
+                wl = "qu30"
+                pa = pmc.get("bench_args") or []
+                if "--workload" in pa:
+                    wl = pa[pa.index("--workload") + 1]
+                if pmc.get("kernel_source_sha") != sha or wl != args.workload:
+                    continue
+                def bases(n):     # "A<6, 6>+B<7, 7>" -> "A+B" (template arguments contain commas and, nested, '+' never)
+                    return "+".join(x.split("<")[0].strip() for x in n.split("+"))
+                base = bases(name)
+                cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and bases(k) == base]
+                # the RK4 stage-fused instantiations of the same body move more bytes (accumulator, provisional
+                # state); the RHS timed here is the plain instantiation: the candidate with the fewest bytes
+                plain = sorted(cands, key=lambda k: pmc[k]["hbm_bytes_per_launch"])
+                if plain:
+                    traffic = pmc[plain[0]]["hbm_bytes_per_launch"]
+                    traffic_src = os.path.relpath(pmc_file, ROOT) + " (kernel_source_sha " + sha + ")"
+                    break
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels,
+                    "kernel_ms": round(ms, 4),
+                    "kernel_timing": "HIP events on the launch stream between the launches, in a second pass of the same "
+                                     "steps right after the timed region",
+                    "kernels_ms": {k: round(v, 4) for k, v in ktimes},
+                    "rhs": {"algorithmic_bytes_per_cell_level": algorithmic_bytes_per_cell_level(NT),
+                            "ms": round(rhs_ms, 4), "kernels_sum_ms": round(kernels_sum_ms, 4), "achieved": round(rhs_ach, 1),
+                            "frac": round(rhs_ach / HBM_PEAK_GBS, 4)}}
+
+    # (everything the record reads exists from here on, whatever the stepping part reaches)
+    wire = None
+    wire_errors = None
+    nrk = args.rk4_steps if args.rk4_steps >= 0 else max(2, args.steps // 4)
+    overlap = N > 1 and not (args.no_overlap or args.no_fuse_stages or args.unfused)
+    emitted = []
+
+    def emit(sypd, t_rk4, rk4_error, overlap_check, cpu=None):
+        """rank 0: the ONE JSON line (also called by the watchdog below if the stepping part does not come back)"""
+        if rank != 0 or emitted:
+            return
+        emitted.append(True)
+        out = {"metric": "tendency_cell_level_updates_per_sec", "value": value, "unit": "cell-level-updates/s",
+               "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
+                          "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
+                          "kernel_paths": {f: mesh.get_int(f) for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK",
+                                                                        "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1")},
+                          "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
+                          "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
+                          "halo_wire": "none (1 rank)" if N == 1 else
+                          ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
+                           ((wire_note + (" " + json.dumps(wire.info()) if wire else "")) if wire_note else
+                            "none: " + "; ".join(wire_errors or ["?"])[:300])),
+                          "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
+                                                   "row-major" if args.block == 1 else f"blocked{args.block}")
+                                        + ", local numbering by Decomp: " + args.local_order,
+                          "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1),
+                          "untimed_settle": {"ms": args.settle_ms, "rhs_evaluations": settle_evals,
+                                             "why": "load step -> ~25 ms power-management transient (profiles/r03_probe_step_ramp.json)"},
+                          "hip_graph": graph_stats},
+               "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
+                       "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
+                       "halo_exchange": "none (1 rank)" if N == 1 else
+                       ("overlapped with the stage's interior cells" if overlap else "after the stage"),
+                       "error": rk4_error, "overlap_check": overlap_check},
+               "roofline": roofline, "cpu_baseline": cpu}
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+
+    # N > 1: if the stepping part (wire set-up, RK4, cross-check) hangs -- a peer died, a collective never returns -- the
+    # RHS measurement above must not be lost with it: rank 0 prints the record with rk4.error set and leaves.
+    watchdog = None
+    if N > 1 and rank == 0 and args.rk4_timeout > 0:
+        import threading
+
+        def give_up():
+            emit(None, None, f"the stepping part did not come back within {args.rk4_timeout:.0f} s (halo wire set-up, RK4 steps "
+                             "or the overlap cross-check hung); the RHS record stands", None)
+            os._exit(4)
+        watchdog = threading.Timer(args.rk4_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     # ------------------------------------------------ the halo wire (N > 1): needed by the stepping part only
     wire = None
@@ -457,95 +570,15 @@ def main():
             rk4_error = "the overlapped-vs-sequential cross-check failed (see rk4.overlap_check)"
             sypd = None
 
-    # ------------------------------------------------ roofline of the dominant kernel (rank 0's view)
-    roofline = None
-    if ktimes:
-        name, ms = max(ktimes, key=lambda kv: kv[1])
-        local_cell_levels = mesh.NCellsAll * K  # every launch sweeps owned + halo elements
-        ach = algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels / (ms * 1e-3) / 1e9
-        # RHS-level figure: B_staged over the device time of one evaluation in the TIMED region (HIP events around it on
-        # the launch stream); the sum of the per-kernel events of the second pass is reported next to it
-        rhs_ms = dev_ms / args.steps
-        kernels_sum_ms = sum(m for _, m in ktimes)
-        rhs_ach = algorithmic_bytes_per_cell_level(NT) * local_cell_levels / (rhs_ms * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, gfx950 correction applied).  Only a file
-        # measured on exactly the kernel sources that run here (hash recorded in the file) and on this workload
-        # counts; otherwise traffic is null rather than stale.
-        traffic = traffic_src = None
-        if N == 1 and not args.unfused:
-            import glob
-            from tools.summarise_profile import kernel_source_sha
-            sha = kernel_source_sha()
-            for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
-                with open(pmc_file) as fh:
-                    pmc = json.load(fh)
-                wl = "qu30"
-                pa = pmc.get("bench_args") or []
-                if "--workload" in pa:
-                    wl = pa[pa.index("--workload") + 1]
-                if pmc.get("kernel_source_sha") != sha or wl != args.workload:
-                    continue
-                def bases(n):     # "A<6, 6>+B<7, 7>" -> "A+B" (template arguments contain commas and, nested, '+' never)
-                    return "+".join(x.split("<")[0].strip() for x in n.split("+"))
-                base = bases(name)
-                cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and bases(k) == base]
-                # the RK4 stage-fused instantiations of the same body move more bytes (accumulator, provisional
-                # state); the RHS timed here is the plain instantiation: the candidate with the fewest bytes
-                plain = sorted(cands, key=lambda k: pmc[k]["hbm_bytes_per_launch"])
-                if plain:
-                    traffic = pmc[plain[0]]["hbm_bytes_per_launch"]
-                    traffic_src = os.path.relpath(pmc_file, ROOT) + " (kernel_source_sha " + sha + ")"
-                    break
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": algorithmic_bytes_per_cell_level(NT, name) * local_cell_levels,
-                    "kernel_ms": round(ms, 4),
-                    "kernel_timing": "HIP events on the launch stream between the launches, in a second pass of the same "
-                                     "steps right after the timed region",
-                    "kernels_ms": {k: round(v, 4) for k, v in ktimes},
-                    "rhs": {"algorithmic_bytes_per_cell_level": algorithmic_bytes_per_cell_level(NT),
-                            "ms": round(rhs_ms, 4), "kernels_sum_ms": round(kernels_sum_ms, 4), "achieved": round(rhs_ach, 1),
-                            "frac": round(rhs_ach / HBM_PEAK_GBS, 4)}}
+    if watchdog is not None:
+        watchdog.cancel()
 
     # ------------------------------------------------ CPU baseline (rank 0, N = 1 only): the oracle
     cpu = None
     if N == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(nx, ny, K, NT, dc, args.dt) if (nx > 0 and not args.workload.endswith("_coast")) else None
 
-    if rank == 0:
-        out = {"metric": "tendency_cell_level_updates_per_sec", "value": value, "unit": "cell-level-updates/s",
-               "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic",
-               "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
-                          "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
-                          "kernel_paths": {f: mesh.get_int(f) for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK",
-                                                                        "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1")},
-                          "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
-                          "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
-                          "halo_wire": "none (1 rank)" if N == 1 else
-                          ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
-                           ((wire_note + (" " + json.dumps(wire.info()) if wire else "")) if wire_note else
-                            "none: " + "; ".join(wire_errors or ["?"])[:300])),
-                          "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
-                                                   "row-major" if args.block == 1 else f"blocked{args.block}")
-                                        + ", local numbering by Decomp: " + args.local_order,
-                          "device_ms_per_step": dev_ms / args.steps, "setup_s": round(setup_s, 1),
-                          "untimed_settle": {"ms": args.settle_ms, "rhs_evaluations": settle_evals,
-                                             "why": "load step -> ~25 ms power-management transient (profiles/r03_probe_step_ramp.json)"},
-                          "hip_graph": graph_stats},
-               "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
-                       "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
-                       "halo_exchange": "none (1 rank)" if N == 1 else
-                       ("overlapped with the stage's interior cells" if overlap else "after the stage"),
-                       "error": rk4_error, "overlap_check": overlap_check},
-               "roofline": roofline, "cpu_baseline": cpu}
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+    emit(sypd, t_rk4, rk4_error, overlap_check, cpu)
     if N > 1:
         oa.device_synchronize()
         dist.barrier()      # every rank's GPU work is complete: the wires may be taken down
