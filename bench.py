@@ -352,6 +352,7 @@ def main():
     # (everything the record reads exists from here on, whatever the stepping part reaches)
     wire = None
     wire_errors = None
+    wire_check = None
     nrk = args.rk4_steps if args.rk4_steps >= 0 else max(2, args.steps // 4)
     overlap = N > 1 and not (args.no_overlap or args.no_fuse_stages or args.unfused)
     emitted = []
@@ -375,6 +376,7 @@ def main():
                           ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else
                            ((wire_note + (" " + json.dumps(wire.info()) if wire else "")) if wire_note else
                             "none: " + "; ".join(wire_errors or ["?"])[:300])),
+                          "halo_wire_check": wire_check,
                           "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
                                                    "row-major" if args.block == 1 else f"blocked{args.block}")
                                         + ", local numbering by Decomp: " + args.local_order,
@@ -480,6 +482,29 @@ def main():
             from omega_amd.transport import GlooStagedTransport
             GlooStagedTransport(halo)
             wire_note = "host-staged gloo (rehearsal, --allow-host-staged)"
+        # The wire is checked before it carries the model state: the reference's HaloTest (test/base/HaloTest.cpp:41-100)
+        # on the real wire -- owned cells and edges hold their global ids, one exchange, every halo layer must hold its
+        # owners' ids.  A wire that fails is not replaced by another one: the cause is reported (rk4.error), the RHS
+        # record stands, the run ends non-zero.
+        wire_check = None
+        if not wire_errors:
+            err = ""
+            try:
+                for elem, ids, rows, n_own, n_all in ((0, cell_id, mesh.NCellsSize, mesh.NCellsOwned, mesh.NCellsAll),
+                                                      (1, edge_id, mesh.NEdgesSize, mesh.NEdgesOwned, mesh.NEdgesAll)):
+                    a = np.zeros(rows, dtype=np.int32)
+                    a[:n_own] = ids[:n_own]
+                    buf = oa.DeviceBuffer(a)
+                    halo.exchange(buf.ptr, 1, rows, 1, elem, stream=stream, elem_bytes=4)
+                    oa.device_synchronize()
+                    if not np.array_equal(buf.to_host()[:n_all], np.asarray(ids[:n_all], dtype=np.int32)):
+                        err = f"rank {rank}: wrong global ids in the halo after an exchange of element kind {elem}"
+            except Exception as exc:  # noqa: BLE001
+                err = f"rank {rank}: id exchange: {type(exc).__name__}: {exc}"
+            errs = gather_errors(err)
+            wire_check = "global-id exchange (cells, edges): " + ("ok on every rank" if not errs else "FAILED")
+            if errs:
+                wire_errors = ["the halo wire does not deliver the owners' values: " + "; ".join(errs)[:400]]
         if wire_errors and rank == 0:
             print("[bench] no halo wire: " + "; ".join(wire_errors), file=sys.stderr, flush=True)
 
