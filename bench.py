@@ -353,6 +353,7 @@ def main():
     wire = None
     wire_errors = None
     wire_check = None
+    state_checksums = None
     nrk = args.rk4_steps if args.rk4_steps >= 0 else max(2, args.steps // 4)
     overlap = N > 1 and not (args.no_overlap or args.no_fuse_stages or args.unfused)
     emitted = []
@@ -388,7 +389,8 @@ def main():
                        "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
                        "halo_exchange": "none (1 rank)" if N == 1 else
                        ("overlapped with the stage's interior cells" if overlap else "after the stage"),
-                       "error": rk4_error, "overlap_check": overlap_check},
+                       "error": rk4_error, "overlap_check": overlap_check,
+                       "state_checksums_after_2_steps": state_checksums},
                "roofline": roofline, "cpu_baseline": cpu}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -559,28 +561,37 @@ def main():
     # interior work, and exchanges after the stage -- must leave the same bits (global double-double checksum of h, u
     # and the tracers over owned elements, combined in rank order).
     overlap_check = None
+
+    def checksum(mode_overlap):
+        """global double-double sums of h, u and every tracer over owned elements after two RK4 steps from the initial state"""
+        ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
+        state.copy_to_device(h, u, 0)
+        tracers.copy_to_device(tr, 0)
+        st2 = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
+        st2.set_option("OverlapHaloExchange", mode_overlap)
+        for _ in range(2):
+            st2.do_step(state, stream=stream)
+        oa.device_synchronize()
+        kp = oa.level_pitch(K)
+        parts = [oa.local_weighted_sum_dd(ones_c.ptr, state.device_ptr(0, 0), mesh.NCellsOwned, K, row_pitch=kp, stream=stream),
+                 oa.local_weighted_sum_dd(ones_e.ptr, state.device_ptr(1, 0), mesh.NEdgesOwned, K, row_pitch=kp, stream=stream)]
+        parts += [oa.local_weighted_sum_dd(ones_c.ptr, tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp,
+                                           mesh.NCellsOwned, K, row_pitch=kp, stream=stream) for l in range(NT)]
+        return [oa.global_sum_dd(p) for p in parts] if N > 1 else [oa.combine_dd([p])[0] for p in parts]
+
+    # N = 1: the same sums, so that the records of an N = 1, 2, 4, 8 series can be compared with each other -- at
+    # HaloWidth >= 4 the partitioned runs must give the one-rank run's sums (rk4.state_checksums_after_2_steps)
+    state_checksums = None
+    if N == 1 and nrk > 0 and rk4_error is None and not (args.no_fuse_stages or args.unfused):
+        try:
+            state_checksums = checksum(False)
+        except Exception as exc:  # noqa: BLE001
+            state_checksums = f"{type(exc).__name__}: {exc}"
     if N > 1 and nrk > 0 and rk4_error is None and overlap:
         check_err = None
         try:
-            ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
-
-            def checksum(mode_overlap):
-                state.copy_to_device(h, u, 0)
-                tracers.copy_to_device(tr, 0)
-                st2 = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
-                st2.set_option("OverlapHaloExchange", mode_overlap)
-                for _ in range(2):
-                    st2.do_step(state, stream=stream)
-                oa.device_synchronize()
-                kp = oa.level_pitch(K)
-                parts = [oa.local_weighted_sum_dd(ones_c.ptr, state.device_ptr(0, 0), mesh.NCellsOwned, K, row_pitch=kp,
-                                                  stream=stream),
-                         oa.local_weighted_sum_dd(ones_e.ptr, state.device_ptr(1, 0), mesh.NEdgesOwned, K, row_pitch=kp,
-                                                  stream=stream)]
-                parts += [oa.local_weighted_sum_dd(ones_c.ptr, tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp,
-                                                   mesh.NCellsOwned, K, row_pitch=kp, stream=stream) for l in range(NT)]
-                return [oa.global_sum_dd(p) for p in parts]
             a, b = checksum(True), checksum(False)
+            state_checksums = a
             overlap_check = {"overlapped_equals_sequential": a == b, "checksums_h_u_tracers": a}
             if a != b:
                 overlap_check["sequential_checksums_h_u_tracers"] = b
