@@ -201,3 +201,27 @@ def test_four_ranks_one_gpu():
     through two of them) on one GPU, overlapped exchanges."""
     outs = run_ranks("gpu", 4, ["--no-del4", "--nx", 48, "--ny", 48, "--levels", 3], timeout=900)
     assert all("OK" in o for o in outs)
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """bench.py's own N > 1 path, rehearsed the way tools/rehearse_n.sh does it: two ranks under torch.distributed.run on
+    ONE GPU (RCCL refuses that, so `auto` takes the library's peer wire), the small workload.  The record must carry the
+    wire check, a stepping part without error, overlapped == sequential, and the state sums of the one-rank run."""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "small", "--no-cpu-baseline"]
+    r1 = subprocess.run([*base, "--gpus", "1"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r1.returncode == 0, r1.stderr.decode()[-2000:]
+    one = json.loads(r1.stdout.decode().strip().splitlines()[-1])
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), *base[1:], "--gpus", "2", "--single-device"],
+                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r2.returncode == 0, r2.stderr.decode()[-3000:]
+    two = json.loads(r2.stdout.decode().strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["value"] > 0 and two["rk4"]["error"] is None
+    assert two["config"]["halo_wire_check"].endswith("ok on every rank")
+    assert two["rk4"]["overlap_check"]["overlapped_equals_sequential"] is True
+    assert two["rk4"]["state_checksums_after_2_steps"] == one["rk4"]["state_checksums_after_2_steps"]
