@@ -1,6 +1,7 @@
 """probe: does the RHS time depend on WHERE the arrays were allocated?  Same process, same mesh: the state / aux /
 tendency objects are created several times over and the fused RHS is timed on each set."""
-import sys, os, time
+import os
+import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import omega_amd as oa
