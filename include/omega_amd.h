@@ -77,6 +77,10 @@ typedef struct omg_global_mesh {
 } omg_global_mesh;
 
 /* ---- raw device buffers for hosts without their own HIP runtime binding (Kokkos::View allocation / deep_copy) ---- */
+/* number of device resources (buffers, streams, events) the library has created in this process: everything a time
+ * step needs is created by the constructors / omg_stepper_create (O/src/timeStepping/RungeKutta4Stepper.cpp:43-64
+ * allocates in finalizeInit), so the number does not move across omg_stepper_do_step calls */
+int omg_device_resource_count(int64_t *n);
 int omg_device_malloc(size_t bytes, void **ptr);
 int omg_device_free(void *ptr);
 int omg_copy_to_device(void *dst, const void *src, size_t bytes);
@@ -147,8 +151,10 @@ int omg_decomp_create(const omg_global_mesh *mesh, int nparts, int mytask, int h
 /* local_order: 0 = the reference's numbering (owned cells in global-id order, every halo layer sorted by global id,
  * O/src/base/Decomp.cpp:1000-1080); 1 = every group ordered along a Morton curve through the cell centres, so that
  * consecutive local elements are spatial neighbours whatever order the mesh file uses; 2 = the same along a Hilbert
- * curve (edges / vertices follow the cells in every case).  Per global id the results of every computation are
- * identical. */
+ * curve; 3 = k-d order: every group bisected recursively at the median of its widest axis, so that aligned runs of 8 /
+ * 16 / 32 local cells -- the kernels' tiles -- are compact patches on the surface the cells live on (spheres: a tile
+ * touches 35 distinct cell rows instead of 42 with the 3-D curves).  Edges / vertices follow the cells in every case.
+ * Per global id the results of every computation are identical. */
 int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
                               const int32_t *cell_task, int local_order, omg_decomp **out);
 /* Built-in partitioners of the cell graph (the reference calls METIS_PartGraphKway, O/src/base/Decomp.cpp:868-1000):
@@ -235,13 +241,25 @@ int omg_halo_exchange_bytes(omg_halo *h, void *dev_array, int elem_bytes, int nt
                             int elem, void *stream);
 int omg_halo_exchange_i4(omg_halo *h, int32_t *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
                          void *stream);
+/* globalSum (O/src/base/Reductions.h:71-88 scalar, :150-190 array forms: MPI_Allreduce with the double-double operator
+ * MPI_SUMDD) for npairs (<= 64) local partial sums at once: local_hi_lo[npairs][2] (from omg_local_sum_dd /
+ * omg_local_weighted_sum_dd) is all-gathered over the Halo's wire -- ncclAllGather on the RCCL communicator, or the
+ * peer wire's gather slots -- and combined in rank order with omg_combine_dd: hi_lo[npairs][2], the same bits on every
+ * rank and for every partition.  Collective over all tasks of the decomposition; synchronises `stream`.  One task: the
+ * combination alone.  Fails on a Halo whose wire is a caller-supplied transport. */
+int omg_halo_global_sum_dd(omg_halo *h, const double *local_hi_lo, int npairs, double *hi_lo, void *stream);
+/* The wire's verdict, to be asked after the host has synchronised with an exchange's stream (the exchange calls return
+ * when the work is queued): 0 = fine; fails (message: omg_last_error) when a peer-wire wait gave up -- the unpack
+ * kernel of that exchange then copied nothing, the halo is stale.  The time steppers ask at the start of every step. */
+int omg_halo_check(const omg_halo *h);
 
 /* ---- Measurement / test options (omega_amd/csrc/Tuning.h).  The library never reads the environment: every switch that
  *      changes the kernel structure or the tile geometry is set through this call.  Defaults are what production
  *      runs.  Names: W TX TY Sweeps ChunkSplit TailSplit (tile geometry); EdgeMode FuseFinal MergeL1 Pair FuseL3
  *      FoldLists InlineOther Alternate (structure of the fused RHS; read at every launch); SendBand BandOnComm
  *      ShrinkSweeps (what a rank leaves out inside an RK4 step; read at every stage); ForceGeneric KeepMaxEdges
- *      DomValence NarrowTables (mesh tables; read when a HorzMesh is created); Graphs (-1 per object, 0 never, 1 default
+ *      DomValence NarrowTables (mesh tables; read when a HorzMesh is created); WaveWindow (local numbering; read when a
+ *      Decomp with a curve order is created); Graphs (-1 per object, 0 never, 1 default
  *      on).  Unknown names fail.
  *      omg_set_timing_level: roctx ranges named after the reference's Pacer timers ("Tend:...", "AuxState:...",
  *      "RK4:haloExch"; share/pacer/Pacer.cpp:138-200) are emitted for timers up to this level (default 3 = all). ---- */

@@ -376,9 +376,20 @@ def local_weighted_sum_dd(w_ptr: int, a_ptr: int, nrows: int, k: int, b_ptr: int
     return out[0], out[1]
 
 
-def global_sum_dd(local_hi_lo, group=None) -> float:
+def device_resource_count() -> int:
+    """omg_device_resource_count: device buffers, streams and events the library has created so far"""
+    n = C.c_int64()
+    _chk(lib().omg_device_resource_count(C.byref(n)))
+    return n.value
+
+
+def global_sum_dd(local_hi_lo, group=None, halo=None, stream=None) -> float:
     """globalSum (Reductions.h:71-84): all-gather the ranks' (hi, lo) partial sums and combine them with the
-    ddSum operator in rank order -- the same value on every rank and for every partition."""
+    ddSum operator in rank order -- the same value on every rank and for every partition.  With `halo` the gather
+    runs inside the library over that Halo's wire (omg_halo_global_sum_dd: RCCL or peer wire); without, over
+    torch.distributed (test rigs on the host-staged transport)."""
+    if halo is not None:
+        return halo.global_sum_dd([local_hi_lo], stream=stream)[0]
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -409,12 +420,13 @@ class Decomp:
     def __init__(self, gm: GlobalMesh, nparts: int = 1, mytask: int = 0, halo_width: int = 3, cell_task=None,
                  local_order: str = "global"):
         """local_order: "global" (the reference's numbering by global id), "curve" (Morton curve through the cell
-        centres: spatially compact local numbering whatever the file's order) or "hilbert" (Hilbert curve)."""
+        centres: spatially compact local numbering whatever the file's order), "hilbert" (Hilbert curve) or "kd" (k-d
+        order: compact tiles on the surface -- what spheres want)."""
         self.gm = gm
         h = C.c_void_p()
         ct = None if cell_task is None else np.ascontiguousarray(cell_task, dtype=np.int32)
         _chk(lib().omg_decomp_create_ordered(C.byref(gm.s), nparts, mytask, halo_width, _pi(ct),
-                                             {"global": 0, "curve": 1, "hilbert": 2}[local_order], C.byref(h)))
+                                             {"global": 0, "curve": 1, "hilbert": 2, "kd": 3}[local_order], C.byref(h)))
         self.h = h
 
     def get_int(self, name: str) -> int:
@@ -563,6 +575,17 @@ class Halo:
         """Route the exchanges through direct peer copies into the neighbours' mailboxes (stream-ordered, no host waits)."""
         _chk(lib().omg_halo_use_peer(self.h, wire.h))
         self._wire = wire
+
+    def global_sum_dd(self, local_pairs, stream=None) -> list:
+        """omg_halo_global_sum_dd: [(hi, lo), ...] local partial sums -> the global sums (hi parts), same bits on every rank"""
+        p = np.ascontiguousarray(local_pairs, dtype=np.float64).reshape(-1, 2)
+        out = np.zeros_like(p)
+        _chk(lib().omg_halo_global_sum_dd(self.h, _pd(p), p.shape[0], _pd(out), _sh(stream)))
+        return [float(x) for x in out[:, 0]]
+
+    def check(self):
+        """omg_halo_check: raises if a peer-wire wait of an earlier exchange gave up (ask after synchronising)"""
+        _chk(lib().omg_halo_check(self.h))
 
     def recv_rows(self, per_cell: int, per_edge: int, per_vertex: int = 0) -> int:
         r = C.c_size_t()

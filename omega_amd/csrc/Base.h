@@ -182,6 +182,12 @@ template <class T> class Registry {
 
 // ---- device helpers (Device.cpp) ----
 void deviceInit(int DeviceId);                 ///< hipSetDevice + sanity check (gfx950)
+/// Number of device resources the library has created so far in this process: device buffers (DeviceBuffer, the peer
+/// wire's mailbox and flags), streams and events.  Everything a time step needs is created when its objects are
+/// initialised (the reference allocates in the constructors / finalizeInit, RungeKutta4Stepper.cpp:43-64), so this
+/// number does not move across doStep calls (tests/test_gpu_properties.py).
+I8 deviceResourceCount();
+void noteDeviceResource(int N = 1);
 void copyToDevice(void *Dst, const void *Src, size_t Bytes, hipStream_t S = nullptr);
 void copyToHost(void *Dst, const void *Src, size_t Bytes, hipStream_t S = nullptr);
 /// rows x width values between a compact host array and a device array of row pitch `Pitch` (values)

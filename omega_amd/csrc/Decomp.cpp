@@ -5,7 +5,10 @@
 #include "Decomp.h"
 #include "Partition.h"
 
+#include "Tuning.h"
+
 #include <algorithm>
+#include <array>
 #include <numeric>
 
 namespace OMEGA {
@@ -98,12 +101,133 @@ void Decomp::buildCellOrder() {
       CellRank[CellSeq[I]] = I;
 }
 
+void Decomp::buildSlotMasks() {
+   SlotMask.assign(NCellsGlobal, 0);
+   NSlots.assign(NCellsGlobal, 0);
+   for (I4 C = 0; C < NCellsGlobal; ++C) {
+      int N = 0;
+      unsigned M = 0;
+      for (int J = 0; J < MaxEdges && N < 8; ++J) {
+         const I4 E = G.EdgesOnCell[(size_t)C * MaxEdges + J];
+         if (E < 0 || E >= NEdgesGlobal)
+            continue; // (slots are compacted to the active edges: buildLocalConnectivity)
+         if (G.CellsOnEdge[2 * (size_t)E + 1] == C)
+            M |= 1u << N;
+         ++N;
+      }
+      SlotMask[C] = (unsigned char)M;
+      NSlots[C]   = (unsigned char)N;
+   }
+}
+
+// Greedy regrouping inside windows: a wave (8 consecutive local cells, aligned to multiples of 8 of the local index) is
+// seeded with the first cell of the window not yet placed and filled with the cells that add the fewest new "second
+// cell" slots and the fewest new "first cell" slots to the wave's unions (ties: curve order).  Deterministic: every
+// rank derives every rank's numbering.
+void Decomp::clusterWaves(std::vector<I4> &List, size_t Begin, size_t End) const {
+   if (WaveWindow < 16 || End - Begin < 16)
+      return;
+   static const auto Pop = [] {
+      std::array<unsigned char, 256> P{};
+      for (int I = 0; I < 256; ++I)
+         P[I] = (unsigned char)__builtin_popcount(I);
+      return P;
+   }();
+   const size_t W = (size_t)WaveWindow;
+   std::vector<I4> Rem, Out;
+   for (size_t W0 = Begin; W0 < End;) {
+      // windows end on multiples of WaveWindow of the local index, waves on multiples of 8
+      size_t W1 = (W0 / W + 1) * W;
+      if (W1 > End)
+         W1 = End;
+      Rem.assign(List.begin() + W0, List.begin() + W1);
+      Out.clear();
+      size_t Pos = W0;
+      while (!Rem.empty()) {
+         const size_t GroupEnd = std::min(W1, (Pos / 8 + 1) * 8);
+         const I4 Seed         = Rem.front();
+         Rem.erase(Rem.begin());
+         Out.push_back(Seed);
+         ++Pos;
+         unsigned U2 = SlotMask[Seed], U1 = (~SlotMask[Seed]) & ((1u << NSlots[Seed]) - 1);
+         while (Pos < GroupEnd && !Rem.empty()) {
+            size_t Best = 0;
+            int BestCost = 1 << 30;
+            for (size_t J = 0; J < Rem.size(); ++J) {
+               const I4 C2      = Rem[J];
+               const unsigned A = U2 | SlotMask[C2], B = U1 | ((~SlotMask[C2]) & ((1u << NSlots[C2]) - 1));
+               const int Cost   = Pop[A & 255] + Pop[B & 255];
+               if (Cost < BestCost)
+                  BestCost = Cost, Best = J;
+            }
+            const I4 C2 = Rem[Best];
+            Rem.erase(Rem.begin() + Best);
+            Out.push_back(C2);
+            U2 |= SlotMask[C2], U1 |= (~SlotMask[C2]) & ((1u << NSlots[C2]) - 1);
+            ++Pos;
+         }
+      }
+      std::copy(Out.begin(), Out.end(), List.begin() + W0);
+      W0 = W1;
+   }
+}
+
+// Recursive median bisection along the widest axis (see LocalOrder::KdTree).  Splits of more than 32 cells fall on a
+// multiple of 32 nearest to the middle, 32 -> 16 + 16, 16 -> 8 + 8: aligned runs of 8, 16 and 32 cells are subtrees.
+// Deterministic (ties by global id): every rank derives every rank's numbering.
+void Decomp::kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const {
+   OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: k-d ordering needs cell coordinates");
+   const R8 *Cd[3] = {G.XCell, G.YCell, G.ZCell};
+   std::vector<std::pair<size_t, size_t>> Stack;
+   Stack.emplace_back(Begin, End);
+   while (!Stack.empty()) {
+      const auto [Lo, Hi] = Stack.back();
+      Stack.pop_back();
+      const size_t M = Hi - Lo;
+      if (M <= 8)
+         continue;
+      int Ax    = 0;
+      R8 BestEx = -1;
+      for (int A = 0; A < 3; ++A) {
+         if (!Cd[A])
+            continue;
+         R8 Mn = 1e300, Mx = -1e300;
+         for (size_t I = Lo; I < Hi; ++I)
+            Mn = std::min(Mn, Cd[A][List[I]]), Mx = std::max(Mx, Cd[A][List[I]]);
+         if (Mx - Mn > BestEx)
+            BestEx = Mx - Mn, Ax = A;
+      }
+      size_t NL;
+      if (M > 32) {
+         NL = (M / 2 + 16) / 32 * 32;
+         if (NL == 0)
+            NL = 32;
+         if (NL >= M)
+            NL = (M - 1) / 32 * 32;
+      } else {
+         NL = M > 16 ? 16 : 8;
+      }
+      const R8 *X = Cd[Ax];
+      std::nth_element(List.begin() + Lo, List.begin() + Lo + NL, List.begin() + Hi,
+                       [X](I4 A, I4 B) { return X[A] < X[B] || (X[A] == X[B] && A < B); });
+      Stack.emplace_back(Lo + NL, Hi);
+      Stack.emplace_back(Lo, Lo + NL);
+   }
+}
+
 // Owner task and local address on the owner for every global cell/edge/vertex.
 void Decomp::computeOwnership() {
-   std::vector<I4> Count(NumTasks, 0);
+   // every task's owned cells in numbering order: the sequence (global-id order in the reference, :1000-1015), regrouped
+   // wave by wave where asked for
+   OwnedSeq.assign(NumTasks, {});
+   for (I4 C : CellSeq)
+      OwnedSeq[CellTask[C]].push_back(C);
    CellLocAll.assign(NCellsGlobal, 0);
-   for (I4 C : CellSeq) // owned cells keep the numbering sequence (global-id order in the reference, :1000-1015)
-      CellLocAll[C] = Count[CellTask[C]]++;
+   for (int T = 0; T < NumTasks; ++T) {
+      orderGroup(OwnedSeq[T], 0, OwnedSeq[T].size());
+      for (size_t L = 0; L < OwnedSeq[T].size(); ++L)
+         CellLocAll[OwnedSeq[T][L]] = (I4)L;
+   }
 
    // edge owner = task of the first valid cell in CellsOnEdge (:1476-1486)
    EdgeTask.assign(NEdgesGlobal, -1);
@@ -129,8 +253,8 @@ void Decomp::computeOwnership() {
    EdgeLocAll.assign(NEdgesGlobal, -1);
    VertexLocAll.assign(NVerticesGlobal, -1);
    std::vector<I4> ECount(NumTasks, 0), VCount(NumTasks, 0);
-   for (I4 C : CellSeq) {
-      const I4 T = CellTask[C];
+   for (int T = 0; T < NumTasks; ++T)
+   for (I4 C : OwnedSeq[T]) {
       for (int J = 0; J < MaxEdges; ++J) {
          I4 E = G.EdgesOnCell[(size_t)C * MaxEdges + J];
          if (E >= 0 && E < NEdgesGlobal && EdgeTask[E] == T && EdgeLocAll[E] < 0)
@@ -146,11 +270,9 @@ LocalSets Decomp::computeLocalSets(I4 Task) const {
    LocalSets S;
    // ---- cells: owned in global order, then HaloWidth BFS layers, each sorted ----
    std::vector<char> InList(NCellsGlobal, 0);
-   for (I4 C : CellSeq)
-      if (CellTask[C] == Task) {
-         S.CellID.push_back(C);
-         InList[C] = 1;
-      }
+   S.CellID = OwnedSeq[Task];
+   for (I4 C : S.CellID)
+      InList[C] = 1;
    S.NCellsOwned = (I4)S.CellID.size();
    S.NCellsHalo.assign(HaloWidth, 0);
    size_t Start = 0, End = S.CellID.size();
@@ -170,6 +292,7 @@ LocalSets Decomp::computeLocalSets(I4 Task) const {
       }
       std::sort(Layer.begin(), Layer.end(), [&](I4 A, I4 B) { return CellRank[A] < CellRank[B]; });
       S.CellID.insert(S.CellID.end(), Layer.begin(), Layer.end());
+      orderGroup(S.CellID, S.CellID.size() - Layer.size(), S.CellID.size());
       S.NCellsHalo[Halo] = (I4)S.CellID.size();
       Start              = End;
       End                = S.CellID.size();
@@ -331,6 +454,10 @@ Decomp::Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask_, I4 HaloWidth_,
       partitionRCB();
    }
    buildCellOrder();
+   if (Order != LocalOrder::GlobalID && tuning().WaveWindow >= 16) {
+      WaveWindow = tuning().WaveWindow / 8 * 8;
+      buildSlotMasks();
+   }
    computeOwnership();
 
    LocalSets S    = computeLocalSets(MyTask);

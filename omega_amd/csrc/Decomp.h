@@ -47,7 +47,13 @@ enum PartMethod { PartMethodRCB, PartMethodUser };
 /// with; Hilbert does the same along a Hilbert curve (no jumps: consecutive cells are always adjacent boxes of the
 /// quantisation grid).  Edges and vertices follow the cells (order of encounter) in every case.  Results per global
 /// id are identical; only the local numbering differs.
-enum class LocalOrder { GlobalID = 0, Curve = 1, Hilbert = 2 };
+/// KdTree orders each group by recursive median bisection along the widest axis of the subset's bounding box, down to
+/// leaves of 8 cells (splits on multiples of 32 cells above that): every aligned run of 8 / 16 / 32 local cells -- a
+/// kernel's tile -- is a compact, roughly square patch ON THE SURFACE the cells live on.  On a sphere the 3-D Morton and
+/// Hilbert curves cut the surface with an axis-aligned grid: their 16-cell runs are 9.7 cell spacings across and touch
+/// 41.9 distinct cell rows (cell + neighbours) against 4.9 spacings / 35.0 rows for the k-d order and 4.7 / 34 for a
+/// planar 4 x 4 block (QU-sized icosahedral and Fibonacci spheres, 163 842 cells).
+enum class LocalOrder { GlobalID = 0, Curve = 1, Hilbert = 2, KdTree = 3 };
 
 /// Ordered local element lists of one rank (global 0-based ids) with layer bounds.
 struct LocalSets {
@@ -101,6 +107,28 @@ class Decomp : public Registry<Decomp> {
    GlobalMeshDesc G;
    std::vector<I4> CellSeq;  ///< cells in the order that numbers them (identity, or along the curve)
    std::vector<I4> CellRank; ///< position of each cell in CellSeq
+   /// Wave clustering (curve orders only; option WaveWindow, Tuning.h).  The cell kernels give one wavefront 8
+   /// consecutive local cells, and the cell-centric PV code finishes an edge in the thread of its second cell
+   /// (CellsOnEdge(e,1)): per edge slot a block only the lanes of "second cells" execute.  On a structured mesh every cell
+   /// has the same slots; on an unstructured one the orientation of CellsOnEdge is arbitrary and a wave of 8 curve
+   /// neighbours executes almost all 6 blocks instead of 3, each a dependent memory round trip.  Inside windows of
+   /// WaveWindow consecutive cells of a group the cells are therefore regrouped so that the 8 cells of a wave have
+   /// similar slot patterns.  Per global id nothing changes; only the local numbering does.
+   std::vector<unsigned char> SlotMask; ///< per global cell: bit j = the cell is CellsOnEdge(e,1) of its j-th active edge
+   std::vector<unsigned char> NSlots;   ///< per global cell: number of active edges
+   int WaveWindow = 0;
+   std::vector<std::vector<I4>> OwnedSeq; ///< per task: its owned cells in numbering order
+   void buildSlotMasks();
+   /// k-d order of List[Begin, End) in place (LocalOrder::KdTree)
+   void kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const;
+   /// what is applied to every group (owned cells of a task, a halo layer) after the sequence order
+   void orderGroup(std::vector<I4> &List, size_t Begin, size_t End) const {
+      if (Order == LocalOrder::KdTree)
+         kdOrder(List, Begin, End);
+      clusterWaves(List, Begin, End);
+   }
+   /// regroup List[Begin, End) -- local indices Begin.. -- in place
+   void clusterWaves(std::vector<I4> &List, size_t Begin, size_t End) const;
    void buildCellOrder();
    void partitionRCB();
    void computeOwnership();

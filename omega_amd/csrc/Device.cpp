@@ -5,6 +5,7 @@
 
 #include <rocprofiler-sdk-roctx/roctx.h>
 
+#include <atomic>
 #include <cctype>
 #include <cstdlib>
 
@@ -40,6 +41,7 @@ const OptionName OptionTable[] = {
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},
     {"NarrowTables", &TuningOptions::NarrowTables},
+    {"WaveWindow", &TuningOptions::WaveWindow},
     {"Graphs", &TuningOptions::Graphs},
 };
 } // namespace
@@ -101,10 +103,17 @@ void abortError(const char *File, int Line, const std::string &Msg) {
    throw OmegaError(OS.str());
 }
 
+namespace {
+std::atomic<I8> ResourceCount{0};
+}
+I8 deviceResourceCount() { return ResourceCount.load(); }
+void noteDeviceResource(int N) { ResourceCount += N; }
+
 DeviceBuffer::DeviceBuffer(size_t B) : Bytes(B) {
    if (B == 0)
       B = 8;
    HIP_CHECK(hipMalloc(&Ptr, B));
+   noteDeviceResource();
    HIP_CHECK(hipMemset(Ptr, 0, B)); // Kokkos views are zero-initialised; the sentinel rows rely on it
    // hipMemset of device memory returns before its fill kernel (queued on the null stream) has run, and work on a
    // non-blocking stream is not ordered after the null stream: an array allocated right before its first use -- the

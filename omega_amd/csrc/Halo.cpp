@@ -11,6 +11,7 @@ namespace OMEGA {
 
 Halo::Halo(const std::string &, const Decomp *D) {
    MyTask    = D->MyTask;
+   NumTasks  = D->NumTasks;
    HaloWidth = D->HaloWidth;
    const int NumTasks = D->NumTasks;
 
@@ -87,9 +88,38 @@ Halo::Halo(const std::string &, const Decomp *D) {
    RecvPtrs.assign(NNghbr, nullptr);
 }
 
+// Device-side resources exist from the moment a wire is chosen (a Halo without a wire is a host object: its lists are
+// used by CPU-side tools and tests): not at the first exchange -- no resource is created inside a time step.
+void Halo::ensureWireResources() {
+   if (NumTasks > 1 && !GatherIn.Ptr) {
+      GatherIn  = Array1DReal("HaloGatherIn", 2 * MaxSumPairs);
+      GatherOut = Array1DReal("HaloGatherOut", NumTasks * 2 * MaxSumPairs);
+   }
+   if (NNghbr > 0 && !EvLast) {
+      HIP_CHECK(hipEventCreateWithFlags(&EvLast, hipEventDisableTiming));
+      noteDeviceResource();
+   }
+}
+
 Halo::~Halo() {
+   unbindPeer();
    if (EvLast)
       (void)hipEventDestroy(EvLast);
+}
+
+void Halo::unbindPeer() {
+   if (Peer)
+      Peer->Bound = false;
+   Peer = nullptr;
+}
+
+void Halo::setTransport(HaloTransportFn Fn, void *Ctx) {
+   unbindPeer();
+   if (Fn)
+      ensureWireResources();
+   Rccl         = nullptr;
+   Transport    = Fn;
+   TransportCtx = Ctx;
 }
 
 void Halo::useRccl(RcclComm *Comm) {
@@ -98,6 +128,7 @@ void Halo::useRccl(RcclComm *Comm) {
    for (I4 T : NeighborList)
       OMEGA_REQUIRE(T < Comm->NRanks, "Halo::useRccl: a neighbour task is outside the communicator");
    setTransport(&RcclComm::transport, Comm);
+   Rccl = Comm;
 }
 
 void Halo::usePeerWire(PeerWire *Wire) {
@@ -105,14 +136,68 @@ void Halo::usePeerWire(PeerWire *Wire) {
    OMEGA_REQUIRE(Wire->Rank == MyTask, "Halo::usePeerWire: the wire's rank is not this Halo's task");
    OMEGA_REQUIRE(NNghbr <= PeerWire::MaxPeers, "Halo::usePeerWire: too many neighbours");
    OMEGA_REQUIRE(!Wire->Bound || Peer == Wire, "Halo::usePeerWire: this wire already serves another Halo");
-   Wire->Bound = true;
    for (I4 T : NeighborList)
       OMEGA_REQUIRE(T < Wire->NRanks, "Halo::usePeerWire: a neighbour task is outside the wire");
-   Peer      = Wire;
-   Transport = nullptr;
+   unbindPeer();
+   ensureWireResources();
+   Wire->Bound  = true;
+   Peer         = Wire;
+   Rccl         = nullptr;
+   Transport    = nullptr;
+   TransportCtx = nullptr;
 }
 
-std::string Halo::wireError() const { return (Peer && !Peer->lastError().empty()) ? ": " + Peer->lastError() : ""; }
+I4 Halo::checkWire() const { return (Peer && Peer->status() != 0) ? -1 : 0; }
+
+I4 Halo::globalSumDD(const double *LocalPairs, int NPairs, double *HiLo, hipStream_t S) {
+   OMEGA_REQUIRE(LocalPairs && HiLo && NPairs >= 0 && NPairs <= MaxSumPairs, "Halo::globalSumDD: 0..64 pairs per call");
+   SumError.clear();
+   if (NPairs == 0)
+      return 0;
+   if (NumTasks == 1) {
+      for (int I = 0; I < NPairs; ++I)
+         combineDD(LocalPairs + 2 * I, 1, HiLo + 2 * I);
+      return 0;
+   }
+   if (!Peer && !Rccl) {
+      SumError = ": Halo::globalSumDD needs the RCCL or the peer wire (a caller-supplied transport has no all-gather)";
+      return -1;
+   }
+   const int NVals = 2 * NPairs;
+   HIP_CHECK(hipMemcpyAsync(GatherIn.Ptr, LocalPairs, NVals * sizeof(double), hipMemcpyHostToDevice, S));
+   const int Err = Peer ? Peer->allGather(GatherIn.Ptr, NVals, GatherOut.Ptr, S)
+                        : Rccl->allGather(GatherIn.Ptr, GatherOut.Ptr, NVals * sizeof(double), S);
+   if (Err != 0) {
+      if (Rccl)
+         SumError = ": " + Rccl->lastError();
+      return -1;
+   }
+   std::vector<double> All((size_t)NumTasks * NVals), Pairs((size_t)NumTasks * 2);
+   HIP_CHECK(hipMemcpyAsync(All.data(), GatherOut.Ptr, All.size() * sizeof(double), hipMemcpyDeviceToHost, S));
+   HIP_CHECK(hipStreamSynchronize(S));
+   if (checkWire() != 0)
+      return -1;
+   for (int I = 0; I < NPairs; ++I) { // rank order: the same bits on every rank
+      for (int R = 0; R < NumTasks; ++R)
+         Pairs[2 * R] = All[(size_t)R * NVals + 2 * I], Pairs[2 * R + 1] = All[(size_t)R * NVals + 2 * I + 1];
+      combineDD(Pairs.data(), NumTasks, HiLo + 2 * I);
+   }
+   return 0;
+}
+
+std::string Halo::wireError() const {
+   if (!SumError.empty())
+      return SumError;
+   if (!Peer)
+      return "";
+   if (!Peer->lastError().empty())
+      return ": " + Peer->lastError();
+   if (int St = Peer->status())
+      return ": PeerWire: a wait for a peer gave up (status " + std::to_string(St) +
+             ": bit 0 = my previous message was never consumed, bit 1 = a neighbour's message never arrived); the halo was "
+             "left as it was";
+   return "";
+}
 
 size_t Halo::recvRows(size_t NTC, size_t NTE, size_t NTV) const {
    size_t R = 0;
@@ -207,8 +292,6 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
       SendPtrs[N] = static_cast<char *>(SendBuf->Ptr) + Pl.SendOff[N];
       RecvPtrs[N] = RecvBase + Pl.RecvOff[N];
    }
-   if (!EvLast)
-      HIP_CHECK(hipEventCreateWithFlags(&EvLast, hipEventDisableTiming));
    if (HaveLast)
       HIP_CHECK(hipStreamWaitEvent(S, EvLast, 0)); // the shared buffers are free once the previous exchange is done
    // pack: one launch for every neighbour and array (Halo.h:324-414)
@@ -220,7 +303,8 @@ I4 Halo::exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S) {
    if (Err != 0)
       return -1;
    // unpack: one launch (Halo.h:566-653)
-   launchHaloUnpackAll(B, RecvBase, Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, Pl.ElemBytes, S);
+   launchHaloUnpackAll(B, RecvBase, Pl.RecvJobs.Ptr, Pl.NRecvRows, Pl.K, Pl.Pitch, Pl.ElemBytes, S,
+                       Peer ? Peer->statusWord() : nullptr);
    if (Peer && Peer->release(NNghbr, NeighborList.data(), S) != 0)
       return -1;
    HIP_CHECK(hipEventRecord(EvLast, S));
@@ -256,6 +340,17 @@ I4 Halo::exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3D
    if (Tr && NT > 0)
       P.push_back(Piece{Tr->Ptr, OnCell, NT, Tr->Ext[1], Tr->Ext[2], Tr->Pitch});
    return exchangePieces(P, S);
+}
+void Halo::reserveState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT) {
+   if (NNghbr == 0)
+      return;
+   std::vector<Piece> P{Piece{H.Ptr, OnCell, 1, H.Ext[0], H.Ext[1], H.Pitch},
+                        Piece{U.Ptr, OnEdge, 1, U.Ext[0], U.Ext[1], U.Pitch}};
+   if (Tr && NT > 0)
+      P.push_back(Piece{Tr->Ptr, OnCell, NT, Tr->Ext[1], Tr->Ext[2], Tr->Pitch});
+   const Plan &Pl        = planFor(P);
+   const size_t RowBytes = (size_t)Pl.K * Pl.ElemBytes;
+   ensureBuffers(Pl.NSendRows * RowBytes, Peer ? 0 : Pl.NRecvRows * RowBytes);
 }
 
 } // namespace OMEGA

@@ -39,16 +39,14 @@ class Halo : public Registry<Halo> {
    Halo(const std::string &Name, const Decomp *InDecomp);
    ~Halo();
 
-   I4 MyTask, NNghbr = 0, HaloWidth;
+   I4 MyTask, NumTasks = 1, NNghbr = 0, HaloWidth;
    std::vector<I4> NeighborList; ///< sorted task ids
 
    /// Exchange lists [kind][neighbour], concatenated over halo layers (local indices).
    std::vector<std::vector<I4>> SendLists[3], RecvLists[3];
 
-   void setTransport(HaloTransportFn Fn, void *Ctx) {
-      Transport    = Fn;
-      TransportCtx = Ctx;
-   }
+   /// (choosing a wire replaces the one chosen before: a peer wire bound to this Halo is unbound)
+   void setTransport(HaloTransportFn Fn, void *Ctx);
    /// production wire: grouped RCCL send / recv on the exchange's stream (the communicator outlives the Halo)
    void useRccl(class RcclComm *Comm);
    /// the other stream-ordered wire: direct peer copies into the neighbours' mailboxes (PeerWire.h); the mailbox of
@@ -76,6 +74,22 @@ class Halo : public Registry<Halo> {
    I4 exchangeFullArrayHalo(const Array1DReal &A, MeshElement E, hipStream_t S);
    /// One aggregated message per neighbour: [h on cells][u on edges][tracers on cells].
    I4 exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT, hipStream_t S);
+   /// Initialisation-time half of exchangeState for arrays of these shapes: builds the job tables and allocates the
+   /// message buffers, so that the exchanges inside a time step allocate nothing (the reference allocates its buffers
+   /// in the Halo constructor, Halo.cpp:92-134; here their size depends on what travels together).
+   /// globalSum of the reference (base/Reductions.h:71-88, 150-190: MPI_Allreduce with the double-double operator) for
+   /// NPairs (<= 64) local double-double partial sums at once: the ranks' (hi, lo) pairs are all-gathered over this
+   /// Halo's wire -- ncclAllGather on the RCCL communicator, PeerWire::allGather on the peer wire -- and combined in rank
+   /// order with the ddSum operator (combineDD), so every rank gets the same bits whatever the partition.  LocalPairs
+   /// [NPairs][2] and HiLo [NPairs][2] are host arrays; synchronises S.  Collective.  One rank: the combination alone.
+   /// Returns 0, or -1 (wireError() / the message of the OmegaError says why; a host-staged test transport has no
+   /// all-gather).
+   I4 globalSumDD(const double *LocalPairs, int NPairs, double *HiLo, hipStream_t S);
+   static constexpr int MaxSumPairs = 64;
+   void reserveState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT);
+   /// The wire's verdict after the host has synchronised with an exchange's stream: 0, or -1 when a peer-wire wait gave up
+   /// (wireError() then names it).  exchange*() can only report what is known when the work is QUEUED.
+   I4 checkWire() const;
 
  private:
    struct Piece {
@@ -98,12 +112,17 @@ class Halo : public Registry<Halo> {
    };
    const Plan &planFor(const std::vector<Piece> &Pieces);
    I4 exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S);
+   void unbindPeer();
+   void ensureWireResources();
    void ensureBuffers(size_t SendBytes, size_t RecvBytes);
 
    /// [neighbour][kind]: number of the NEIGHBOUR's halo elements of that kind owned by tasks below mine = rows (per
    /// array-per-element) that precede my message in its receive buffer.  Derived locally, like the lists.
    std::vector<std::array<size_t, 3>> PeerRecvPrefix;
    class PeerWire *Peer      = nullptr;
+   class RcclComm *Rccl      = nullptr;
+   Array1DReal GatherIn, GatherOut; ///< device scratch of globalSumDD: [2 * MaxSumPairs], [NumTasks][2 * MaxSumPairs]
+   std::string SumError;
    HaloTransportFn Transport = nullptr;
    void *TransportCtx        = nullptr;
    std::map<std::vector<int>, Plan> Plans; ///< keyed by (Elem, NT, RowsSize, K) of every piece

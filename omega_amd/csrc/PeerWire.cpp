@@ -22,10 +22,11 @@ PeerWire::PeerWire(int NRanks_, int Rank_, size_t MailboxBytes_)
    // uncached (fine-grained) device memory: written by peers through the fabric, read by local kernels
    HIP_CHECK(hipExtMallocWithFlags(&Mailbox, MailboxBytes, hipDeviceMallocUncached));
    void *F = nullptr;
-   HIP_CHECK(hipExtMallocWithFlags(&F, 2 * (size_t)NRanks * sizeof(unsigned long long), hipDeviceMallocUncached));
+   HIP_CHECK(hipExtMallocWithFlags(&F, flagWords() * sizeof(unsigned long long), hipDeviceMallocUncached));
+   noteDeviceResource(2);
    Flags = static_cast<unsigned long long *>(F);
    HIP_CHECK(hipMemset(Mailbox, 0, MailboxBytes));
-   HIP_CHECK(hipMemset(Flags, 0, 2 * (size_t)NRanks * sizeof(unsigned long long)));
+   HIP_CHECK(hipMemset(Flags, 0, flagWords() * sizeof(unsigned long long)));
    HIP_CHECK(hipStreamSynchronize(nullptr)); // the fills have run before any peer can see these buffers (Device.cpp)
    void *St = nullptr;
    HIP_CHECK(hipHostMalloc(&St, sizeof(int), hipHostMallocMapped));
@@ -128,14 +129,41 @@ int PeerWire::put(int N, const int *Peers, void *const *SendPtrs, const size_t *
    return 0;
 }
 
+int PeerWire::allGather(const void *In, int NVals, void *Out, hipStream_t S) {
+   auto Fail = [&](const std::string &Msg) {
+      LastError = Msg;
+      return 1;
+   };
+   if (!Connected)
+      return Fail("PeerWire: not connected");
+   if (NRanks > MaxRanksGather || NVals < 1 || NVals > MaxGatherVals)
+      return Fail("PeerWire::allGather: at most " + std::to_string(MaxRanksGather) + " ranks and " +
+                  std::to_string(MaxGatherVals) + " values per rank");
+   if (int St = status())
+      return Fail("PeerWire: an earlier exchange timed out waiting for a peer (status " + std::to_string(St) + ")");
+   PeerBlockPtrs B{};
+   for (int R = 0; R < NRanks; ++R)
+      B.P[R] = R == Rank ? Flags : PeerFlags[R];
+   launchPeerAllGather(B, NRanks, Rank, static_cast<const unsigned long long *>(In), NVals,
+                       static_cast<unsigned long long *>(Out), (unsigned long long)(NGathers + 1), Status, TimeoutTicks, S);
+   ++NGathers;
+   return 0;
+}
+
 int PeerWire::release(int N, const int *Peers, hipStream_t S) {
    if (N < 0 || N > MaxPeers) {
       LastError = "PeerWire: too many neighbours in one exchange";
       return 1;
    }
    PeerFlagPtrs ConsumedAt{};
-   for (int I = 0; I < N; ++I)
-      ConsumedAt.P[I] = PeerFlags[Peers[I]] + NRanks + Rank; // consumed[me] in the peer's block
+   for (int I = 0; I < N; ++I) {
+      const int P = Peers[I];
+      if (!Connected || P < 0 || P >= NRanks || P == Rank || !PeerFlags[P]) {
+         LastError = "PeerWire: bad peer rank";
+         return 1;
+      }
+      ConsumedAt.P[I] = PeerFlags[P] + NRanks + Rank; // consumed[me] in the peer's block
+   }
    ConsumedAt.N = N;
    PeerFlagIdx None{};
    launchPeerSignalWait(ConsumedAt, (unsigned long long)NExchanges, Flags, None, false, Status, 0, TimeoutTicks, S);

@@ -29,6 +29,8 @@ namespace OMEGA {
 class PeerWire {
  public:
    static constexpr int MaxPeers    = 32;  ///< neighbours of one rank in one exchange
+   static constexpr int MaxRanksGather = 64;  ///< ranks an allGather spans (one lane each)
+   static constexpr int MaxGatherVals  = 128; ///< 8-byte values per rank in one allGather (64 double-double pairs)
    static constexpr int HandleBytes = 160; ///< two hipIpcMemHandle_t (64 B each) + sizes
 
    /// The calling process must already have selected its GPU (deviceInit).  MailboxBytes: capacity of this rank's
@@ -61,8 +63,23 @@ class PeerWire {
    /// Step 6: the mailbox has been read (unpack kernel queued on S before this call): tell the neighbours.
    int release(int N, const int *Peers, hipStream_t S);
 
-   /// 0, or the sticky failure raised by a wait kernel that gave up (bit 0: "consumed" wait, bit 1: "arrived" wait)
+   /// All-gather of NVals (<= MaxGatherVals) 8-byte values per rank over ALL ranks of the wire (not only the halo
+   /// neighbours): In[NVals] -> Out[NRanks][NVals], both local device memory, on stream S; one one-wavefront kernel, lane
+   /// r writes this rank's values into rank r's gather slots (system-scope stores, then a release store of the gather's
+   /// sequence number), waits for rank r's sequence number in the local block and copies its values out.  Slots are
+   /// double-buffered by the parity of the sequence number: a rank can only be one gather ahead of any other (it needs
+   /// everybody's values to finish one).  Collective; gathers must be issued in the same order on every rank and
+   /// stream-ordered among themselves.  The reductions' wire (Reductions.h:71-88: MPI_Allreduce there).
+   int allGather(const void *In, int NVals, void *Out, hipStream_t S);
+   I8 NGathers = 0;
+
+   /// 0, or the sticky failure raised by a wait kernel that gave up (bit 0: "consumed" wait, bit 1: "arrived" wait).
+   /// Once it is raised the unpack kernel of that exchange and of every later one copies nothing and no "consumed"
+   /// signal leaves this rank (the neighbours' next exchange then gives up too: the failure spreads instead of a state
+   /// with stale halos); the host sees it here after synchronising with the exchange's stream, and the next put() fails.
    int status() const;
+   /// the status word as kernels read it (pinned host memory)
+   const int *statusWord() const { return Status; }
    const std::string &lastError() const { return LastError; }
    /// how long a wait kernel spins before it gives up [s] (default 60)
    void setTimeout(double Seconds);
@@ -70,7 +87,10 @@ class PeerWire {
  private:
    size_t MailboxBytes;
    void *Mailbox = nullptr;
-   unsigned long long *Flags = nullptr; ///< [2 * NRanks]: arrived[r], consumed[r] written by rank r
+   /// [2 * NRanks]: arrived[r], consumed[r] written by rank r; then [NRanks] gather sequence numbers and
+   /// [2][NRanks][MaxGatherVals] gather slots (allGather)
+   unsigned long long *Flags = nullptr;
+   size_t flagWords() const { return (size_t)NRanks * (3 + 2 * (size_t)MaxGatherVals); }
    int *Status               = nullptr; ///< pinned host word the wait kernels raise
    bool Connected            = false;
    long long TimeoutTicks;
@@ -92,7 +112,14 @@ struct PeerFlagIdx {
 /// wait until Local[Idx.I[i]] >= Seq for every i (bounded; raises *Status |= Bit on timeout)
 void launchPeerWait(const unsigned long long *Local, const PeerFlagIdx &Idx, unsigned long long Seq, int *Status, int Bit,
                     long long TimeoutTicks, hipStream_t S);
-/// *Remote.P[i] = Seq (system-scope release), then optionally wait as above
+struct PeerBlockPtrs {
+   unsigned long long *P[PeerWire::MaxRanksGather]; ///< every rank's flag block as mapped here ([Rank]: the local one)
+};
+void launchPeerAllGather(const PeerBlockPtrs &Blocks, int NRanks, int Rank, const unsigned long long *In, int NVals,
+                         unsigned long long *Out, unsigned long long Seq, int *Status, long long TimeoutTicks,
+                         hipStream_t S);
+/// *Remote.P[i] = Seq (system-scope release), then optionally wait as above.  Wait == false (the "consumed" signal after
+/// the unpack kernel): nothing is signalled if *Status is already raised.
 void launchPeerSignalWait(const PeerFlagPtrs &Remote, unsigned long long Seq, const unsigned long long *Local,
                           const PeerFlagIdx &Idx, bool Wait, int *Status, int Bit, long long TimeoutTicks, hipStream_t S);
 

@@ -92,6 +92,20 @@ int RcclComm::exchange(int N, const int *Peers, void *const *SendPtrs, const siz
    return 0;
 }
 
+int RcclComm::allGather(const void *Send, void *Recv, size_t BytesPerRank, hipStream_t S) {
+   if (Failed || !Comm) {
+      LastError = "RcclComm::allGather: the communicator was aborted after an earlier error (" + LastError + ")";
+      return 1;
+   }
+   const ncclResult_t R = ncclAllGather(Send, Recv, BytesPerRank, ncclInt8, static_cast<ncclComm_t>(Comm), S);
+   if (R != ncclSuccess) {
+      LastError = std::string("ncclAllGather: ") + ncclGetErrorString(R);
+      abort();
+      return 1;
+   }
+   return 0;
+}
+
 int RcclComm::transport(void *Ctx, int NNghbr, const int *Tasks, void *const *SendPtrs, const size_t *SendBytes,
                         void *const *RecvPtrs, const size_t *RecvBytes, void *Stream) {
    return static_cast<RcclComm *>(Ctx)->exchange(NNghbr, Tasks, SendPtrs, SendBytes, RecvPtrs, RecvBytes,

@@ -35,6 +35,8 @@ class RcclComm {
    /// Returns 0, or a non-zero code with the RCCL error string in lastError().
    int exchange(int N, const int *Peers, void *const *SendPtrs, const size_t *SendBytes, void *const *RecvPtrs,
                 const size_t *RecvBytes, hipStream_t S);
+   /// ncclAllGather of BytesPerRank bytes from every rank on stream S: Recv[NRanks][BytesPerRank] (device memory)
+   int allGather(const void *Send, void *Recv, size_t BytesPerRank, hipStream_t S);
    const std::string &lastError() const { return LastError; }
    /// ncclCommAbort: after any error, or when the job decides not to use this communicator (e.g. another rank could
    /// not create its own).  Every later exchange returns an error.

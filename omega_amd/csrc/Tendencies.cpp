@@ -10,6 +10,9 @@ Tendencies::Tendencies(const std::string &, const HorzMesh *Mesh_, int K, int NT
    LayerThicknessTend = Array2DReal::levels("LayerThicknessTend", Mesh->NCellsSize, K);
    NormalVelocityTend = Array2DReal::levels("NormalVelocityTend", Mesh->NEdgesSize, K);
    TracerTend         = Array3DReal::levels("TracerTend", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+   // the running PV sums of the fused RHS: allocated here, not at the first evaluation (no allocation inside a step)
+   if (fusedRHSSupported(Mesh->view(), K))
+      EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, K);
 }
 
 Tendencies::~Tendencies() {
@@ -130,8 +133,6 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
    Array2DReal LayerThick, NormVel;
    OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 && State->getNormalVelocity(NormVel, VelLvl) == 0,
                  "Tendencies: bad time level");
-   if (!EdgeScratch.Ptr)
-      EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
    return launchFusedRHS(Mesh->view(), NVertLayers, NTracers, paramsFor(Aux), Aux->ptrs(), LayerThicknessTend.Ptr,
                          NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, nullptr,
                          EdgeScratch.Ptr, &Stage, Mesh->narrowView());
@@ -152,8 +153,6 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
       OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 &&
                         State->getNormalVelocity(NormVel, VelLvl) == 0,
                     "Tendencies: bad time level");
-      if (!EdgeScratch.Ptr)
-         EdgeScratch = Array2DReal::levels("EdgeScratch", Mesh->NEdgesSize, NVertLayers);
       hipEvent_t *Ev = nullptr;
       if (TimingOn && TimingEvents.size() < 4096) {
          TimingEvents.emplace_back(FusedNumKernels + 1);

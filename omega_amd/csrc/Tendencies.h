@@ -1,8 +1,9 @@
 // Tendencies.h -- RHS tendencies of layer thickness, normal velocity and tracers.
 // Interface after the reference (components/omega/src/ocn/Tendencies.h:73-144;
 // Tendencies.cpp:217-600).  The `TimeInstant` argument of the reference is only forwarded
-// to custom-tendency hooks (Tendencies.cpp:288-293), which are out of scope here, so the
-// methods take the stream instead.
+// to the custom-tendency hooks (Tendencies.cpp:288-293): here the methods take the stream
+// instead, and the hooks (CustomThicknessTend / CustomVelocityTend below) receive the model
+// time as `ModelTime` seconds, which the time steppers set for every stage.
 #ifndef OMEGA_AMD_TENDENCIES_H
 #define OMEGA_AMD_TENDENCIES_H
 
@@ -80,7 +81,7 @@ class Tendencies : public Registry<Tendencies> {
    bool MaterialiseAuxForCustom = true;
 
  private:
-   Array2DReal EdgeScratch; ///< running PV sums of the fused RHS (allocated on first use)
+   Array2DReal EdgeScratch; ///< running PV sums of the fused RHS (allocated by the constructor)
    bool TimingOn = false;
    bool WarnedUnfused = false;
    std::vector<std::vector<hipEvent_t>> TimingEvents;

@@ -160,6 +160,12 @@ void TimeStepper::attachData(Tendencies *T, AuxiliaryState *A, const HorzMesh *M
    Trc      = Tr;
 }
 
+void TimeStepper::finalizeInit() {
+   if (MeshHalo && MeshHalo->NNghbr > 0 && Tend)
+      MeshHalo->reserveState(Tend->LayerThicknessTend, Tend->NormalVelocityTend, Tend->NTracers > 0 ? &Tend->TracerTend : nullptr,
+                             Tend->NTracers);
+}
+
 // ---- update kernels ----
 void TimeStepper::updateThicknessByTend(OceanState *S1, int L1, OceanState *S2, int L2, R8 C, hipStream_t S) const {
    Array2DReal H1, H2;
@@ -202,6 +208,11 @@ void TimeStepper::finalizeTracersUpdate(const Array3DReal &Next, OceanState *St,
    launchFinalizeTracers(Trc ? Trc->NTracers : 0, Mesh->NCellsAll, Mesh->NCellsSize, H.Pitch, Next.Ptr, H.Ptr, S);
 }
 
+void TimeStepper::requireHealthyWire() const {
+   OMEGA_REQUIRE(!MeshHalo || MeshHalo->checkWire() == 0,
+                 "TimeStepper: a halo exchange of an earlier step failed" + MeshHalo->wireError());
+}
+
 void TimeStepper::updateTimeLevels(OceanState *State, hipStream_t S) const {
    if (MeshHalo && MeshHalo->NNghbr > 0) {
       Array2DReal H, U;
@@ -226,6 +237,7 @@ void TimeStepper::updateTimeLevels(OceanState *State, hipStream_t S) const {
 
 // ---- ForwardBackwardStepper::doStep (ForwardBackwardStepper.cpp:27-82) ----
 void ForwardBackwardStepper::doStep(OceanState *State, hipStream_t S) {
+   requireHealthyWire();
    const int CurLevel = 0, NextLevel = 1;
    Array3DReal CurTracerArray, NextTracerArray;
    OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
@@ -249,6 +261,7 @@ void ForwardBackwardStepper::doStep(OceanState *State, hipStream_t S) {
 
 // ---- RungeKutta2Stepper::doStep (RungeKutta2Stepper.cpp:27-73) ----
 void RungeKutta2Stepper::doStep(OceanState *State, hipStream_t S) {
+   requireHealthyWire();
    const int CurLevel = 0, NextLevel = 1;
    Array3DReal CurTracerArray, NextTracerArray;
    OMEGA_REQUIRE(Trc->getAll(CurTracerArray, CurLevel) == 0 && Trc->getAll(NextTracerArray, NextLevel) == 0,
@@ -278,8 +291,17 @@ RungeKutta4Stepper::RungeKutta4Stepper(const std::string &Name, R8 Dt)
 void RungeKutta4Stepper::finalizeInit() {
    OMEGA_REQUIRE(Tend && Mesh && Trc, "RungeKutta4Stepper: attachData before finalizeInit");
    const int K = Tend->LayerThicknessTend.Ext[1];
+   const int NT = Trc->NTracers;
    ProvisState.reset(new OceanState("Provis" + Name, Mesh, MeshHalo, K, 1)); // 1 time level (:56-60)
-   ProvisTracers = Array3DReal::levels("ProvisTracers", Trc->NTracers > 0 ? Trc->NTracers : 1, Mesh->NCellsSize, K);
+   ProvisTracers = Array3DReal::levels("ProvisTracers", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+   // Everything a step needs is created here, as the reference does (RungeKutta4Stepper.cpp:43-64), never inside doStep:
+   // the second provisional buffer of the stage-fused form, and with neighbours the communication stream, its events and
+   // the halo's job tables and message buffers for the state exchange (h + u + tracers in one message per neighbour).
+   ProvisState2.reset(new OceanState("Provis2" + Name, Mesh, MeshHalo, K, 1));
+   ProvisTracers2 = Array3DReal::levels("ProvisTracers2", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
+   if (MeshHalo && MeshHalo->NNghbr > 0)
+      ensureCommStream();
+   TimeStepper::finalizeInit();
 }
 
 // The same scheme with every stage's updates applied in the epilogue of the kernels that produce
@@ -316,6 +338,7 @@ void RungeKutta4Stepper::ensureCommStream() {
    HIP_CHECK(hipEventCreateWithFlags(&EvBand, hipEventDisableTiming));
    HIP_CHECK(hipEventCreateWithFlags(&EvDone, hipEventDisableTiming));
    HIP_CHECK(hipEventCreateWithFlags(&EvFork, hipEventDisableTiming));
+   noteDeviceResource(4);
 }
 void RungeKutta4Stepper::startExchange(const ExchangeJob &Job) {
    ensureCommStream();
@@ -337,10 +360,7 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
    const int CurLevel = 0, NextLevel = 1;
    const int NT = Trc->NTracers;
    const int K  = Tend->LayerThicknessTend.Ext[1];
-   if (!ProvisState2) {
-      ProvisState2.reset(new OceanState("Provis2" + Name, Mesh, MeshHalo, K, 1));
-      ProvisTracers2 = Array3DReal::levels("ProvisTracers2", NT > 0 ? NT : 1, Mesh->NCellsSize, K);
-   }
+   (void)K;
    Array3DReal NextTr, CurTr;
    Array2DReal CurH, CurU, NextH, NextU;
    OMEGA_REQUIRE(Trc->getAll(CurTr, CurLevel) == 0 && Trc->getAll(NextTr, NextLevel) == 0,
@@ -449,6 +469,7 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
 void RungeKutta4Stepper::doStep(OceanState *State, hipStream_t S) {
    if (!ProvisState)
       finalizeInit();
+   requireHealthyWire();
    if (FuseStageUpdates && doStepFused(State, S))
       return;
    const int CurLevel = 0, NextLevel = 1;

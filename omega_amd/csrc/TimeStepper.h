@@ -37,7 +37,9 @@ class TimeStepper {
 
    /// attach the objects the scheme works on (TimeStepper::attachData)
    void attachData(Tendencies *Tend, AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, Tracers *Trc);
-   virtual void finalizeInit() {}
+   /// after attachData: creates whatever a step needs, so that doStep allocates nothing (base: the halo's job tables
+   /// and message buffers for the end-of-step exchange of h, u and the tracers)
+   virtual void finalizeInit();
 
    /// advance State (and the attached Tracers) by one step on stream S
    virtual void doStep(OceanState *State, hipStream_t S) = 0;
@@ -82,6 +84,9 @@ class TimeStepper {
    /// end-of-step: halo exchange of the new level, then rotate (State->updateTimeLevels();
    /// Tracers::updateTimeLevels()) -- h, u and tracers travel in one message per neighbour
    void updateTimeLevels(OceanState *State, hipStream_t S) const;
+   /// first thing in every doStep: a peer-wire wait of an EARLIER step that gave up is reported now (the status word is
+   /// host memory: no synchronisation); the halo of that step was left untouched and the state is not to be trusted
+   void requireHealthyWire() const;
    Tendencies *Tend         = nullptr;
    AuxiliaryState *AuxState = nullptr;
    const HorzMesh *Mesh     = nullptr;

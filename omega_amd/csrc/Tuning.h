@@ -36,6 +36,8 @@ struct TuningOptions {
    int KeepMaxEdges = 0; ///< keep the mesh file's maxEdges as the table width
    int DomValence   = 1; ///< full sweeps at the valence most cells have
    int NarrowTables = 1; ///< hexagon-dominant meshes with heptagons: second, MaxEdges-1 wide set of cell tables
+   // ---- local numbering (read when a Decomp is constructed with a curve order)
+   int WaveWindow = 0; ///< >= 16: cells regrouped inside windows of this many consecutive cells so that a wave's 8 cells finish the same edge slots (Decomp.h)
    // ---- HIP-graph replay: -1 = as each object's UseGraphs says, 0 = never, 1 = default on
    int Graphs = -1;
 };

@@ -159,6 +159,12 @@ int omg_event_elapsed_ms(void *start, void *stop, float *ms) {
 }
 
 // ---------------------------------------------------------------- raw device buffers
+int omg_device_resource_count(int64_t *n) {
+   OMG_TRY
+   OMG_ARG(n);
+   *n = deviceResourceCount();
+   OMG_CATCH
+}
 int omg_device_malloc(size_t bytes, void **ptr) {
    OMG_TRY
    OMG_ARG(ptr);
@@ -352,7 +358,7 @@ int omg_decomp_create(const omg_global_mesh *m, int nparts, int mytask, int halo
 int omg_decomp_create_ordered(const omg_global_mesh *mesh, int nparts, int mytask, int halo_width,
                               const int32_t *cell_task, int local_order, omg_decomp **out) {
    OMG_TRY
-   OMG_ARG(mesh && out && local_order >= 0 && local_order <= 2);
+   OMG_ARG(mesh && out && local_order >= 0 && local_order <= 3);
    auto *R = new omg_decomp;
    try {
       R->D.reset(new Decomp(toDesc(*mesh), nparts, mytask, halo_width, cell_task, (LocalOrder)local_order));
@@ -654,6 +660,20 @@ int omg_halo_exchange_bytes(omg_halo *h, void *dev_array, int elem_bytes, int nt
 int omg_halo_exchange_i4(omg_halo *h, int32_t *dev_array, int nt, int rows_size, int k, int row_pitch, int elem,
                          void *stream) {
    return omg_halo_exchange_bytes(h, dev_array, 4, nt, rows_size, k, row_pitch, elem, stream);
+}
+int omg_halo_global_sum_dd(omg_halo *h, const double *local_hi_lo, int npairs, double *hi_lo, void *stream) {
+   OMG_TRY
+   OMG_ARG(h && local_hi_lo && hi_lo && npairs >= 0);
+   if (h->H->globalSumDD(local_hi_lo, npairs, hi_lo, (hipStream_t)stream) != 0)
+      OMEGA_ABORT("Halo::globalSumDD failed" + h->H->wireError());
+   OMG_CATCH
+}
+int omg_halo_check(const omg_halo *h) {
+   OMG_TRY
+   OMG_ARG(h);
+   if (h->H->checkWire() != 0)
+      OMEGA_ABORT("Halo: the wire reports a failed exchange" + h->H->wireError());
+   OMG_CATCH
 }
 
 // ---------------------------------------------------------------- HorzMesh

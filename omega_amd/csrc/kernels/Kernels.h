@@ -174,8 +174,9 @@ struct HaloBases {
 /// (buffer rows are compact, K values of ElemBytes (4: I4 / R4, 8: R8 / I8) bytes each; array rows have pitch Pitch values)
 void launchHaloPackAll(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
                        hipStream_t S);
+/// SkipIfSet: optional device-readable status word (PeerWire); if it is non-zero when the kernel runs nothing is unpacked
 void launchHaloUnpackAll(const HaloBases &B, const void *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch,
-                         int ElemBytes, hipStream_t S);
+                         int ElemBytes, hipStream_t S, const int *SkipIfSet = nullptr);
 
 } // namespace OMEGA
 #endif

@@ -432,8 +432,12 @@ void launchFinalizeTracers(int NT, int NRows, int RowsSize, int K, Real *NextTr,
 // plane stack of piece Jobs[2j].  threadIdx.x walks the level chunks of a row (coalesced on both sides),
 // threadIdx.y the rows of the workgroup.
 template <class T, bool Pack> __global__ void __launch_bounds__(256)
-haloCopyAllKernel(T *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int Pitch) {
+haloCopyAllKernel(T *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int Pitch, const int *Skip) {
    // (KV, Pitch: row length / row pitch in units of T)
+   // Skip (unpack over the peer wire): the wire's status word; non-zero = a wait for a neighbour's message gave up, the
+   // mailbox holds a stale or partial message -- the halo is left as it was and the host learns it from the status
+   if (Skip && *reinterpret_cast<const volatile int *>(Skip) != 0)
+      return;
    for (size_t J = (size_t)blockIdx.x * blockDim.y + threadIdx.y; J < NRows; J += (size_t)gridDim.x * blockDim.y) {
       const int Piece  = Jobs[2 * J];
       const size_t Row = (size_t)(unsigned)Jobs[2 * J + 1];
@@ -448,7 +452,8 @@ haloCopyAllKernel(T *Buf, HaloBases B, const I4 *Jobs, size_t NRows, int KV, int
    }
 }
 template <class T, bool Pack>
-static void launchHaloCopyT(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int KV, int Pitch, hipStream_t S) {
+static void launchHaloCopyT(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int KV, int Pitch, hipStream_t S,
+                            const int *Skip) {
    int TX = 1;
    while (TX < KV && TX < 64)
       TX *= 2;
@@ -457,30 +462,30 @@ static void launchHaloCopyT(void *Buf, const HaloBases &B, const I4 *Jobs, size_
    if (Blocks > 8192)
       Blocks = 8192;
    hipLaunchKernelGGL((haloCopyAllKernel<T, Pack>), dim3((unsigned)Blocks), dim3(TX, TY), 0, S, static_cast<T *>(Buf), B,
-                      Jobs, NRows, KV, Pitch);
+                      Jobs, NRows, KV, Pitch, Skip);
    HIP_CHECK(hipGetLastError());
 }
 template <bool Pack>
 static void launchHaloCopyAll(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
-                              hipStream_t S) {
+                              hipStream_t S, const int *Skip = nullptr) {
    if (NRows == 0)
       return;
    // the widest unit that divides both the row length and the row pitch: 16, 8 or 4 bytes
    const size_t RowB = (size_t)K * ElemBytes, PitchB = (size_t)Pitch * ElemBytes;
    if (RowB % 16 == 0 && PitchB % 16 == 0)
-      launchHaloCopyT<dv2, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 16), (int)(PitchB / 16), S);
+      launchHaloCopyT<dv2, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 16), (int)(PitchB / 16), S, Skip);
    else if (RowB % 8 == 0 && PitchB % 8 == 0)
-      launchHaloCopyT<double, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 8), (int)(PitchB / 8), S);
+      launchHaloCopyT<double, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 8), (int)(PitchB / 8), S, Skip);
    else
-      launchHaloCopyT<int, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 4), (int)(PitchB / 4), S);
+      launchHaloCopyT<int, Pack>(Buf, B, Jobs, NRows, (int)(RowB / 4), (int)(PitchB / 4), S, Skip);
 }
 void launchHaloPackAll(void *Buf, const HaloBases &B, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
                        hipStream_t S) {
    launchHaloCopyAll<true>(Buf, B, Jobs, NRows, K, Pitch, ElemBytes, S);
 }
 void launchHaloUnpackAll(const HaloBases &B, const void *Buf, const I4 *Jobs, size_t NRows, int K, int Pitch, int ElemBytes,
-                         hipStream_t S) {
-   launchHaloCopyAll<false>(const_cast<void *>(Buf), B, Jobs, NRows, K, Pitch, ElemBytes, S);
+                         hipStream_t S, const int *SkipIfSet) {
+   launchHaloCopyAll<false>(const_cast<void *>(Buf), B, Jobs, NRows, K, Pitch, ElemBytes, S, SkipIfSet);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""Halo wires for test rigs.
+"""Halo wire for test rigs (test infrastructure: not part of the omega_amd package).
 
 The production wire is inside the library: `omega_amd.RcclComm` + `Halo.use_rccl` (omega_amd/csrc/Rccl.cpp:
 grouped ncclSend / ncclRecv over xGMI on the exchange's HIP stream, no Python on the path).

@@ -1,6 +1,6 @@
 """2-rank run of the full product path on the GPU: C++ Decomp / Halo with HIP pack / unpack
 kernels, RungeKutta4Stepper::doStep with its two exchange points, one process per rank, both on
-GPU 0 (this pool's test boxes have one GPU), messages staged through gloo (omega_amd/transport.py
+GPU 0 (this pool's test boxes have one GPU), messages staged through gloo (tests/gloo_transport.py
 test mode).  Must reproduce the single-rank CPU oracle bit for bit on owned elements.
 
 The ranks (and the re-runs of the parity suite under other kernel structures) are fresh child processes; nothing in

@@ -457,10 +457,10 @@ def test_hip_graph_replay_matches_the_oracle():
     check("u", u, ost["u"][0], m.NEdgesOwned)
 
 
-@pytest.mark.parametrize("order", ["curve", "hilbert"])
+@pytest.mark.parametrize("order", ["curve", "hilbert", "kd"])
 @pytest.mark.parametrize("mesh", ["hex", "ico3"])
 def test_curve_ordered_local_numbering(mesh, order):
-    """Decomp with LocalOrder::Curve / Hilbert on a row-major (unordered) input mesh: another local numbering, the same
+    """Decomp with LocalOrder::Curve / Hilbert / KdTree on a row-major (unordered) input mesh: another local numbering, the same
     results per global id -- fused RHS and an RK4 step against the oracle running on the product's own local arrays."""
     g = planar_hex(40, 24, 30e3) if mesh == "hex" else sphere("ico3")
     P = Problem(g, 12, 2, local_order=order)

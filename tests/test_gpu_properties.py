@@ -148,3 +148,31 @@ def test_arrays_allocated_right_before_their_first_use_on_a_non_blocking_stream(
         for a, b in zip(first, again):
             assert np.array_equal(a, b)
         del tend
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "stage-fused", "graphs", "rk2", "fb"])
+def test_no_device_resource_is_created_inside_a_step(mode):
+    """The reference allocates a stepper's provisional state in finalizeInit (RungeKutta4Stepper.cpp:43-64).  Here the
+    constructors / omg_stepper_create create everything a step uses -- the second provisional buffer of the stage-fused
+    form, the PV scratch of the fused RHS: the library's resource counter does not move across doStep 1..3 (the overlapped
+    multi-rank form is checked in tests/mp_worker.py, where the communication stream, its events and the halo's message
+    buffers join the list)."""
+    oa.device_init(0)
+    P = Problem(planar_hex(24, 20, 30.0e3), 8, 2, oracle=False)
+    kind = {"rk2": "RungeKutta2", "fb": "Forward-Backward"}.get(mode, "RungeKutta4")
+    st = oa.TimeStepper(kind, 300.0, P.tend, P.aux, P.mesh, None, P.tracers)
+    stream = None
+    if kind == "RungeKutta4":
+        st.set_option("FuseStageUpdates", mode != "plain")
+        if mode == "graphs":
+            st.set_option("UseGraphs", True)
+            stream = oa.Stream()
+    n0 = oa.device_resource_count()
+    assert n0 > 0
+    for _ in range(3):
+        st.do_step(P.state, stream=stream)
+    oa.device_synchronize()
+    assert oa.device_resource_count() == n0
+    h, _ = P.state.copy_to_host(0)
+    assert np.isfinite(h[: P.mesh.NCellsOwned]).all()

@@ -61,6 +61,7 @@ def run_ranks(mode, world, extra=(), timeout=600):
     (3, ["--halo-width", 4, "--nx", 24, "--ny", 24, "--local-order", "curve"]),  # local numbering along a Morton curve
     (3, ["--no-del4", "--mesh", "ico3", "--levels", 3, "--partition", "graph"]),   # built-in graph partitioner
     (3, ["--halo-width", 4, "--mesh", "ico4", "--levels", 3, "--partition", "graph", "--local-order", "curve"]),
+    (3, ["--halo-width", 4, "--mesh", "ico4", "--levels", 3, "--partition", "graph", "--local-order", "kd"]),  # k-d order
 ])
 def test_partitioned_oracle_matches_single_rank(world, extra):
     outs = run_ranks("cpu", world, extra)
@@ -120,7 +121,7 @@ def test_decomp_every_element_owned_once(nparts):
     assert np.array_equal(tot, n * (n + 1) // 2)
 
 
-@pytest.mark.parametrize("order", ["curve", "hilbert"])
+@pytest.mark.parametrize("order", ["curve", "hilbert", "kd"])
 @pytest.mark.parametrize("nparts", [1, 3, 8])
 def test_curve_ordered_decomp_owns_every_element_once_and_is_compact(nparts, order):
     """LocalOrder::Curve / Hilbert: same element sets per rank and layer as the reference numbering, ordered along a
@@ -145,7 +146,11 @@ def test_curve_ordered_decomp_owns_every_element_once_and_is_compact(nparts, ord
             own = cid[: d.get_int("NCellsOwned")] - 1
             x, y = own % nx, own // nx
             step = np.abs(np.diff(x)) + np.abs(np.diff(y))
-            assert np.median(step) <= 2 and step.mean() < (4.0 if order == "curve" else 1.5)
+            assert np.median(step) <= 2 and step.mean() < (4.0 if order in ("curve", "kd") else 1.5)
+        if order == "kd" and nparts == 1:   # every aligned run of 16 cells is a compact patch: it fits a 5 x 5 box
+            for t in range(0, d.get_int("NCellsOwned") - 15, 16):
+                c = cid[t: t + 16] - 1
+                assert np.ptp(c % nx) <= 4 and np.ptp(c // nx) <= 4, (t, c)
     n = np.array([g["nCells"], g["nEdges"], g["nVertices"]], dtype=np.int64)
     assert np.array_equal(tot, n * (n + 1) // 2)
 
