@@ -13,7 +13,7 @@ is partitioned N ways (strong scaling) and halos travel as RCCL send/recv over x
 A "step" is one full RHS evaluation over the whole mesh (all N ranks).  The JSON line also
 carries `sypd` (RK4 steps, halo exchanges included), `roofline` (dominant kernel, live HIP
 events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a
-bounded sample of the same workload on the host cores).
+the same full mesh -- a bounded number of evaluations -- on the host cores).
 """
 import argparse
 import json
@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import omega_amd as oa  # noqa: E402
 oa.lib()   # load libomega_amd.so (and with it ROCm's own libamdhip64 / librccl) before anything imports torch
 from omega_amd.meshgen import (icosahedral_points, planar_hex, reorder_cells_blocked, reorder_cells_morton,  # noqa: E402
-                               spherical_voronoi, synthetic_state)
+                               spherical_voronoi, synthetic_state, synthetic_state_rows)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -50,6 +50,9 @@ WORKLOADS = {
     "ico6": (0, 6, 0.0, 60, 2, "spherical icosahedral Voronoi mesh, 40962 cells (12 pentagons), 60L, 2 tracers"),
     "ico5": (0, 5, 0.0, 60, 2, "QU240-sized ON THE SPHERE: icosahedral Voronoi mesh, 10242 cells (12 pentagons), 60L, 2 tracers"),
     "small": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96, 80L, 6 tracers"),
+    "orrs18to6": (1924, 1924, 6.0e3, 80, 37,
+                  "oRRS18to6-sized planar periodic hex mesh 1924x1924 (3701776 cells), 80L, 37 tracers -- BASELINE configs[4]; "
+                  "needs 8 GPUs (59 GB of arrays per rank)"),
     "hex405": (404, 406, 49.0e3, 80, 6, "planar periodic hex mesh of the size of ico7 / fib7 (404x406 = 164024 cells; the "
                                         "periodic generator needs an even row count), 80L, 6 tracers: the planar reference of the "
                                         "spherical workloads"),
@@ -174,6 +177,9 @@ def main():
     N = world
 
     nx, ny, dc, K, NT, desc = WORKLOADS[args.workload]
+    if args.workload == "orrs18to6" and N < 8:
+        raise SystemExit("--workload orrs18to6 is BASELINE configs[4] (3.7 M cells x 80 levels x 37 tracers: ~470 GB of arrays): "
+                         "run it with --gpus 8; its per-GPU share on one GPU is --workload orrs18to6_eighth")
     if args.dt <= 0:
         ncell_sphere = -ny if ny < 0 else 10 * 4 ** ny + 2
         cell = dc if dc > 0 else (4.0 * np.pi * 6371.22e3 ** 2 / ncell_sphere) ** 0.5   # sphere: mean spacing
@@ -229,20 +235,34 @@ def main():
     mesh = oa.HorzMesh(decomp, K)
     halo = oa.Halo(decomp) if N > 1 else None
     cell_id, edge_id = decomp.get_array("CellID"), decomp.get_array("EdgeID")
-    hg, ug, trg = synthetic_state(g, K, NT)
-    if "boundaryEdge" in g:     # an ocean state: no normal flow through the coast
-        from omega_amd.meshgen import zero_boundary_velocity
-        ug = zero_boundary_velocity(g, ug)
+    # The state is synthesised PER RANK: the rows of this rank's local elements only, each value a function of (global
+    # id, level) alone (meshgen.synthetic_state_rows), so that no rank ever holds a global [nCells, K] array -- 88 GB for
+    # configs[4] -- and an N = 1 and an N = 8 run still start from the same bits (rk4.state_checksums_after_2_steps is the
+    # check).  The reference initialises per task too (components/omega/src/ocn/OceanState.cpp:65-117).
+    cells0, edges0 = cell_id[: mesh.NCellsAll] - 1, edge_id[: mesh.NEdgesAll] - 1
+    kp = oa.level_pitch(K)
 
-    def to_local(glob, ids, rows):
-        out = np.zeros(glob.shape[:-2] + (rows, glob.shape[-1]))
-        out[..., : rows - 1, :] = glob[..., ids[: rows - 1] - 1, :]
+    def local_rows(a2d, rows):      # [n, K] -> [rows, K] with the zero sentinel row(s) behind
+        out = np.zeros((rows, a2d.shape[1]))
+        out[: a2d.shape[0]] = a2d
         return out
 
-    h = to_local(hg, cell_id, mesh.NCellsSize)
-    u = to_local(ug, edge_id, mesh.NEdgesSize)
-    tr = to_local(trg, cell_id, mesh.NCellsSize)
-    del hg, ug, trg
+    def make_hu():
+        hh, uu, _ = synthetic_state_rows(g, K, 0, cells0, edges0, tracers=[])
+        if "boundaryEdge" in g:     # an ocean state: no normal flow through the coast
+            uu[np.asarray(g["boundaryEdge"])[edges0] != 0] = 0.0
+        return local_rows(hh, mesh.NCellsSize), local_rows(uu, mesh.NEdgesSize)
+
+    def upload_tracers(trc):
+        """one tracer at a time (a rank's 37 tracers of configs[4] are 11 GB: never as one host array)"""
+        base = trc.device_ptr(0)
+        for l in range(NT):
+            t2 = synthetic_state_rows(g, K, NT, cells0, edges0[:0], tracers=[l])[2][0]
+            buf = np.zeros((mesh.NCellsSize, kp))
+            buf[: t2.shape[0], :K] = t2
+            oa.copy_to_device(base + 8 * l * mesh.NCellsSize * kp, buf)
+
+    h, u = make_hu()
 
     comm = None
     wire_note = None
@@ -258,7 +278,7 @@ def main():
     tend = oa.Tendencies(mesh, K, NT, cfg)
     tend.set_fused(not args.unfused)
     state.copy_to_device(h, u, 0)
-    tracers.copy_to_device(tr, 0)
+    upload_tracers(tracers)
     setup_s = time.time() - t0
 
     def barrier():
@@ -391,6 +411,11 @@ def main():
         out = {"metric": "tendency_cell_level_updates_per_sec", "value": value, "unit": "cell-level-updates/s",
                "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "scaling_note": "value = RHS evaluations of the whole (N-way partitioned) mesh, every rank sweeping its owned + halo "
+                               "cells, WITHOUT a halo exchange inside the timed loop (a tendency evaluation has none; "
+                               "config.rhs_excludes_halo_exchange); the strong-scaling figure that includes the two exchanges of "
+                               "a step is rk4.cell_level_updates_per_sec (= cells x levels x 4 evaluations / rk4.ms_per_step) "
+                               "and sypd",
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
@@ -403,6 +428,7 @@ def main():
                            ((wire_note + (" " + json.dumps(wire.info()) if wire else "")) if wire_note else
                             "none: " + "; ".join(wire_errors or ["?"])[:300])),
                           "halo_wire_check": wire_check,
+                          "rhs_excludes_halo_exchange": True,
                           "partition_independent": bool(N == 1 or halo_width >= 4), "mesh_order": "input " + ("hilbert" if args.block < 0 else "morton" if args.block == 0 else
                                                    "row-major" if args.block == 1 else f"blocked{args.block}")
                                         + ", local numbering by Decomp: " + args.local_order,
@@ -411,6 +437,7 @@ def main():
                                              "why": "load step -> ~25 ms power-management transient (profiles/r03_probe_step_ramp.json)"},
                           "hip_graph": graph_stats},
                "sypd": sypd, "rk4": {"steps": nrk, "dt_s": args.dt, "ms_per_step": None if t_rk4 is None else 1e3 * t_rk4,
+                       "cell_level_updates_per_sec": None if t_rk4 is None else 4.0 * cell_levels / t_rk4,
                        "stage_updates": "separate kernels" if (args.no_fuse_stages or args.unfused) else "fused into the RHS kernels",
                        "halo_exchange": "none (1 rank)" if N == 1 else
                        ("overlapped with the stage's interior cells" if overlap else "after the stage"),
@@ -567,6 +594,8 @@ def main():
             hh, _ = state.copy_to_host(0)
             if not np.isfinite(hh[: mesh.NCellsOwned]).all():
                 raise FloatingPointError("state went non-finite during the RK4 steps")
+            if halo is not None:
+                halo.check()    # the host is synchronised with the last exchange: a peer-wire wait that gave up shows now
         except Exception as exc:  # noqa: BLE001
             rk4_error = f"rank {rank}: {type(exc).__name__}: {exc}"
             sypd = t_rk4 = None
@@ -591,7 +620,7 @@ def main():
         """global double-double sums of h, u and every tracer over owned elements after two RK4 steps from the initial state"""
         ones_c, ones_e = oa.DeviceBuffer(np.ones(mesh.NCellsSize)), oa.DeviceBuffer(np.ones(mesh.NEdgesSize))
         state.copy_to_device(h, u, 0)
-        tracers.copy_to_device(tr, 0)
+        upload_tracers(tracers)
         st2 = oa.TimeStepper("RungeKutta4", args.dt, tend, aux, mesh, halo, tracers)
         st2.set_option("OverlapHaloExchange", mode_overlap)
         for _ in range(2):
@@ -602,7 +631,11 @@ def main():
                  oa.local_weighted_sum_dd(ones_e.ptr, state.device_ptr(1, 0), mesh.NEdgesOwned, K, row_pitch=kp, stream=stream)]
         parts += [oa.local_weighted_sum_dd(ones_c.ptr, tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp,
                                            mesh.NCellsOwned, K, row_pitch=kp, stream=stream) for l in range(NT)]
-        return [oa.global_sum_dd(p) for p in parts] if N > 1 else [oa.combine_dd([p])[0] for p in parts]
+        if N == 1:
+            return [oa.combine_dd([p])[0] for p in parts]
+        if comm is not None or wire is not None:    # globalSum inside the library, over the halo's own wire
+            return [x for i in range(0, len(parts), 32) for x in halo.global_sum_dd(parts[i: i + 32], stream=stream)]
+        return [oa.global_sum_dd(p) for p in parts]          # (host-staged rehearsal: over the side channel)
 
     # N = 1: the same sums, so that the records of an N = 1, 2, 4, 8 series can be compared with each other -- at
     # HaloWidth >= 4 the partitioned runs must give the one-rank run's sums (rk4.state_checksums_after_2_steps)

@@ -348,6 +348,12 @@ class DeviceBuffer:
             pass
 
 
+def copy_to_device(dev_ptr: int, host: np.ndarray):
+    """omg_copy_to_device: a contiguous host array to raw device memory (synchronous)"""
+    a = np.ascontiguousarray(host)
+    _chk(lib().omg_copy_to_device(C.c_void_p(dev_ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)))
+
+
 def combine_dd(pairs) -> tuple:
     """ddSum (Reductions.h:24-35) over an [n][2] array of (hi, lo) partial sums, in order."""
     p = np.ascontiguousarray(pairs, dtype=np.float64).reshape(-1, 2)

@@ -32,6 +32,7 @@ const OptionName OptionTable[] = {
     {"Pair", &TuningOptions::Pair},
     {"FuseL3", &TuningOptions::FuseL3},
     {"FoldLists", &TuningOptions::FoldLists},
+    {"TracerPatch", &TuningOptions::TracerPatch},
     {"InlineOther", &TuningOptions::InlineOther},
     {"Alternate", &TuningOptions::Alternate},
     {"SendBand", &TuningOptions::SendBand},
@@ -63,10 +64,15 @@ TuningOptions &tuning() {
    }();
    return T;
 }
+namespace {
+std::atomic<unsigned long long> TuningGen{0};
+}
+unsigned long long tuningGeneration() { return TuningGen.load(); }
 bool setTuningOption(const std::string &Name, int Value) {
    for (const OptionName &O : OptionTable)
       if (Name == O.Name) {
          tuning().*(O.Field) = Value;
+         ++TuningGen;
          return true;
       }
    return false;
@@ -85,14 +91,28 @@ int &timingLevel() {
    static int Level = 3;
    return Level;
 }
+namespace {
+constexpr int MaxLevels = 16;
+thread_local int PushedAt[MaxLevels] = {}; // open ranges per level of this thread
+int slot(int Level) { return Level < 0 ? 0 : (Level >= MaxLevels ? MaxLevels - 1 : Level); }
+} // namespace
 bool start(const char *Name, int Level) {
-   if (Level <= timingLevel())
+   if (Level <= timingLevel()) {
       roctxRangePushA(Name);
+      if (Level > -1000000)
+         ++PushedAt[slot(Level)];
+   }
    return true;
 }
 bool stop(const char * /*Name*/, int Level) {
-   if (Level <= timingLevel())
+   if (Level <= -1000000) { // a Range that knows its push happened
       roctxRangePop();
+      return true;
+   }
+   if (PushedAt[slot(Level)] > 0) { // pop what a start of this level pushed, whatever the level is now
+      --PushedAt[slot(Level)];
+      roctxRangePop();
+   }
    return true;
 }
 } // namespace Pacer

@@ -425,6 +425,7 @@ void HorzMesh::buildCoefficientTables() {
    buildDel2Tables();
    buildCellL1Tables();
    buildBandLists((I4)NCellsHaloH.size());
+   buildPatchTables();
    buildNarrowTables();
    // test hook: pretend the mesh is not in MPAS ring order, so that every kernel takes its generic form
    if (tuning().ForceGeneric == 1)
@@ -495,6 +496,57 @@ void HorzMesh::buildNarrowTables() {
    N.DomM1        = 0;
    N.NWideCells   = 0; // (the list lives in the wide view)
    HasNarrow      = true;
+}
+
+// Tile patches (see HorzMesh.h): rows in order of first appearance (the tile's own cells first).
+void HorzMesh::buildPatchTables() {
+   MeshView &W         = View;
+   const int Tiles[3]  = {8, 16, 32};
+   const int NPs[3]    = {24, 48, 96}; // what the kernel's LDS budget holds (FusedKernels.hip: CellPVFinalTracerPatchBody)
+   const int ME        = MaxEdges;
+   std::vector<I4> Pos(NCellsSize, -1);
+   for (int S = 0; S < MeshView::NPatchSizes; ++S) {
+      const int T = Tiles[S], NP = NPs[S];
+      const int NTiles = (NCellsAll + T - 1) / T;
+      std::vector<I4> Rows((size_t)std::max(NTiles, 1) * NP, -1), OK(std::max(NTiles, 1), 0);
+      std::vector<unsigned char> Idx((size_t)NCellsSize * 8, 0);
+      std::vector<I4> Touched;
+      for (int Tl = 0; Tl < NTiles; ++Tl) {
+         const int C0 = Tl * T, C1 = std::min(NCellsAll, C0 + T);
+         Touched.clear();
+         auto Add = [&](I4 R) {
+            if (Pos[R] < 0) {
+               Pos[R] = (I4)Touched.size();
+               Touched.push_back(R);
+            }
+            return Pos[R];
+         };
+         for (int Cc = C0; Cc < C1; ++Cc)
+            Add(Cc);
+         bool Fits = true;
+         for (int Cc = C0; Cc < C1; ++Cc) {
+            for (int J = 0; J < 7; ++J) {
+               const I4 P = J < ME ? Add(HostNbrF(Cc, J) & 0x3fffffff) : 0;
+               Idx[(size_t)Cc * 8 + J] = (unsigned char)std::min<I4>(P, 255);
+            }
+            Idx[(size_t)Cc * 8 + 7] = (unsigned char)Pos[Cc];
+         }
+         Fits = (int)Touched.size() <= NP && ME <= 7;
+         OK[Tl] = Fits ? 1 : 0;
+         for (size_t I = 0; I < Touched.size(); ++I) {
+            if (Fits)
+               Rows[(size_t)Tl * NP + I] = Touched[I];
+            Pos[Touched[I]] = -1;
+         }
+      }
+      PatchRowsD[S] = Array1DI4("PatchRows", (int)Rows.size());
+      PatchOKD[S]   = Array1DI4("PatchOK", (int)OK.size());
+      PatchIdxD[S]  = Array1DI4("PatchIdx", (int)(Idx.size() / 4));
+      OMEGA::copyToDevice(PatchRowsD[S].Ptr, Rows.data(), Rows.size() * sizeof(I4));
+      OMEGA::copyToDevice(PatchOKD[S].Ptr, OK.data(), OK.size() * sizeof(I4));
+      OMEGA::copyToDevice(PatchIdxD[S].Ptr, Idx.data(), Idx.size());
+      W.PatchNP[S] = NP, W.PatchRows[S] = PatchRowsD[S].Ptr, W.PatchIdx[S] = PatchIdxD[S].Ptr, W.PatchOK[S] = PatchOKD[S].Ptr;
+   }
 }
 
 // Band / interior split of the local cells for overlapping a halo exchange with interior work

@@ -125,6 +125,17 @@ struct MeshView {
    // interior only: every other local value is about to be overwritten by the exchange.
    I4 NBandSendCells;
    const I4 *BandSendCells;
+   // ---- tile patches (HorzMesh::buildPatchTables) ----
+   // For the tile sizes the cell sweeps use (8, 16, 32 consecutive cells), tile t: PatchRows[s][t][0 .. PatchNP[s]) = the
+   // distinct cell rows its cells and their neighbours touch (-1 = unused slot), PatchIdx[s][c][j] (bytes: j < 7 the cell
+   // across edge slot j, j = 7 the cell itself) = position of that row in the tile's list, PatchOK[s][t] = the list fits.
+   // The level-3 kernel stages each tracer's rows of a tile once per workgroup into LDS (straight from the buffer, no
+   // registers) instead of gathering them per thread: a row is loaded once, not by up to 7 threads, and the next
+   // tracer's rows are in flight while this one is computed.
+   static constexpr int NPatchSizes = 3;
+   I4 PatchNP[NPatchSizes];
+   const I4 *PatchRows[NPatchSizes], *PatchIdx[NPatchSizes], *PatchOK[NPatchSizes];
+   static constexpr int patchSlot(int Tile) { return Tile == 8 ? 0 : (Tile == 16 ? 1 : (Tile == 32 ? 2 : -1)); }
 };
 
 class HorzMesh : public Registry<HorzMesh> {
@@ -201,6 +212,8 @@ class HorzMesh : public Registry<HorzMesh> {
    Array2DReal RingSignOnCell;
    Array1DI4 RingCellsM0, RingCellsM1, RingCellsM2, BandCells, InteriorCells, BandSendCells;
    void buildBandLists(I4 HaloWidth);
+   void buildPatchTables();
+   Array1DI4 PatchRowsD[MeshView::NPatchSizes], PatchIdxD[MeshView::NPatchSizes], PatchOKD[MeshView::NPatchSizes];
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;
    DeviceArray<I4, 3> PVChainVert, PVChainFar, PVChainEdge;

@@ -167,10 +167,11 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
                         EdgeScratch.Ptr, nullptr, Mesh->narrowView());
       };
       // wind forcing reads the stress arrays through a non-tile kernel too, still plain launches: capturable
-      if (UseGraphs && !Ev && !CustomThicknessTend && !CustomVelocityTend) {
+      if (graphsOn() && !Ev && !CustomThicknessTend && !CustomVelocityTend) {
          GraphCache::Key Key;
          GraphCache::add(Key, LayerThick.Ptr), GraphCache::add(Key, NormVel.Ptr), GraphCache::add(Key, TracerArray.Ptr);
          GraphCache::add(Key, Aux), GraphCache::add(Key, P), GraphCache::add(Key, S);
+         GraphCache::add(Key, tuningGeneration()); // (the kernel structure options are read at every launch)
          Graphs.run(Key, S, Launch);
       } else {
          Launch();

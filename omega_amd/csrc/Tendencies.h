@@ -31,8 +31,10 @@ class Tendencies : public Registry<Tendencies> {
    /// Replay the fused RHS as a HIP graph when it is called again with the same arrays on a non-default stream
    /// (GraphCache.h): one host call instead of 7 launches.  Default off (no gain measured); never used while
    /// kernel timing or custom tendencies are on.
-   bool UseGraphs = GraphCache::defaultOn();
+   bool UseGraphs = false;
    GraphCache Graphs;
+   /// the object's switch, or the option Graphs = 1 (read when asked, not when the object was made)
+   bool graphsOn() const { return UseGraphs || GraphCache::defaultOn(); }
 
    /// Custom tendencies (Tendencies.h:51-53, 182-183): called at the end of the thickness / velocity
    /// group with the tendency array, the state / aux state, the two time levels and the model time

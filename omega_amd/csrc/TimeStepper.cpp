@@ -437,7 +437,7 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
       }
    }
    };
-   if (!Exchanges && UseGraphs && StageFusedKnownGood && !Tend->CustomThicknessTend && !Tend->CustomVelocityTend) {
+   if (!Exchanges && (UseGraphs || GraphCache::defaultOn()) && StageFusedKnownGood && !Tend->CustomThicknessTend && !Tend->CustomVelocityTend) {
       // one rank: nothing but kernel launches on S -- replay them as a graph (keyed by everything that enters them)
       GraphCache::Key Key;
       GraphCache::add(Key, State), GraphCache::add(Key, CurH.Ptr), GraphCache::add(Key, NextH.Ptr);
@@ -445,6 +445,7 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
       GraphCache::add(Key, NextTr.Ptr), GraphCache::add(Key, TimeStep), GraphCache::add(Key, (int)StoreStageTendencies);
       GraphCache::add(Key, Tend), GraphCache::add(Key, AuxState), GraphCache::add(Key, Tend->Params), GraphCache::add(Key, S);
       GraphCache::add(Key, (int)Tend->UseFusedRHS);
+      GraphCache::add(Key, tuningGeneration()); // (the kernel structure options are read at every launch)
       GraphCache::add(Key, (int)AuxState->LayerThicknessAux.FluxThickEdgeChoice);
       GraphCache::add(Key, (int)AuxState->TracerAux.TracersOnEdgeChoice);
       GraphCache::add(Key, (int)AuxState->WindForcingAux.InterpChoice);

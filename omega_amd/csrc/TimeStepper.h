@@ -130,7 +130,7 @@ class RungeKutta4Stepper : public TimeStepper {
    bool OverlapHaloExchange   = true;
    /// Without neighbours (one rank) the 28 launches of a stage-fused step are replayed as one HIP graph per
    /// time-level parity when the step runs on a non-default stream (GraphCache.h).
-   bool UseGraphs             = GraphCache::defaultOn();
+   bool UseGraphs             = false; ///< (or the option Graphs = 1, read at every step)
    GraphCache Graphs;
    ~RungeKutta4Stepper() override;
 

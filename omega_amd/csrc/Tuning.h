@@ -26,6 +26,7 @@ struct TuningOptions {
    int Pair      = 1; ///< independent sweeps share a launch
    int FuseL3    = 1; ///< plain RHS: both level-3 kernels in one thread
    int InlineOther = 1; ///< merged level-1 kernel: side-0 PV sums of the cells with one edge fewer inside the sweep
+   int TracerPatch = 1; ///< level-3 kernel of the plain RHS: the tracer loop's neighbour values staged through LDS tile patches (CellPVFinalTracerPatchBody)
    int FoldLists = 1; ///< plain RHS: the other valence's final-pass cell list joins the level-3 sweep's launch
    int Alternate  = 0; ///< 1: consecutive dependency levels sweep the mesh in opposite directions (measured: no gain)
    int SendBand   = 1; ///< overlapped RK4 stages: the level-3 kernels skip the halo cells whose results the exchange replaces
@@ -43,6 +44,9 @@ struct TuningOptions {
 };
 
 TuningOptions &tuning();
+/// bumped by every setTuningOption: captured launch sequences (GraphCache keys) are only replayed under the options
+/// they were captured with
+unsigned long long tuningGeneration();
 /// false if there is no option of that name
 bool setTuningOption(const std::string &Name, int Value);
 bool getTuningOption(const std::string &Name, int &Value);

@@ -103,6 +103,13 @@ template <class T> __device__ __forceinline__ T ldnt(const Real *Base, unsigned 
 template <class T> __device__ __forceinline__ T ldntIf(bool Cond, const Real *Base, unsigned ByteOff) {
    return ldnt<T>(Base, Cond ? ByteOff : BufOOB);
 }
+/// 16 bytes per lane from a buffer straight into LDS (`buffer_load_dwordx4 ... lds`, gfx950): lane l of the wavefront
+/// lands at LdsWaveBase + 16 l; no VGPR is written, the load counts on vmcnt like any other; an out-of-range offset
+/// (BufOOB) moves nothing.  LdsWaveBase must be wave-uniform.
+__device__ __forceinline__ void ldsDma16(const Real *Base, unsigned ByteOff, unsigned char *LdsWaveBase) {
+   __builtin_amdgcn_raw_ptr_buffer_load_lds(bufRsrc(Base), (__attribute__((address_space(3))) void *)LdsWaveBase, 16, ByteOff,
+                                            0, 0, 0);
+}
 /// keeps loop-invariant LDS reads inside the loop (a register each otherwise): nothing after this point may be
 /// assumed unchanged in memory
 __device__ __forceinline__ void loopFence() { __asm__ volatile("" ::: "memory"); }
@@ -318,7 +325,17 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
 /// INLO: cells with NR - 1 edges (the pentagons of a hexagon mesh) do their side-0 sums here as well, with the ring code
 /// instantiated a second time, instead of through a list launch of CellPVBody (12 pentagons on a QU240-sized sphere:
 /// that launch was 9 % of the RHS).  Only instantiated for meshes that have such cells.
-template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false> struct FusedCellL1PVBody {
+/// FL (compile-time list / width flags of the cell bodies): bit 0 = the launch may run over a cell list (`List`), bit 1 =
+/// the mesh has cells with more edges than these tables hold (narrow view: such cells are skipped here and served by a
+/// list launch on the wide tables).  The full sweeps of a mesh without wider cells are instantiated with FL = 0: no list
+/// selects, no width test -- the instruction stream they had before lists and narrow tables existed.
+template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false, int FL = 3> struct FusedCellL1PVBody {
+   __device__ __forceinline__ int cellOf(int I) const {
+      if constexpr ((FL & 1) != 0)
+         return List ? List[I] : I;
+      else
+         return I;
+   }
    static constexpr int MinWaves = OMEGA_L1PV_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    static constexpr int TM1      = TME - 1;
@@ -363,7 +380,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false>
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
          const int Cl = I / TME, Jl = I - Cl * TME;
-         const int C  = List ? List[First + Cl] : First + Cl;
+         const int C  = cellOf(First + Cl);
          const size_t G = (size_t)C * TME + Jl;
          L.KEC[I]       = M.KECoefOnCell[G];
          L.DivC[I]      = M.DivCoefOnCell[G];
@@ -380,7 +397,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false>
          L.FV[I]        = M.FVertex[M.VertRingOnCell[G]];
          L.Role[I]      = M.PVRoleOnCell[G];
       }
-      if (!List) { // a sweep: the tile's rows are one contiguous piece of every table
+      if (!(FL & 1) || !List) { // a sweep: the tile's rows are one contiguous piece of every table
          for (int I = Tid; I < Cnt * TME * TM1; I += NThr)
             L.Wt[I] = M.PVWeightOnCell[(size_t)First * TME * TM1 + I];
          for (int I = Tid; I < Cnt * TME * 3; I += NThr) {
@@ -400,16 +417,18 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false>
          }
       }
       for (int I = Tid; I < Cnt; I += NThr) {
-         const int C = List ? List[First + I] : First + I;
+         const int C = cellOf(First + I);
          L.InvA[I]   = M.InvAreaCell[C];
          L.N[I]      = M.NEdgesOnCell[C];
       }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
       const int N = L.N[Le];
-      if (N > TME)
-         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
-      const int ICell       = List ? List[IElem] : IElem;
+      if constexpr ((FL & 2) != 0) {
+         if (N > TME)
+            return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      }
+      const int ICell       = cellOf(IElem);
       const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
       const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
       const Real InvA       = L.InvA[Le];
@@ -687,7 +706,7 @@ struct FusedDel2VertexBody {
 
 // L2 cell pass, ring form (HorzMesh::buildDel2Tables): same arithmetic as FusedDel2CellBody with
 // every row gathered once -- Div at the cell and its TME neighbours, RelVort on its TME ring vertices.
-template <int TME> struct Del2CellRingBody {
+template <int TME, int FL = 3> struct Del2CellRingBody {
    static constexpr bool HoistTables = true; // (KernelCommon.h: measured 0.588 against 0.600 ms for the pair)
    MeshView M;
    int K;
@@ -716,7 +735,7 @@ template <int TME> struct Del2CellRingBody {
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
          size_t G = (size_t)First * TME + I;
-         if (List) {
+         if ((FL & 1) && List) {
             const int Cl = I / TME;
             G            = (size_t)List[First + Cl] * TME + (I - Cl * TME);
          }
@@ -728,12 +747,14 @@ template <int TME> struct Del2CellRingBody {
          L.Ring[I]      = M.VertRingOnCell[G];
       }
       for (int I = Tid; I < Cnt; I += NThr)
-         L.N[I] = M.NEdgesOnCell[List ? List[First + I] : First + I];
+         L.N[I] = M.NEdgesOnCell[((FL & 1) && List) ? List[First + I] : First + I];
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
-      if (L.N[Le] > TME)
-         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
-      const int ICell = List ? List[IElem] : IElem;
+      if constexpr ((FL & 2) != 0) {
+         if (L.N[Le] > TME)
+            return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      }
+      const int ICell = ((FL & 1) && List) ? List[IElem] : IElem;
       T Dn[TME], Rv[TME];
 #pragma unroll
       for (int J = 0; J < TME; ++J) {
@@ -1440,7 +1461,13 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
 // CellPVFinalBody<TME, TME> and the default-term FusedCell3Body in one thread: the L3 work of a cell with one gather
 // of h and u (32 B per cell-level less than the paired launch of the two kernels; same expressions, so same bits).
 // Plain RHS only: with the stage updates in the epilogues the paired launch is the faster one.
-template <int TME, int NR = TME> struct CellPVFinalTracerBody {
+template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
+   __device__ __forceinline__ int cellOf(int I) const {
+      if constexpr ((FL & 1) != 0)
+         return List ? List[I] : I;
+      else
+         return I;
+   }
    static constexpr int MinWaves = OMEGA_PVF_MINW;
    static constexpr int TM1      = TME - 1;
    MeshView M;
@@ -1456,7 +1483,7 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
       Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs, *FV, *MDvS, *Df2, *Df4, *InvA;
       int *Edge, *NbrF, *Ring, *Role, *N;
    };
-   size_t ldsBytes(int Tile) const {
+   __host__ __device__ size_t ldsBytes(int Tile) const {
       return ldsRound8(sizeof(Real) * Tile * TME * TM1) + ldsRound8(sizeof(Real) * Tile * TME) * 9 +
              ldsRound8(sizeof(Real) * Tile) * 2 + ldsRound8(sizeof(int) * Tile * TME) * 4 + ldsRound8(sizeof(int) * Tile);
    }
@@ -1485,12 +1512,12 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME * TM1; I += NThr) {
          const int Le = I / (TME * TM1);
-         const int C  = List ? List[First + Le] : First + Le;
+         const int C  = cellOf(First + Le);
          L.Wt[I]      = M.PVWeightOnCell[(size_t)C * TME * TM1 + (I - Le * TME * TM1)];
       }
       for (int I = Tid; I < Cnt * TME; I += NThr) {
          const int Le    = I / TME;
-         const int C     = List ? List[First + Le] : First + Le;
+         const int C     = cellOf(First + Le);
          const size_t G  = (size_t)C * TME + (I - Le * TME);
          const int Ed    = M.EdgesOnCell[G];
          const int F     = M.NbrFlagOnCell[G];
@@ -1510,21 +1537,35 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
          L.Df4[I]        = M.Diff4CoefSOnCell[G];
       }
       for (int I = Tid; I < Cnt; I += NThr) {
-         const int C = List ? List[First + I] : First + I;
+         const int C = cellOf(First + I);
          L.BDs[I]    = M.BottomDepth[C];
          L.N[I]      = M.NEdgesOnCell[C];
          L.InvA[I]   = M.InvAreaCell[C];
       }
    }
+   /// what the velocity part gathers and the tracer loop goes on with
+   template <class T> struct RingVals {
+      unsigned OffS, OffN[TME];
+      T Hs, Hn[TME], Uj[TME];
+   };
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
-      if (L.N[Le] > TME)
-         return; // a cell wider than these tables: it has its own (list) launches on the wide tables
-      const int ICell = List ? List[IElem] : IElem;
+      if constexpr ((FL & 2) != 0) {
+         if (L.N[Le] > TME)
+            return; // a cell wider than these tables: it has its own (list) launches on the wide tables
+      }
+      RingVals<T> R;
+      velPart<T>(L, Le, cellOf(IElem), Kv, R);
+      tracerLoopDirect<T>(L, Le, R);
+   }
+   /// CellPVFinalBody<TME, NR>: finishes the edges of which this cell is the second cell
+   template <class T> __device__ __forceinline__ void velPart(const Lds &L, int Le, int ICell, int Kv, RingVals<T> &R) const {
       const Real Grav = 9.80665; // TendencyTerms.h:176
-      unsigned OffE[TME], OffN[TME];
-      T Uj[TME], Hn[TME];
-      const unsigned OffS = rowOff<T>(ICell, K, Kv);
-      const T Hs          = ldo<T>(H, OffS);
+      unsigned OffE[TME];
+      unsigned(&OffN)[TME] = R.OffN;
+      T(&Uj)[TME] = R.Uj;
+      T(&Hn)[TME] = R.Hn;
+      const unsigned OffS = R.OffS = rowOff<T>(ICell, K, Kv);
+      const T Hs = R.Hs   = ldo<T>(H, OffS);
 #pragma unroll
       for (int J = 0; J < TME; ++J) {
          OffE[J] = rowOff<T>(L.Edge[Le * TME + J], K, Kv);
@@ -1609,7 +1650,14 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
             stnt<T>(Tend, OffE[I], TendV);
          }
       }
-      // ---- FusedCell3Body<TME, true> ----
+   }
+   /// FusedCell3Body<TME, true>: every tracer's neighbour values gathered by the thread
+   template <class T> __device__ __forceinline__ void tracerLoopDirect(const Lds &L, int Le, const RingVals<T> &R) const {
+      const unsigned OffS = R.OffS;
+      const unsigned(&OffN)[TME] = R.OffN;
+      const T Hs = R.Hs;
+      const T(&Hn)[TME] = R.Hn;
+      const T(&Uj)[TME] = R.Uj;
       const Real InvA      = L.InvA[Le];
       const size_t CStride = (size_t)M.NCellsSize * K;
 #ifndef OMEGA_L3_TRUNROLL
@@ -1652,6 +1700,164 @@ template <int TME, int NR = TME> struct CellPVFinalTracerBody {
             TendV += P.EddyDiff2 * DiffTmp * InvA;
             TendV -= P.EddyDiff4 * HypTmp * InvA;
             stntIf<T>(Valid, uniformPtr(TrTend + (Valid ? Lt + Q : Lt) * CStride), OffS, TendV);
+         }
+      }
+   }
+};
+
+
+// ---------------------------------------------------------------------------------------
+// CellPVFinalTracerBody with the tracer loop's neighbour values staged through LDS once per workgroup (tile patches,
+// HorzMesh.h).  Per (tile, level chunk, tracer) the workgroup moves the chunk's 128 bytes of every row of the tile's patch
+// -- Tr and Del2Tr: 2 x PatchNP rows -- from the buffers straight into LDS (`buffer_load_dwordx4 ... lds`: 16 bytes per
+// lane, 8 rows per instruction, no registers), double-buffered: tracer t+1 is in flight while tracer t is computed, one
+// workgroup barrier per tracer.  A thread then reads its 2 x 7 values from LDS.  Against the per-thread gathers: each
+// row is asked for once instead of by up to seven threads, the loop's loads never wait for registers, and its compute
+// phase always has the next tracer's requests outstanding.  Same expressions in the same order: same bits.
+// The transfers are inline assembly on purpose: the compiler makes every LDS read wait for all LDS-DMA it knows of, which
+// would serialise the pipeline; hidden from it, the waits are placed by hand (memory operations of a wave complete in
+// order, so the compiler's own counts stay safe -- they can only wait for more than they need).
+template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody : CellPVFinalTracerBody<TME, NR, FL> {
+   using Base = CellPVFinalTracerBody<TME, NR, FL>;
+   static constexpr bool Cooperative = true; // the tile kernels call computeTile() with every thread of the workgroup
+   const I4 *PRows, *PIdx, *POK; // the mesh's patch tables for this launch's tile size
+   int NP;                       // rows per patch (multiple of 8)
+   int NWv = 4;                  // wavefronts per workgroup (KernelCommon.h: setWaves)
+   struct Lds : Base::Lds {
+      int *PRow;
+      unsigned char *PIdxB, *Buf; // Buf: [2 buffers][2 arrays][NP rows][128 bytes]
+      int *OKp;
+   };
+   size_t ldsBytes(int Tile) const {
+      return Base::ldsBytes(Tile) + ldsRound8(sizeof(int) * NP) + ldsRound8((size_t)Tile * 8) + 16 + 8 + (size_t)4 * NP * 128;
+   }
+   __device__ Lds carve(unsigned char *Ptr, int Tile) const {
+      Lds L;
+      static_cast<typename Base::Lds &>(L) = Base::carve(Ptr, Tile);
+      LdsCarver C{Ptr + Base::ldsBytes(Tile)};
+      L.PRow  = C.take<int>(NP);
+      L.PIdxB = C.take<unsigned char>(Tile * 8);
+      L.OKp   = C.take<int>(2);
+      L.Buf   = C.P + ((16u - ((unsigned)(C.P - Ptr) & 15u)) & 15u); // (pointer arithmetic only: stays an LDS address)
+      return L;
+   }
+   __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
+      Base::stage(L, First, Cnt, Tid, NThr);
+      const int Tile = blockDim.y, Tl = First / Tile;
+      for (int I = Tid; I < NP; I += NThr)
+         L.PRow[I] = PRows[(size_t)Tl * NP + I];
+      const unsigned char *Src = reinterpret_cast<const unsigned char *>(PIdx) + (size_t)First * 8;
+      for (int I = Tid; I < Cnt * 8; I += NThr)
+         L.PIdxB[I] = Src[I];
+      if (Tid == 0)
+         L.OKp[0] = POK[Tl];
+   }
+   /// one 16-byte-per-lane transfer buffer -> LDS; LdsAddr = LDS byte address of the wavefront's 1 KiB destination
+   __device__ __forceinline__ static void dma16(const Real *Plane, unsigned ByteOff, unsigned LdsAddr) {
+      const unsigned long long V = reinterpret_cast<unsigned long long>(Plane);
+      BufV4 Rs;
+      Rs.x = __builtin_amdgcn_readfirstlane((unsigned)V);
+      Rs.y = __builtin_amdgcn_readfirstlane((unsigned)(V >> 32) & 0xffffu);
+      Rs.z = BufOOB;
+      Rs.w = 0x00020000u;
+      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                       :
+                       : "s"(LdsAddr), "v"(ByteOff), "s"(Rs)
+                       : "memory");
+   }
+   /// this wavefront's share of tracer Lt's rows into buffer (It & 1)
+   template <class T> __device__ __forceinline__ void fetchTracer(const Lds &L, int Lt, unsigned It, int Kv, bool KvOK) const {
+      const unsigned Tid  = threadIdx.y * blockDim.x + threadIdx.x;
+      const unsigned Wv   = __builtin_amdgcn_readfirstlane(Tid >> 6);
+      const unsigned Lane = Tid & 63u;
+      const size_t CStride = (size_t)this->M.NCellsSize * this->K;
+      const Real *TrL = uniformPtr(this->Tr + Lt * CStride), *D2L = uniformPtr(this->Del2Tr + Lt * CStride);
+      const unsigned BufBase =
+          __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(L.Buf)) + (It & 1u) * 2u * (unsigned)NP * 128u;
+      for (int G = (int)Wv; G * 8 < NP; G += NWv) { // 8 rows (1 KiB) per transfer
+         const int Row      = L.PRow[G * 8 + (int)(Lane >> 3)];
+         const unsigned Off = (Row >= 0 && KvOK) ? rowOff<T>(Row, this->K, Kv) : BufOOB;
+         dma16(TrL, Off, BufBase + (unsigned)G * 1024u);
+         dma16(D2L, Off, BufBase + (unsigned)NP * 128u + (unsigned)G * 1024u);
+      }
+   }
+   template <class T> __device__ void computeTile(const Lds &L, int First, int Cnt, int C0, int CS, int KV) const {
+      if constexpr (sizeof(T) != 16) { // (the launcher only takes this body with 16-byte accesses; never run)
+         for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+            for (int Kv = C0 * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * CS)
+               Base::template compute<T>(L, Le, First + Le, Kv);
+         return;
+      }
+      const int Le    = threadIdx.y;
+      const bool Mine = Le < Cnt && !(((FL & 2) != 0) && L.N[Le < Cnt ? Le : 0] > TME);
+      const int ICell = this->cellOf(First + (Le < Cnt ? Le : 0));
+      const bool Patch = L.OKp[0] != 0; // (workgroup-uniform)
+      unsigned It = 0;                  // transfers issued so far by this workgroup: buffer = It & 1
+      for (int Kc = C0; Kc * (int)blockDim.x < KV; Kc += CS) { // (the same trip count for every thread)
+         chunkFence<CellPVFinalTracerPatchBody>();
+         const int Kv    = Kc * blockDim.x + threadIdx.x;
+         const bool KvOK = Kv < KV;
+         const bool Act  = Mine && KvOK;
+         if (!Patch) { // a tile whose patch does not fit: the per-thread gathers
+            if (Act)
+               Base::template compute<T>(L, Le, First + Le, Kv);
+            continue;
+         }
+         // the first tracer's rows travel while the velocity part runs (the buffer was last read two tracers ago, and
+         // every wave has passed the barrier of the tracer in between)
+         fetchTracer<T>(L, 0, It, Kv, KvOK);
+         typename Base::template RingVals<T> R;
+         R.OffS = BufOOB, R.Hs = splat<T>(0.0);
+#pragma unroll
+         for (int J = 0; J < TME; ++J)
+            R.OffN[J] = BufOOB, R.Hn[J] = splat<T>(0.0), R.Uj[J] = splat<T>(0.0);
+         if (Act)
+            Base::template velPart<T>(L, Le, ICell, Kv, R);
+         const unsigned OffS = Act ? R.OffS : BufOOB; // (inactive threads run the loop for its barriers; they store nothing)
+         const Real InvA      = L.InvA[Le < Cnt ? Le : 0];
+         const size_t CStride = (size_t)this->M.NCellsSize * this->K;
+         const unsigned char *PI = L.PIdxB + (Le < Cnt ? Le : 0) * 8;
+         unsigned PO[TME + 1]; // byte offsets of this thread's 7 + 1 values inside a buffer plane
+#pragma unroll
+         for (int J = 0; J < TME; ++J)
+            PO[J] = (unsigned)PI[J] * 128u + threadIdx.x * 16u;
+         PO[TME] = (unsigned)PI[7] * 128u + threadIdx.x * 16u;
+#pragma nounroll
+         for (int Lt = 0; Lt < this->NT; ++Lt, ++It) {
+            loopFence();
+            // tracer Lt's rows have landed: everything this wave asked for before its most recent store
+            if (Lt == 0)
+               __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+               __asm__ volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __asm__ volatile("" ::: "memory");
+            if (Lt + 1 < this->NT)
+               fetchTracer<T>(L, Lt + 1, It + 1, Kv, KvOK);
+            const unsigned char *BT = L.Buf + (size_t)(It & 1u) * 2u * NP * 128u, *BD = BT + (size_t)NP * 128u;
+            T Tn[TME], Dn[TME];
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               Tn[J] = *reinterpret_cast<const T *>(BT + PO[J]);
+               Dn[J] = *reinterpret_cast<const T *>(BD + PO[J]);
+            }
+            const T Ts = *reinterpret_cast<const T *>(BT + PO[TME]), Ds = *reinterpret_cast<const T *>(BD + PO[TME]);
+            T HAdvTmp = splat<T>(0.0), DiffTmp = splat<T>(0.0), HypTmp = splat<T>(0.0);
+            const T HsTs = R.Hs * Ts;
+#pragma unroll
+            for (int J = 0; J < TME; ++J) {
+               const int I  = (Le < Cnt ? Le : 0) * TME + J;
+               const T HTr  = 0.5 * (HsTs + R.Hn[J] * Tn[J]);
+               HAdvTmp -= L.MDvS[I] * HTr * R.Uj[J] * InvA;
+               const T Mean = 0.5 * (R.Hs + R.Hn[J]);
+               DiffTmp -= L.Df2[I] * Mean * (Tn[J] - Ts);
+               HypTmp -= L.Df4[I] * (Dn[J] - Ds);
+            }
+            T TendV = splat<T>(0.0);
+            TendV -= HAdvTmp;
+            TendV += this->P.EddyDiff2 * DiffTmp * InvA;
+            TendV -= this->P.EddyDiff4 * HypTmp * InvA;
+            stnt<T>(uniformPtr(this->TrTend + Lt * CStride), OffS, TendV); // (exactly one store per tracer: the wait above counts on it)
          }
       }
    }
@@ -1765,7 +1971,7 @@ template <bool Fast> struct EdgeFinalBody {
 // ---------------------------------------------------------------------------------------
 // L3 cell pass: tracer tendencies (TendencyTerms.h:349-480) with HTracersEdge
 // (TracerAuxVars.h:25-59) and MeanLayerThickEdge rebuilt inline; tracer loop inside.
-template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
+template <int TME, bool Fast, bool EPI = false, int FL = 3> struct FusedCell3Body {
    static constexpr int MinWaves = OMEGA_C3_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
    MeshView M;
@@ -1813,8 +2019,10 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell3Body {
       }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
-      if (L.N[Le] > TME)
-         return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      if constexpr ((FL & 2) != 0) {
+         if (L.N[Le] > TME)
+            return; // a cell wider than these tables: it has its own (list) launch on the wide tables
+      }
       const int ICell     = List ? List[IElem] : IElem;
       const bool TrUpwind = Fast ? false : (P.FluxTracerUpwind != 0);
       const bool AdvOn = Fast ? true : (P.TracerHorzAdvTendencyEnable != 0);
@@ -1945,7 +2153,9 @@ bool fusedRHSSupported(const MeshView &M, int K) {
 /// ND = the valence the full sweeps of the cell-centric PV kernels are instantiated for: TME, or TME-1 when most
 /// cells have one edge fewer than the widest (hexagons with a few heptagons).  NA = the other of the two; cells of
 /// valence NA and TME-2 go through list launches.
-template <int TME, bool Fast, int ND = TME>
+/// HW: M is the NARROW view of a mesh with wider cells (*Wide the full-width one); without, the cell bodies of the sweeps
+/// carry neither list selects nor width tests (FL above).
+template <int TME, bool Fast, int ND = TME, bool HW = false>
 static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend,
                          Real *UTend, Real *TrTend, const Real *H, const Real *U, const Real *Tr, hipStream_t S,
                          hipEvent_t *Ev, Real *EdgeScratch, const StageUpdate *Stage, const MeshView *Wide = nullptr) {
@@ -1953,7 +2163,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // TW = TME+1 edges (Wide->WideCells: the heptagons of a hexagon mesh) are skipped by every sweep over M and run
    // through list launches of the TW-slot bodies on *Wide, level by level.
    constexpr int TW       = TME < 8 ? TME + 1 : TME;
-   constexpr bool CanWide = ND == TME && TME < 8;
+   constexpr bool CanWide = HW && ND == TME && TME < 8;
+   constexpr int FLS      = HW ? 2 : 0; // flags of a full sweep: no list; width test only next to wider cells
+   constexpr int FLL      = HW ? 3 : 1; // ... of a body that may also run over band / interior lists
    const I4 NWide         = (CanWide && Wide) ? Wide->NWideCells : 0;
    constexpr int NA     = ND == TME ? TME - 1 : TME;
    const I4 NMain       = ND == TME ? M.NRingCellsM0 : M.NRingCellsM1; // cells of the sweeps' valence
@@ -2031,12 +2243,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    if (MergeL1) {
       auto LaunchL1x = [&](auto Epi, auto Inl) {
          constexpr bool EP = decltype(Epi)::value, IL = decltype(Inl)::value && ND == TME;
-         FusedCellL1PVBody<TME, Fast, EP, ND, IL> B{M,  K,  NT,    P,      DoDel2Tr,        H,
+         FusedCellL1PVBody<TME, Fast, EP, ND, IL, FLS> B{M,  K,  NT,    P,      DoDel2Tr,        H,
                                             U,  Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
                                             A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
          if constexpr (CanWide) {
             if (NWide > 0) { // the wide cells' level-1 work rides along: same body, TW slots, wide tables, cell list
-               FusedCellL1PVBody<TW, Fast, EP, TW> Bw{*Wide, K,  NT,    P,      DoDel2Tr,        H,
+               FusedCellL1PVBody<TW, Fast, EP, TW, false, 1> Bw{*Wide, K,  NT,    P,      DoDel2Tr,        H,
                                                        U,     Tr, A.KineticEnergyCell, A.VelocityDivCell, HTend, A.Del2TracersCell,
                                                        A.RelVortVertex, A.InvThickVertex, EdgeScratch, EH};
                Bw.List = Wide->WideCells;
@@ -2108,12 +2320,12 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    FusedKernelNames[2] = FusedKernelNames[3] = "";
    if (PairL2) {
       FusedKernelNames[2] = "Del2CellRingBody+Del2VertexSelBody";
-      Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+      Del2CellRingBody<TME, FLS> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
       Del2VertexSelBody BV{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2RelVortVertex};
       bool Launched = false;
       if constexpr (CanWide) {
          if (NWide > 0) {
-            Del2CellRingBody<TW> BW{*Wide, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+            Del2CellRingBody<TW, 1> BW{*Wide, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
             BW.List = Wide->WideCells;
             launchTileV(K, S, BC, M.NCellsAll, BV, M.NVerticesAll, BW, NWide);
             Launched = WideL2Done = true;
@@ -2124,7 +2336,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    } else if (P.VelHyperDiffTendencyEnable) {
       FusedKernelNames[2] = M.Del2RingOK ? "Del2CellRingBody" : "FusedDel2CellBody";
       if (M.Del2RingOK) {
-         Del2CellRingBody<TME> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+         Del2CellRingBody<TME, FLS> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
          launchTile(BC, M.NCellsAll, K, S);
       } else {
          FusedDel2CellBody BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
@@ -2144,7 +2356,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    }
    if constexpr (CanWide) {
       if (NWide > 0 && P.VelHyperDiffTendencyEnable && !WideL2Done) { // (a narrow view implies the ring form)
-         Del2CellRingBody<TW> BC{*Wide, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
+         Del2CellRingBody<TW, 1> BC{*Wide, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
          BC.List = Wide->WideCells;
          launchTile(BC, NWide, K, S);
       }
@@ -2407,7 +2619,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       if (NWide > 0 && NT > 0 && !FoldL3) {
          auto WideTr = [&](auto Epi) {
             constexpr bool EP = decltype(Epi)::value;
-            FusedCell3Body<TW, Fast, EP> B{*Wide, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            FusedCell3Body<TW, Fast, EP, 1> B{*Wide, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
             B.List = Wide->WideCells;
             launchTile(B, NWide, K, S);
          };
@@ -2442,45 +2654,64 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                                              UTend,
                                              nullptr,
                                              EU};
-            FusedCell3Body<TME, true, EP> B3{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            FusedCell3Body<TME, true, EP, FLL> B3{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
             if constexpr (!EP) {
                if (FuseL3) { // one thread per (cell, levels) does both: h and u gathered once
-                  CellPVFinalTracerBody<TME, ND> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                  CellPVFinalTracerBody<TME, ND, FLS> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                 A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                 A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
+                  // the sweep's body Bs -- plain or with the tracer loop through LDS tile patches -- alone or with the lists
+                  // that ride along in its launch
+                  auto LaunchSweep = [&](const auto &Bs) {
                   if constexpr (CanWide) {
-                     if (FoldL3 && NWide > 0) {
-                        CellPVFinalTracerBody<TW, TW> BW{*Wide, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
-                                                         A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
-                                                         A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
-                        BW.List = Wide->WideCells;
+                        if (FoldL3 && NWide > 0) {
+                           CellPVFinalTracerBody<TW, TW, 1> BW{*Wide, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                            A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
+                                                            A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
+                           BW.List = Wide->WideCells;
+                           constexpr int NM1f = ND == TME ? TME - 1 : TME;
+                           CellPVFinalBody<TME, NM1f, false> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
+                                                                 A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
+                                                                 A.Del2DivCell, A.Del2RelVortVertex, UTend, OtherCells, EU};
+                           launchTileV(K, S, Bs, M.NCellsAll, BW, NWide, Bm, NOther);
+                           return;
+                        }
+                     }
+                     if (FoldL3 || FoldChain) { // (no wide cells: the sweep, the other valence's final pass, the irregular edges)
                         constexpr int NM1f = ND == TME ? TME - 1 : TME;
                         CellPVFinalBody<TME, NM1f, false> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                               A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
                                                               A.Del2DivCell, A.Del2RelVortVertex, UTend, OtherCells, EU};
-                        launchTileV(K, S, BF, M.NCellsAll, BW, NWide, Bm, NOther);
+                        FusedEdgeChainBody<TME, Fast, false, true> Bc{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, nullptr,
+                                                                      A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
+                                                                      A.Del2RelVortVertex, A.NormalStressEdge, UTend,
+                                                                      M.IrregularEdges, EU};
+                        const int NO = FoldL3 ? NOther : 0, NC = FoldChain ? M.NIrregularEdges : 0;
+                        if (NO > 0 && NC > 0)
+                           launchTileV(K, S, Bs, M.NCellsAll, Bm, NO, Bc, NC);
+                        else if (NC > 0)
+                           launchTileV(K, S, Bs, M.NCellsAll, Bc, NC);
+                        else
+                           launchTileV(K, S, Bs, M.NCellsAll, Bm, NO);
+                        return;
+                     }
+                     launchTile(Bs, M.NCellsAll, K, S);
+                     return;
+                  };
+                  if constexpr (TME <= 7) {
+                     // option TracerPatch: the tracer loop's neighbour values through LDS tile patches (16-byte accesses,
+                     // line-wide thread geometry and a tile size the mesh has patch tables for); the lists keep their bodies
+                     const int NList = (CanWide && FoldL3 ? NWide : 0) + (FoldL3 ? NOther : 0) + (FoldChain ? M.NIrregularEdges : 0);
+                     const Geom Gp   = makeGeom(M.NCellsAll + NList, K, 2, levelPitch(K), NT <= 8 ? 16 : 0);
+                     const int Slot  = MeshView::patchSlot(Gp.Tile);
+                     if (Tn.TracerPatch && Gp.W == 2 && Gp.Block.x == 8 && Slot >= 0 && (int)Gp.Block.y == Gp.Tile) {
+                        CellPVFinalTracerPatchBody<TME, ND, FLS> BP{{BF}, M.PatchRows[Slot], M.PatchIdx[Slot], M.PatchOK[Slot],
+                                                                   M.PatchNP[Slot]};
+                        LaunchSweep(BP);
                         return;
                      }
                   }
-                  if (FoldL3 || FoldChain) { // (no wide cells: the sweep, the other valence's final pass, the irregular edges)
-                     constexpr int NM1f = ND == TME ? TME - 1 : TME;
-                     CellPVFinalBody<TME, NM1f, false> Bm{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
-                                                           A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell,
-                                                           A.Del2DivCell, A.Del2RelVortVertex, UTend, OtherCells, EU};
-                     FusedEdgeChainBody<TME, Fast, false, true> Bc{M, K, P, H, U, A.RelVortVertex, A.InvThickVertex, nullptr,
-                                                                   A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
-                                                                   A.Del2RelVortVertex, A.NormalStressEdge, UTend,
-                                                                   M.IrregularEdges, EU};
-                     const int NO = FoldL3 ? NOther : 0, NC = FoldChain ? M.NIrregularEdges : 0;
-                     if (NO > 0 && NC > 0)
-                        launchTileV(K, S, BF, M.NCellsAll, Bm, NO, Bc, NC);
-                     else if (NC > 0)
-                        launchTileV(K, S, BF, M.NCellsAll, Bc, NC);
-                     else
-                        launchTileV(K, S, BF, M.NCellsAll, Bm, NO);
-                     return;
-                  }
-                  launchTile(BF, M.NCellsAll, K, S);
+                  LaunchSweep(BF);
                   return;
                }
             }
@@ -2504,7 +2735,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       bool Done = false;
       if constexpr (Fast) {
          if (Stage) {
-            FusedCell3Body<TME, true, true> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
+            FusedCell3Body<TME, true, true, FLL> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
             if (Stage->AfterBand && M.NBandCells > 0) {
                B.List = BandList;
                launchTile(B, NBandList, K, BandS());
@@ -2521,7 +2752,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          }
       }
       if (!Done) {
-         FusedCell3Body<TME, Fast> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
+         FusedCell3Body<TME, Fast, false, FLL> B{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend};
          launchTile(B, M.NCellsAll, K, S);
       }
    }
@@ -2555,13 +2786,15 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
 #define OMEGA_NARROW_CASE(MN_)                                                                                     \
    case MN_:                                                                                                       \
       if (Fast)                                                                                                    \
-         launchFusedT<MN_, true>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage, &M); \
+         launchFusedT<MN_, true, MN_, true>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, Stage, &M); \
       else                                                                                                         \
-         launchFusedT<MN_, false>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr, &M); \
+         launchFusedT<MN_, false, MN_, true>(*Narrow, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr, &M); \
       return true;
+#ifndef OMEGA_ONLY_ME6
          OMEGA_NARROW_CASE(5)
          OMEGA_NARROW_CASE(6)
          OMEGA_NARROW_CASE(7)
+#endif
 #undef OMEGA_NARROW_CASE
       default:
          break;
@@ -2587,10 +2820,14 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
          launchFusedT<ME_, false>(M, K, NT, P, A, HTend, UTend, TrTend, H, U, Tr, S, Ev, EdgeScratch, nullptr);    \
       break;
    switch (M.MaxEdges) {
+#ifndef OMEGA_ONLY_ME6 // (measurement builds of a kernel experiment: hexagon meshes only, a quarter of the compile time)
       OMEGA_CASE(5)
+#endif
       OMEGA_CASE(6)
+#ifndef OMEGA_ONLY_ME6
       OMEGA_CASE(7)
       OMEGA_CASE(8)
+#endif
    default:
       return false; // callers check fusedRHSSupported()
    }

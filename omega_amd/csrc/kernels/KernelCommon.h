@@ -200,6 +200,12 @@ template <class B> __device__ __forceinline__ void chunkFence() {
       __asm__ volatile("" ::: "memory");
 #endif
 }
+template <class B, class = void> struct BodyCooperative {
+   static constexpr bool V = false;
+};
+template <class B> struct BodyCooperative<B, std::enable_if_t<B::Cooperative>> {
+   static constexpr bool V = true;
+};
 template <class B, class = void> struct BodyMinWaves {
    static constexpr int V = 1;
 };
@@ -245,12 +251,15 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
 #ifdef OMEGA_STAGE_ONLY // measurement build: what the staging of the tables costs (time, HBM bytes)
    return;
 #endif
-   for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-      for (int Kv = C0 * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * CS)
-      {
-         chunkFence<Body>();
-         B.template compute<T>(L, Le, First + Le, Kv);
-      }
+   if constexpr (BodyCooperative<Body>::V) { // bodies with workgroup barriers walk the tile themselves, all threads
+      B.template computeTile<T>(L, First, Cnt, C0, CS, KV);
+   } else {
+      for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+         for (int Kv = C0 * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * CS) {
+            chunkFence<Body>();
+            B.template compute<T>(L, Le, First + Le, Kv);
+         }
+   }
 }
 
 /// Two INDEPENDENT sweeps in one launch: the first NTilesA workgroups run body A over its tiles, the others body B.
@@ -329,6 +338,18 @@ template <class B, class = void> struct BodyHasKLog {
 template <class B> struct BodyHasKLog<B, decltype((void)std::declval<B &>().KLog)> {
    static constexpr bool V = true;
 };
+/// Bodies that keep per-wavefront areas in LDS (the prefetch slots of CellPVFinalTracerBody) declare `int NWv`: the
+/// launchers set it to the wavefronts per workgroup before asking for ldsBytes().
+template <class B, class = void> struct BodyHasNWv {
+   static constexpr bool V = false;
+};
+template <class B> struct BodyHasNWv<B, decltype((void)std::declval<B &>().NWv)> {
+   static constexpr bool V = true;
+};
+template <class B> inline void setWaves(B &Body, const Geom &G) {
+   if constexpr (BodyHasNWv<B>::V)
+      Body.NWv = (int)(G.Block.x * G.Block.y + 63) / 64;
+}
 /// Sweep of elements [0, N) x K levels.  Every body addresses rows through its member `K`, which this launcher
 /// sets to the row pitch of the arrays (levelPitch(K) for the library's own arrays; Pitch >= K for caller-owned
 /// ones, e.g. compact raw arrays of the C ABI); bodies that also need the level COUNT (bottom level of the drag
@@ -349,6 +370,7 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
    if constexpr (BodyHasKLog<Body>::V)
       B.KLog = K;
    Geom G           = makeGeom(N, K, BodyMaxW<Body>::V, B.K, bodyMaxTY(B));
+   setWaves(B, G);
    const size_t Lds = B.ldsBytes(G.Tile);
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
@@ -382,6 +404,7 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
    const int TyA = bodyMaxTY(A), TyB = bodyMaxTY(Bb);
    Geom G        = makeGeom(NA + NB, K, BodyMaxW<BA>::V, A.K, TyA > TyB ? TyA : TyB);
    const int NTA = (NA + G.Tile - 1) / G.Tile, NTB = (NB + G.Tile - 1) / G.Tile;
+   setWaves(A, G), setWaves(Bb, G);
    const size_t LA = A.ldsBytes(G.Tile), LB = Bb.ldsBytes(G.Tile), Lds = LA > LB ? LA : LB;
    // tail split on the second body's last tiles (the combined sweep's last, partial round of workgroups)
    int NFullB = NTB, TailSplit = 1;
@@ -432,11 +455,15 @@ __device__ __forceinline__ void runSweep(const SweepPlan &Pl, int KV, int Tile, 
       if (Cnt > 0)
          Body.stage(L, First, Cnt, Tid, blockDim.x * blockDim.y);
       __syncthreads();
-      for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y) {
-            chunkFence<B>();
-            Body.template compute<T>(L, Le, First + Le, Kv);
-         }
+      if constexpr (BodyCooperative<B>::V) {
+         Body.template computeTile<T>(L, First, Cnt, blockIdx.y, gridDim.y, KV);
+      } else {
+         for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
+            for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y) {
+               chunkFence<B>();
+               Body.template compute<T>(L, Le, First + Le, Kv);
+            }
+      }
       return;
    }
    if constexpr (sizeof...(Rest) > 0)
@@ -482,6 +509,7 @@ template <class B0, class B1> void launchTileV(int K, hipStream_t S, const B0 &A
    }
    if (Pl.TileStart[2] == 0)
       return;
+   setWaves(X0, G), setWaves(X1, G);
    const size_t L0 = X0.ldsBytes(G.Tile), L1 = X1.ldsBytes(G.Tile), Lds = L0 > L1 ? L0 : L1;
    const dim3 Grid(Pl.TileStart[2], G.TailSplit > 1 ? 1 : G.Grid.y, 1);
    if constexpr (BodyMaxW<B0>::V >= 2) {
@@ -517,6 +545,7 @@ void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N
    }
    if (Pl.TileStart[3] == 0)
       return;
+   setWaves(X0, G), setWaves(X1, G), setWaves(X2, G);
    size_t Lds = X0.ldsBytes(G.Tile);
    Lds        = X1.ldsBytes(G.Tile) > Lds ? X1.ldsBytes(G.Tile) : Lds;
    Lds        = X2.ldsBytes(G.Tile) > Lds ? X2.ldsBytes(G.Tile) : Lds;

@@ -329,6 +329,60 @@ def synthetic_state(mesh: dict, nvertlayers: int, ntracers: int, seed: int = 202
     return h, u, tr
 
 
+def _hash_uniform(seed: int, stream: int, rows: np.ndarray, k: int) -> np.ndarray:
+    """U[0, 1) for every (global row id, level): a counter-based generator (splitmix64 of seed, stream, row * k + level),
+    so that a value depends on WHICH element it belongs to and on nothing else -- not on the partition, not on how many
+    rows the caller asks for."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        key = (np.uint64(seed) * np.uint64(0x2545F4914F6CDD1D) + np.uint64(stream) * np.uint64(0x9E3779B97F4A7C15)) & M
+        x = rows.astype(np.uint64)[:, None] * np.uint64(k) + np.arange(k, dtype=np.uint64)[None, :]
+        z = (x + key) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def synthetic_state_rows(mesh: dict, nvertlayers: int, ntracers: int, cell_rows, edge_rows, seed: int = 20251003,
+                         tracers=None):
+    """The synthetic state of synthetic_state() -- the same smooth fields, h strictly > 1 -- for the given GLOBAL
+    (0-based) cell and edge ids only, with noise that is a function of (global id, level) alone: a rank of a partitioned
+    run builds exactly its local rows, never a global [nCells, K] array, and an N = 1 and an N = 8 run hold the same
+    value for the same element, bit for bit (the reference initialises the state per task too,
+    components/omega/src/ocn/OceanState.cpp:65-117).  Returns h [len(cell_rows), K], u [len(edge_rows), K],
+    tr [NT, len(cell_rows), K] (`tracers`: an iterable of tracer indices to build instead of all)."""
+    K = nvertlayers
+    c = np.asarray(cell_rows, dtype=np.int64)
+    e = np.asarray(edge_rows, dtype=np.int64)
+    lev = 1.0 + 0.05 * np.arange(K) / max(K, 1)
+    if mesh.get("on_a_sphere", False):
+        lonC, latC, lonE, latE = mesh["lonCell"][c], mesh["latCell"][c], mesh["lonEdge"][e], mesh["latEdge"][e]
+        sC = np.cos(lonC) * np.cos(latC) ** 4
+        ux = -np.sin(lonE) ** 2 * np.cos(latE) ** 3
+        uy = -4 * np.sin(lonE) * np.cos(lonE) * np.cos(latE) ** 3 * np.sin(latE)
+    else:
+        ax, ay = 2 * np.pi / mesh["x_period"], 2 * np.pi / mesh["y_period"]
+        sC = np.cos(ax * mesh["xCell"][c]) * np.cos(ay * mesh["yCell"][c])
+        ux = np.sin(ax * mesh["xEdge"][e]) * np.cos(ay * mesh["yEdge"][e])
+        uy = np.cos(ax * mesh["xEdge"][e]) * np.sin(ay * mesh["yEdge"][e])
+
+    def fill(rows, col_base, amp, offset, stream):
+        out = _hash_uniform(seed, stream, rows, K)
+        out *= 2.0 * amp
+        out += offset - amp
+        out += col_base[:, None] * lev
+        return out
+    h = fill(c, 0.5 * sC, 0.1, 2.0, 0)
+    un = np.cos(mesh["angleEdge"][e]) * ux + np.sin(mesh["angleEdge"][e]) * uy
+    u = fill(e, un, 0.01, 0.0, 1)
+    which = list(range(max(ntracers, 1))) if tracers is None else list(tracers)
+    tr = np.empty((len(which), len(c), K))
+    for n, l in enumerate(which):
+        tr[n] = fill(c, -sC, 0.05, 2.0 + 0.1 * l, 2 + l)
+    return h, u, tr
+
+
 # ---------------------------------------------------------------------------------------
 # Spherical Voronoi mesh (quasi-uniform, pentagons / hexagons / heptagons)
 # ---------------------------------------------------------------------------------------

@@ -1,0 +1,118 @@
+"""BASELINE configs[4] -- the oRRS18to6-sized mesh (planar 1924 x 1924 = 3 701 776 cells), 80 levels, 37 tracers, 8 GPUs --
+assembled at its stated size: the 8-way graph partition, every rank's Decomp and Halo on the host (no device), and ONE real
+rank of it on the GPU (halo included, 37 tracers, ~ 60 GB of arrays) with a wire that moves nothing.
+
+The reference reads and partitions the mesh in a distributed way and initialises the state per task
+(components/omega/src/base/Decomp.cpp:108-395 readMesh, :868-1000 partition + scatter; src/ocn/OceanState.cpp:65-117);
+here every rank holds the global connectivity (5.5 GB of host memory at this size) and builds only its own rows of the
+state (meshgen.synthetic_state_rows)."""
+import numpy as np
+import pytest
+
+import omega_amd as oa
+from omega_amd.meshgen import planar_hex, synthetic_state_rows
+
+NX, K, NT, NPARTS, HALO = 1924, 80, 37, 8, 4
+
+
+@pytest.fixture(scope="module")
+def big():
+    g = planar_hex(NX, NX, 6.0e3)
+    gm = oa.GlobalMesh(g)
+    cell_task, cut = oa.partition_cells(gm, NPARTS, "graph")
+    return g, gm, cell_task, cut
+
+
+def test_eight_way_partition_decomp_and_halo_of_the_full_mesh_on_the_host(big):
+    g, gm, cell_task, cut = big
+    sizes = np.bincount(cell_task, minlength=NPARTS)
+    assert sizes.min() > 0 and sizes.max() <= 1.03 * g["nCells"] / NPARTS, sizes   # the partitioner's 3 % tolerance
+    assert cut < 4 * 8 * NX                                                          # a few straight cuts' worth of edges
+    own_sum = np.zeros(3, dtype=object)
+    for r in range(NPARTS):
+        d = oa.Decomp(gm, NPARTS, r, HALO, cell_task=cell_task, local_order="kd")
+        for i, (arr, n) in enumerate((("CellID", "NCellsOwned"), ("EdgeID", "NEdgesOwned"), ("VertexID", "NVerticesOwned"))):
+            own_sum[i] += int(d.get_array(arr)[: d.get_int(n)].astype(np.int64).sum())
+        h = oa.Halo(d)
+        nbrs = h.neighbors
+        assert 1 <= len(nbrs) <= 32, nbrs                                            # PeerWire::MaxPeers
+        rows = h.recv_rows(1 + NT, 1, 0)                                             # h + 37 tracers on cells, u on edges
+        mailbox = rows * K * 8
+        assert 0 < mailbox < 1 << 30, mailbox                                        # ~ 280 MB per rank: one hipMalloc, one IPC handle
+        # 32-bit job table of the pack / unpack kernels (Halo.cpp: plane = tracer * RowsSize + row) and the fused RHS's
+        # 32-bit byte offsets inside one array plane (FusedKernels.hip: BufOOB)
+        assert NT * (d.get_int("NCellsAll") + 1) < 1 << 31
+        assert (d.get_int("NEdgesAll") + 1) * K * 8 < 0xffffff00
+        assert d.get_int("NCellsAll") < 1.05 * d.get_int("NCellsOwned")             # HaloWidth 4: ~ 2.3 % more cells
+    n = [g["nCells"], g["nEdges"], g["nVertices"]]
+    assert [int(x) for x in own_sum] == [m * (m + 1) // 2 for m in n]              # every element owned exactly once
+
+
+@pytest.mark.gpu
+def test_one_real_rank_of_the_eight_on_the_gpu(big):
+    g, gm, cell_task, _ = big
+    oa.device_init(0)
+    rank = 3
+    d = oa.Decomp(gm, NPARTS, rank, HALO, cell_task=cell_task, local_order="kd")
+    mesh = oa.HorzMesh(d, K)
+    halo = oa.Halo(d)
+    halo.set_transport(lambda *a: 0)             # a wire that moves nothing (tools/probes/send_band.py)
+    for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK", "Del2VertOK"):
+        assert mesh.get_int(f) == 1
+    cells0 = d.get_array("CellID")[: mesh.NCellsAll] - 1
+    edges0 = d.get_array("EdgeID")[: mesh.NEdgesAll] - 1
+    kp = oa.level_pitch(K)
+    hh, uu, _ = synthetic_state_rows(g, K, 0, cells0, edges0, tracers=[])
+    h = np.zeros((mesh.NCellsSize, K)); h[: mesh.NCellsAll] = hh
+    u = np.zeros((mesh.NEdgesSize, K)); u[: mesh.NEdgesAll] = uu
+    state = oa.OceanState(mesh, halo, K, 2)
+    tracers = oa.Tracers(mesh, halo, K, NT, 2)
+    aux = oa.AuxiliaryState(mesh, halo, K, NT)
+    tend = oa.Tendencies(mesh, K, NT, oa.default_config())
+    state.copy_to_device(h, u, 0)
+
+    def upload(scale=1.0):
+        for l in range(NT):   # one tracer at a time: 37 of them are 11 GB
+            t2 = synthetic_state_rows(g, K, NT, cells0, edges0[:0], tracers=[l])[2][0]
+            buf = np.zeros((mesh.NCellsSize, kp)); buf[: t2.shape[0], :K] = t2 * scale
+            oa.copy_to_device(tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp, buf)
+    upload()
+    nc, ne = mesh.NCellsOwned, mesh.NEdgesOwned
+    tend.compute_all_tendencies(state, aux, tracers)
+    oa.device_synchronize()
+    hT, uT = tend.get(0)[:nc].copy(), tend.get(1)[:ne].copy()
+    trT = tend.get(2)[[0, 17, 36], :nc].copy()
+    assert np.isfinite(hT).all() and np.isfinite(uT).all() and np.isfinite(trT).all() and np.abs(trT).max() > 0
+    # determinism, and the reference-structured launch sequence gives the same bits on owned elements
+    tend.compute_all_tendencies(state, aux, tracers)
+    oa.device_synchronize()
+    assert np.array_equal(tend.get(0)[:nc], hT) and np.array_equal(tend.get(1)[:ne], uT)
+    tend.set_fused(False)
+    tend.compute_all_tendencies(state, aux, tracers)
+    oa.device_synchronize()
+    assert np.array_equal(tend.get(0)[:nc], hT) and np.array_equal(tend.get(1)[:ne], uT)
+    assert np.array_equal(tend.get(2)[[0, 17, 36], :nc], trT)
+    tend.set_fused(True)
+    # the tracer tendency is linear in the tracer: a power of two scales it exactly
+    upload(4.0)
+    tend.compute_all_tendencies(state, aux, tracers)
+    oa.device_synchronize()
+    assert np.array_equal(tend.get(2)[[0, 17, 36], :nc], 4.0 * trT)
+    upload()
+    # two overlapped RK4 steps of the rank: band / interior launches, pack and unpack of a 280 MB exchange on the
+    # communication stream.  Nothing arrives -- the unpack kernel copies the (zeroed) receive buffer into the halo, so zeros
+    # and then NaNs walk inwards from the rim, two cells per evaluation: 16 cells in two steps.  What is checked is that
+    # the sequence runs at this size with every resource created beforehand, and that the owned cells it cannot have
+    # reached (most of the 680-cell-wide part) hold a finite, positive thickness.
+    st = oa.TimeStepper("RungeKutta4", 120.0 * (6.0 / 30.0) ** 2, tend, aux, mesh, halo, tracers)
+    st.set_option("OverlapHaloExchange", True)
+    stream = oa.Stream()
+    n_res = oa.device_resource_count()
+    for _ in range(2):
+        st.do_step(state, stream=stream)
+    oa.device_synchronize()
+    assert oa.device_resource_count() == n_res
+    h1, _ = state.copy_to_host(0)
+    ok = np.isfinite(h1[:nc]).all(axis=1)
+    assert ok.mean() > 0.8, ok.mean()
+    assert h1[:nc][ok].min() > 0.5
