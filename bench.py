@@ -63,6 +63,10 @@ WORKLOADS = {
     "fib7_coast": (0, -163842, 0.0, 80, 6, "relaxed Fibonacci sphere (valences 5, 6, 7) of 163842 cells with 28 % land removed, "
                                            "80L, 6 tracers"),
     "small_coast": (96, 96, 30.0e3, 80, 6, "small smoke workload 96x96 with 28 % land removed, 80L, 6 tracers"),
+    # a mesh file whose per-cell lists are not in ring order for 1 % of the cells (meshgen.permute_cell_slots): those cells
+    # run through the generic per-cell bodies (MeshView::BadCells), everything else keeps the fast kernels
+    "hex405_perm1": (404, 406, 49.0e3, 80, 6, "the hex405 mesh with two slots of edgesOnCell / cellsOnCell / verticesOnCell "
+                                             "swapped in 1 % of the cells, 80L, 6 tracers"),
 }
 
 
@@ -226,6 +230,9 @@ def main():
     if args.workload.endswith("_coast"):
         from omega_amd.meshgen import coast_mask, cull
         g = cull(g, coast_mask(g, "continents"))
+    if args.workload.endswith("_perm1"):
+        from omega_amd.meshgen import permute_cell_slots
+        g = permute_cell_slots(g, 0.01)
     if args.max_edges > g["maxEdges"]:
         from omega_amd.meshgen import pad_max_edges
         g = pad_max_edges(g, args.max_edges)
@@ -420,7 +427,8 @@ def main():
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
                           "kernel_paths": {f: mesh.get_int(f) for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK",
-                                                                        "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1")},
+                                                                        "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1",
+                                                                        "NBadCells")},
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
                           "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else

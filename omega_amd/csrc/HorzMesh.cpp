@@ -331,9 +331,16 @@ void HorzMesh::buildCoefficientTables() {
          }
          int Prev = E;
          for (int Kk = 1; Kk < N; ++Kk) {
-            const int Ep = EdgesOnCellH(Cs, (P0 + Kk) % N);
-            // the walk must reproduce EdgesOnEdge(E, :) entry by entry
-            if (Pos >= ME2 || EdgesOnEdgeH(E, Pos) != Ep) {
+            // the next entries of EdgesOnEdge(E, :) are the other edges of this side's cell, each sharing a vertex with its
+            // predecessor (MPAS writes them walking around the cell).  The chain is taken from EdgesOnEdge itself, not
+            // from the cell's EdgesOnCell list: a cell whose own list is not in ring order then only loses its own ring
+            // tables (buildCellPV compares the two and marks it, MeshView::BadCells), not the mesh its chain form.
+            if (Pos >= ME2) {
+               ChainOK = false;
+               break;
+            }
+            const int Ep = EdgesOnEdgeH(E, Pos);
+            if (Ep < 0 || Ep >= NEdgesAll || (CellsOnEdgeH(Ep, 0) != Cs && CellsOnEdgeH(Ep, 1) != Cs)) {
                ChainOK = false;
                break;
             }
@@ -421,9 +428,16 @@ void HorzMesh::buildCoefficientTables() {
    W.PVChainWeight = PVChainWeight.Ptr;
    HostChV = ChV, HostChF = ChF, HostChE = ChE, HostNbrF = NbrF;
    HostChW = ChW;
-   buildCellPV();
-   buildDel2Tables();
-   buildCellL1Tables();
+   CellBad.assign(NCellsSize, 0);
+   for (int Pass = 0; Pass < 8; ++Pass) { // (a pass that finds a new bad cell is followed by one that knows it)
+      NewBad = false;
+      buildDel2Tables();
+      buildCellPV();
+      buildCellL1Tables();
+      if (!NewBad)
+         break;
+   }
+   publishBadCells();
    buildBandLists((I4)NCellsHaloH.size());
    buildPatchTables();
    buildNarrowTables();
@@ -462,7 +476,7 @@ void HorzMesh::buildNarrowTables() {
    // worth it (and possible) when the sweeps already run at MaxEdges-1 and every ring table is valid; the kernels are
    // instantiated for 5..8 slots
    if (!(tuning().NarrowTables != 0 && W.DomM1 && ME >= 6 && ME <= 8 && W.CellL1OK && W.CellPVOK && W.CellPVFinalOK &&
-         W.Del2RingOK && W.Del2VertOK))
+         W.Del2RingOK && W.Del2VertOK && W.NBadCells == 0))
       return; // (no wide cell at all -- tables kept at a file's width by the option KeepMaxEdges -- is fine too)
    const int MN = ME - 1;
    Narrow       = View;
@@ -496,6 +510,29 @@ void HorzMesh::buildNarrowTables() {
    N.DomM1        = 0;
    N.NWideCells   = 0; // (the list lives in the wide view)
    HasNarrow      = true;
+}
+
+void HorzMesh::publishBadCells() {
+   MeshView &W = View;
+   std::vector<I4> Bad, NRing(NCellsSize, 0);
+   for (int C = 0; C < NCellsAll; ++C) {
+      NRing[C] = CellBad[C] ? 99 : NEdgesOnCellH(C);
+      if (CellBad[C])
+         Bad.push_back(C);
+   }
+   if (!W.CellL1OK) // (the list of vertices the merged level-1 kernel leaves out only exists with its tables)
+      Orphans.clear();
+   BadCellsD         = Array1DI4("BadCells", (int)std::max<size_t>(Bad.size(), 1));
+   OrphanVerticesD   = Array1DI4("OrphanVertices", (int)std::max<size_t>(Orphans.size(), 1));
+   NEdgesOnCellRingD = Array1DI4("NEdgesOnCellRing", NCellsSize);
+   if (!Bad.empty())
+      OMEGA::copyToDevice(BadCellsD.Ptr, Bad.data(), Bad.size() * sizeof(I4));
+   if (!Orphans.empty())
+      OMEGA::copyToDevice(OrphanVerticesD.Ptr, Orphans.data(), Orphans.size() * sizeof(I4));
+   OMEGA::copyToDevice(NEdgesOnCellRingD.Ptr, NRing.data(), NRing.size() * sizeof(I4));
+   W.NBadCells = (I4)Bad.size(), W.BadCells = BadCellsD.Ptr;
+   W.NOrphanVertices = (I4)Orphans.size(), W.OrphanVertices = OrphanVerticesD.Ptr;
+   W.NEdgesOnCellRing = NEdgesOnCellRingD.Ptr;
 }
 
 // Tile patches (see HorzMesh.h): rows in order of first appearance (the tile's own cells first).
@@ -608,16 +645,27 @@ void HorzMesh::buildDel2Tables() {
    HostArrayReal GradS(NCellsSize, ME, 1, 0.0), IDcC(NCellsSize, ME, 1, 0.0), CurlC(NCellsSize, ME, 1, 0.0);
    bool RingOK = true;
    auto InvDv2 = [&](int E) { return 1. / std::max(DvEdgeH(E), 0.25 * DcEdgeH(E)); }; // VelocityDel2AuxVars.h:32-33
-   for (int C = 0; C < NCellsAll && RingOK; ++C) {
+   for (int C = 0; C < NCellsAll; ++C) {
       const int N = NEdgesOnCellH(C);
-      if (N < 3 || N > ME) {
-         RingOK = false;
-         break;
+      // a cell the ring form cannot describe: left out of the ring tables (sentinel vertices, zero coefficients) and marked
+      auto Bad = [&]() {
+         markBad(C);
+         for (int J = 0; J < ME; ++J)
+            Ring(C, J) = NVerticesAll, GradS(C, J) = IDcC(C, J) = CurlC(C, J) = 0.0;
+      };
+      if (CellBad[C]) {
+         Bad();
+         continue;
       }
-      for (int J = 0; J < N; ++J) {
+      if (N < 3 || N > ME) {
+         Bad();
+         continue;
+      }
+      bool CellOK = true;
+      for (int J = 0; J < N && CellOK; ++J) {
          const int E = EdgesOnCellH(C, J), En = EdgesOnCellH(C, (J + 1) % N);
          if (E >= NEdgesAll || En >= NEdgesAll) {
-            RingOK = false;
+            CellOK = false;
             break;
          }
          int Shared = -1;
@@ -625,35 +673,35 @@ void HorzMesh::buildDel2Tables() {
             for (int B = 0; B < 2; ++B)
                if (VerticesOnEdgeH(E, A) == VerticesOnEdgeH(En, B) && VerticesOnEdgeH(E, A) < NVerticesAll)
                   Shared = VerticesOnEdgeH(E, A);
-         if (Shared < 0) {
-            RingOK = false;
-            break;
-         }
+         if (Shared < 0)
+            CellOK = false;
          Ring(C, J) = Shared;
       }
-      if (!RingOK)
-         break;
+      if (!CellOK) {
+         Bad();
+         continue;
+      }
       for (int J = N; J < ME; ++J)
          Ring(C, J) = Ring(C, N - 1); // so that slot 0 finds its first vertex at index ME-1
-      for (int J = 0; J < N; ++J) {
+      for (int J = 0; J < N && CellOK; ++J) {
          const int E  = EdgesOnCellH(C, J);
          const int Vb = Ring(C, J), Va = Ring(C, (J + N - 1) % N);
-         Real SV;
+         Real SV = 0.0;
          if (VerticesOnEdgeH(E, 1) == Vb && VerticesOnEdgeH(E, 0) == Va)
             SV = 1.0;
          else if (VerticesOnEdgeH(E, 0) == Vb && VerticesOnEdgeH(E, 1) == Va)
             SV = -1.0;
-         else {
-            RingOK = false;
-            break;
-         }
+         else
+            CellOK = false;
          const Real SC = CellsOnEdgeH(E, 0) == C ? 1.0 : -1.0;
          if (CellsOnEdgeH(E, 0) != C && CellsOnEdgeH(E, 1) != C)
-            RingOK = false;
+            CellOK = false;
          GradS(C, J) = EdgeMask1DH(E) * SC;
          IDcC(C, J)  = 1. / DcEdgeH(E);
          CurlC(C, J) = -SV * InvDv2(E);
       }
+      if (!CellOK)
+         Bad();
    }
    HostArrayI4 NbrV(NVerticesSize, VD, 1, NVerticesAll), Sel(NVerticesSize, VD, 1, 0);
    HostArrayReal MaskV(NVerticesSize, VD, 1, 0.0), IDcV(NVerticesSize, VD, 1, 0.0), CurlV(NVerticesSize, VD, 1, 0.0);
@@ -721,7 +769,10 @@ void HorzMesh::buildCellL1Tables() {
    std::vector<I4> Owner(NVerticesAll, -1), OwnerSlot(NVerticesAll, -1), NOwned(NCellsAll, 0);
    for (int C = 0; C < NCellsAll && OK; ++C) {
       const int N = NEdgesOnCellH(C);
-      for (int R = 0; R < N && OK; ++R) {
+      if (CellBad[C])
+         continue; // (served by the generic bodies: no cell-side vertex tables, owns no vertex)
+      bool CellOK = true;
+      for (int R = 0; R < N && CellOK; ++R) {
          const int V  = HostVertRing(C, R);
          const int E0 = EdgesOnCellH(C, R), E1 = EdgesOnCellH(C, (R + 1) % N);
          const int N0 = HostNbrF(C, R) & 0x3fffffff, N1 = HostNbrF(C, (R + 1) % N) & 0x3fffffff;
@@ -730,7 +781,7 @@ void HorzMesh::buildCellL1Tables() {
          // t0 + t1 commutes, so all the cell side needs is each role's coefficient and WHICH ROLE IS LAST.
          int Sp = NEdgesAll, LastC = -1, LastE = -1;
          bool SeenC[3] = {false, false, false}, SeenE[3] = {false, false, false};
-         for (int J = 0; J < 3 && OK; ++J) {
+         for (int J = 0; J < 3 && CellOK; ++J) {
             const int Cv = CellsOnVertexH(V, J), Ev = EdgesOnVertexH(V, J);
             int Rc = -1, Re = -1;
             if (Cv == C && !SeenC[0])
@@ -746,7 +797,7 @@ void HorzMesh::buildCellL1Tables() {
             else if (!SeenE[2] && (Ev >= NEdgesAll || (Ev != E0 && Ev != E1)))
                Re = 2, Sp = Ev; // the spoke, or no third edge here (sentinel row)
             if (Rc < 0 || Re < 0) {
-               OK = false;
+               CellOK = false;
                break;
             }
             SeenC[Rc] = SeenE[Re] = true;
@@ -755,8 +806,17 @@ void HorzMesh::buildCellL1Tables() {
             if (J == 2)
                LastC = Rc, LastE = Re;
          }
+         if (!CellOK)
+            break;
          Spoke(C, R) = Sp;
          Sel(C, R)   = LastC | (LastE << 2);
+      }
+      if (!CellOK) { // this cell's ring does not match its vertices' lists: a bad cell from the next pass on
+         markBad(C);
+         continue;
+      }
+      for (int R = 0; R < N; ++R) {
+         const int V = HostVertRing(C, R);
          // ownership: the cell with the fewest stores so far among those that see the vertex
          if (Owner[V] < 0 || NOwned[C] < NOwned[Owner[V]] - 1) {
             if (Owner[V] >= 0)
@@ -766,9 +826,10 @@ void HorzMesh::buildCellL1Tables() {
          }
       }
    }
+   Orphans.clear();
    for (int V = 0; V < NVerticesAll && OK; ++V) {
       if (Owner[V] < 0)
-         OK = false; // a local vertex no local cell has in its ring
+         Orphans.push_back(V); // no good local cell has it in its ring: the vertex kernel computes it (list launch)
       else
          Sel(Owner[V], OwnerSlot[V]) |= 1 << 4;
    }
@@ -781,8 +842,8 @@ void HorzMesh::buildCellL1Tables() {
    // the PV tables number the ring the same way (they are only filled for cells that own regular edges)
    for (int C = 0; C < NCellsAll && OK; ++C)
       for (int R = 0; R < NEdgesOnCellH(C); ++R)
-         if (HostPVRole(C, R) != 0 && HostPVRing(C, R) != HostVertRing(C, R))
-            OK = false;
+         if (!CellBad[C] && HostPVRole(C, R) != 0 && HostPVRing(C, R) != HostVertRing(C, R))
+            markBad(C);
    W.CellL1OK = OK && W.CellPVOK ? 1 : 0;
 }
 
@@ -800,15 +861,16 @@ void HorzMesh::buildCellPV() {
       for (int E = 0; E < NEdgesAll; ++E) {
          const int C0 = CellsOnEdgeH(E, 0), C1 = CellsOnEdgeH(E, 1);
          const bool R = EdgeMask1DH(E) != 0.0 && C0 < NCellsAll && C1 < NCellsAll && ValenceOK(NEdgesOnCellH(C0)) &&
-                        ValenceOK(NEdgesOnCellH(C1));
+                        ValenceOK(NEdgesOnCellH(C1)) && !CellBad[C0] && !CellBad[C1];
          Reg(E) = R ? 1 : 0;
          if (!R)
             Irregular.push_back(E);
       }
       for (int C = 0; C < NCellsAll && OK; ++C) {
          const int N = NEdgesOnCellH(C);
-         if (!ValenceOK(N))
+         if (!ValenceOK(N) || CellBad[C])
             continue; // all its edges are irregular
+         bool CellOK = true;
          for (int Kk = 0; Kk < N; ++Kk) {
             const int E = EdgesOnCellH(C, Kk);
             if (E >= NEdgesAll || !Reg(E))
@@ -818,22 +880,27 @@ void HorzMesh::buildCellPV() {
             // the chain of (E, Sd) must be the walk around this cell starting after slot Kk
             for (int J = 1; J < N; ++J) {
                if (HostChE.V[((size_t)E * 2 + Sd) * MEm1 + J - 1] != EdgesOnCellH(C, (Kk + J) % N))
-                  OK = false;
+                  CellOK = false;
                Wt.V[((size_t)C * ME + Kk) * MEm1 + J - 1] = HostChW.V[((size_t)E * 2 + Sd) * MEm1 + J - 1];
             }
             // vertex between slot Kk and slot Kk+1 = first chain vertex of this edge on this side
             const int V = HostChV.V[((size_t)E * 2 + Sd) * ME + 0];
             if (Ring(C, Kk) != NVerticesAll && Ring(C, Kk) != V)
-               OK = false;
+               CellOK = false;
             Ring(C, Kk) = V;
             // and the remaining chain vertices are the following ring vertices
             for (int J = 1; J < N; ++J) {
                const int Vj = HostChV.V[((size_t)E * 2 + Sd) * ME + J];
                int &Slot    = Ring(C, (Kk + J) % N);
                if (Slot != NVerticesAll && Slot != Vj)
-                  OK = false;
+                  CellOK = false;
                Slot = Vj;
             }
+         }
+         if (!CellOK) { // its edges' chains do not follow the walk around it: its edges are irregular from the next pass on
+            markBad(C);
+            for (int Kk = 0; Kk < ME; ++Kk)
+               Role(C, Kk) = 0, Ring(C, Kk) = NVerticesAll;
          }
       }
    }
@@ -843,7 +910,7 @@ void HorzMesh::buildCellPV() {
    for (int C = 0; C < NCellsAll && FinalOK; ++C) {
       const int N = NEdgesOnCellH(C);
       for (int Kk = 0; Kk < N && Kk < ME; ++Kk) {
-         if (Role(C, Kk) == 0)
+         if (Role(C, Kk) == 0 || CellBad[C])
             continue;
          const int E = EdgesOnCellH(C, Kk), Vb = Ring(C, Kk), Va = Ring(C, (Kk + N - 1) % N);
          if (VerticesOnEdgeH(E, 1) == Vb && VerticesOnEdgeH(E, 0) == Va)
@@ -851,7 +918,7 @@ void HorzMesh::buildCellPV() {
          else if (VerticesOnEdgeH(E, 0) == Vb && VerticesOnEdgeH(E, 1) == Va)
             RSign(C, Kk) = -1.0;
          else
-            FinalOK = false;
+            markBad(C);
       }
    }
    RingSignOnCell = createDeviceMirrorCopy<Real, 2>("RingSignOnCell", RSign);

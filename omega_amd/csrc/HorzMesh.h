@@ -132,6 +132,16 @@ struct MeshView {
    // The level-3 kernel stages each tracer's rows of a tile once per workgroup into LDS (straight from the buffer, no
    // registers) instead of gathering them per thread: a row is loaded once, not by up to 7 threads, and the next
    // tracer's rows are in flight while this one is computed.
+   // ---- cells outside the ring tables (HorzMesh::BadCells) ----
+   // A cell whose EdgesOnCell list does not walk around the cell (consecutive slots sharing a vertex), or whose edges'
+   // EdgesOnEdge chains do not follow that walk, cannot use the ring-form tables.  The reference does not care about the
+   // order (components/omega/src/base/Decomp.cpp:2030-2064 only compacts the lists), so such a cell must not cost the
+   // mesh its fast kernels: it is served by the generic per-cell bodies over the list BadCells -- its edges are irregular
+   // (edge-centric chain kernel), the ring-form sweeps skip it (NEdgesOnCellRing holds 99 for it), the vertices no good
+   // cell stores are on OrphanVertices -- and everything else keeps the fast paths.
+   I4 NBadCells, NOrphanVertices;
+   const I4 *BadCells, *OrphanVertices;
+   const I4 *NEdgesOnCellRing; // [C] NEdgesOnCell, 99 for a bad cell
    static constexpr int NPatchSizes = 3;
    I4 PatchNP[NPatchSizes];
    const I4 *PatchRows[NPatchSizes], *PatchIdx[NPatchSizes], *PatchOK[NPatchSizes];
@@ -213,6 +223,17 @@ class HorzMesh : public Registry<HorzMesh> {
    Array1DI4 RingCellsM0, RingCellsM1, RingCellsM2, BandCells, InteriorCells, BandSendCells;
    void buildBandLists(I4 HaloWidth);
    void buildPatchTables();
+   /// cells the ring tables cannot describe (see MeshView::BadCells); the three table builders mark them and are run
+   /// again until no new one turns up
+   std::vector<char> CellBad;
+   bool NewBad = false;
+   void markBad(int C) {
+      if (!CellBad[C])
+         CellBad[C] = 1, NewBad = true;
+   }
+   void publishBadCells();
+   Array1DI4 BadCellsD, OrphanVerticesD, NEdgesOnCellRingD;
+   std::vector<I4> Orphans;
    Array1DI4 PatchRowsD[MeshView::NPatchSizes], PatchIdxD[MeshView::NPatchSizes], PatchOKD[MeshView::NPatchSizes];
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;

@@ -717,6 +717,8 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"NIrregularInner", W.NIrregularInner},
                                         {"DomM1", W.DomM1},
                                         {"NWideCells", W.NWideCells},
+                                        {"NBadCells", W.NBadCells},
+                                        {"NOrphanVertices", W.NOrphanVertices},
                                         {"NarrowTables", M.narrowView() ? 1 : 0},
                                         {"Del2RingOK", W.Del2RingOK},
                                         {"Del2VertOK", W.Del2VertOK},

@@ -17,6 +17,7 @@ struct VortVertexBody {
    const Real *H, *U;
    Real *RelVort, *NormRelVort, *NormPlanetVort, *InvThick;
    int StoreNorm, StoreInv;
+   const int *List = nullptr; // optional vertex list (MeshView::OrphanVertices)
    struct Lds {
       Real *KiteC, *VortC, *F;
       int *Cell, *Edge;
@@ -40,17 +41,22 @@ struct VortVertexBody {
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       const int VD = M.VertexDegree;
       for (int I = Tid; I < Cnt * VD; I += NThr) {
-         const size_t G = (size_t)First * VD + I;
+         size_t G = (size_t)First * VD + I;
+         if (List) {
+            const int Vl = I / VD;
+            G            = (size_t)List[First + Vl] * VD + (I - Vl * VD);
+         }
          L.KiteC[I]     = M.KiteCoefOnVertex[G];
          L.VortC[I]     = M.VortCoefOnVertex[G];
          L.Cell[I]      = M.CellsOnVertex[G];
          L.Edge[I]      = M.EdgesOnVertex[G];
       }
       for (int I = Tid; I < Cnt; I += NThr)
-         L.F[I] = M.FVertex[First + I];
+         L.F[I] = M.FVertex[List ? List[First + I] : First + I];
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int IVertex, int Kv) const {
-      const int VD = M.VertexDegree;
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      const int VD      = M.VertexDegree;
+      const int IVertex = List ? List[IElem] : IElem;
       T LayerThickVertex = splat<T>(0.0), RelVortTmp = splat<T>(0.0);
       for (int J = 0; J < VD; ++J) {
          const T Hc = ldk<T>(H, L.Cell[Le * VD + J], K, Kv);
@@ -82,6 +88,13 @@ void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Rea
                     StoreNorm ? 1 : 0,
                     StoreInv ? 1 : 0};
    launchTile(B, M.NVerticesAll, K, S);
+}
+void launchVertexAuxState1List(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S,
+                               const I4 *Vertices, int N) {
+   if (N <= 0)
+      return;
+   VortVertexBody B{M, K, H, U, A.RelVortVertex, A.NormRelVortVertex, A.NormPlanetVortVertex, A.InvThickVertex, 0, 1, Vertices};
+   launchTile(B, N, K, S);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -347,6 +347,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false,
    Real *KE, *Div, *HTend, *Del2Tr, *RelVortV, *InvThickV, *Partial;
    StageEpi E{}; // thickness stage update (EPI)
    const int *List = nullptr; // optional cell list (the wide cells of a mesh with narrow tables: launchFusedT)
+   int SkipBad     = 0;       // the mesh has cells outside the ring tables (MeshView::BadCells): skipped here
    struct Lds {
       Real *KEC, *DivC, *DvS, *D2T, *InvA, *Wt, *FV, *KC, *VC;
       int *Edge, *NbrF, *Spoke, *Sel, *Ring, *Role, *N;
@@ -419,15 +420,13 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false,
       for (int I = Tid; I < Cnt; I += NThr) {
          const int C = cellOf(First + I);
          L.InvA[I]   = M.InvAreaCell[C];
-         L.N[I]      = M.NEdgesOnCell[C];
+         L.N[I]      = M.NEdgesOnCellRing[C]; // (99 for a cell outside the ring tables)
       }
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
       const int N = L.N[Le];
-      if constexpr ((FL & 2) != 0) {
-         if (N > TME)
-            return; // a cell wider than these tables: it has its own (list) launch on the wide tables
-      }
+      if (((FL & 2) != 0 || SkipBad) && N > TME)
+         return; // a cell wider than these tables, or outside the ring tables: it has its own (list) launch
       const int ICell       = cellOf(IElem);
       const bool FluxUpwind = Fast ? false : (P.FluxThicknessUpwind != 0);
       const bool ThickOn    = Fast ? true : (P.ThicknessFluxTendencyEnable != 0);
@@ -591,6 +590,7 @@ struct FusedDel2CellBody {
    int K;
    const Real *Div, *RelVort;
    Real *Del2Div;
+   const int *List = nullptr; // optional cell list (the cells outside the ring tables: MeshView::BadCells)
    struct Lds {
       Real *DivC, *InvDc, *InvDv2, *Mask;
       int *C0, *C1, *V0, *V1, *N;
@@ -618,7 +618,11 @@ struct FusedDel2CellBody {
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       const int ME = M.MaxEdges;
       for (int I = Tid; I < Cnt * ME; I += NThr) {
-         const size_t G = (size_t)First * ME + I;
+         size_t G = (size_t)First * ME + I;
+         if (List) {
+            const int Cl = I / ME;
+            G            = (size_t)List[First + Cl] * ME + (I - Cl * ME);
+         }
          const int E    = M.EdgesOnCell[G];
          L.DivC[I]      = M.DivCoefOnCell[G];
          L.InvDc[I]     = M.InvDcEdge[E];
@@ -630,12 +634,13 @@ struct FusedDel2CellBody {
          L.V1[I]        = M.VerticesOnEdge[2 * E + 1];
       }
       for (int I = Tid; I < Cnt; I += NThr)
-         L.N[I] = M.NEdgesOnCell[First + I];
+         L.N[I] = M.NEdgesOnCell[List ? List[First + I] : First + I];
    }
-   template <class T> __device__ void compute(const Lds &L, int Le, int ICell, int Kv) const {
-      const int ME = M.MaxEdges;
-      const int N  = L.N[Le];
-      T Tmp        = splat<T>(0.0);
+   template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
+      const int ME    = M.MaxEdges;
+      const int ICell = List ? List[IElem] : IElem;
+      const int N     = L.N[Le];
+      T Tmp           = splat<T>(0.0);
       for (int J = 0; J < N; ++J) {
          const int I     = Le * ME + J;
          const T GradDiv = (ldk<T>(Div, L.C1[I], K, Kv) - ldk<T>(Div, L.C0[I], K, Kv)) * L.InvDc[I];
@@ -706,6 +711,8 @@ struct FusedDel2VertexBody {
 
 // L2 cell pass, ring form (HorzMesh::buildDel2Tables): same arithmetic as FusedDel2CellBody with
 // every row gathered once -- Div at the cell and its TME neighbours, RelVort on its TME ring vertices.
+/// (FL only names the instantiation here: this body keeps its run-time list / width tests -- with them compiled out the
+/// three-sweep launch of a mesh with narrow tables came out 23 % slower, 224 -> 276 us on the Fibonacci sphere)
 template <int TME, int FL = 3> struct Del2CellRingBody {
    static constexpr bool HoistTables = true; // (KernelCommon.h: measured 0.588 against 0.600 ms for the pair)
    MeshView M;
@@ -735,7 +742,7 @@ template <int TME, int FL = 3> struct Del2CellRingBody {
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       for (int I = Tid; I < Cnt * TME; I += NThr) {
          size_t G = (size_t)First * TME + I;
-         if ((FL & 1) && List) {
+         if (List) {
             const int Cl = I / TME;
             G            = (size_t)List[First + Cl] * TME + (I - Cl * TME);
          }
@@ -747,14 +754,12 @@ template <int TME, int FL = 3> struct Del2CellRingBody {
          L.Ring[I]      = M.VertRingOnCell[G];
       }
       for (int I = Tid; I < Cnt; I += NThr)
-         L.N[I] = M.NEdgesOnCell[((FL & 1) && List) ? List[First + I] : First + I];
+         L.N[I] = M.NEdgesOnCellRing[List ? List[First + I] : First + I];
    }
    template <class T> __device__ void compute(const Lds &L, int Le, int IElem, int Kv) const {
-      if constexpr ((FL & 2) != 0) {
-         if (L.N[Le] > TME)
-            return; // a cell wider than these tables: it has its own (list) launch on the wide tables
-      }
-      const int ICell = ((FL & 1) && List) ? List[IElem] : IElem;
+      if (L.N[Le] > TME)
+         return; // a cell wider than these tables, or outside the ring tables (99): it has its own (list) launch
+      const int ICell = List ? List[IElem] : IElem;
       T Dn[TME], Rv[TME];
 #pragma unroll
       for (int J = 0; J < TME; ++J) {
@@ -2256,7 +2261,17 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                return;
             }
          }
+         B.SkipBad = M.NBadCells > 0;
          launchTile(B, NSweepL1, K, S);
+         if (M.NBadCells > 0) {
+            // the cells outside the ring tables: the generic level-1 cell body over their list (their edges are on the
+            // irregular-edge list), and the vertices no good cell stores through the vertex kernel
+            FusedCell1Body<TME, Fast, EP> Bb{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell,
+                                             HTend, A.Del2TracersCell, EH};
+            Bb.List = M.BadCells;
+            launchTile(Bb, M.NBadCells, K, S);
+            launchVertexAuxState1List(M, K, A, H, U, S, M.OrphanVertices, M.NOrphanVertices);
+         }
       };
       auto LaunchL1 = [&](auto Epi) {
          if (InlineOther)
@@ -2337,7 +2352,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
       FusedKernelNames[2] = M.Del2RingOK ? "Del2CellRingBody" : "FusedDel2CellBody";
       if (M.Del2RingOK) {
          Del2CellRingBody<TME, FLS> BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
-         launchTile(BC, M.NCellsAll, K, S);
+            launchTile(BC, M.NCellsAll, K, S);
       } else {
          FusedDel2CellBody BC{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell};
          launchTile(BC, M.NCellsAll, K, S);
@@ -2360,6 +2375,10 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          BC.List = Wide->WideCells;
          launchTile(BC, NWide, K, S);
       }
+   }
+   if (P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.NBadCells > 0) { // the cells outside the ring tables
+      FusedDel2CellBody Bb{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell, M.BadCells};
+      launchTile(Bb, M.NBadCells, K, S);
    }
    Pacer::stop("Tend:fused:L2", 2);
    Flip();

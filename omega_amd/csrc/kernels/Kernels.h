@@ -40,6 +40,9 @@ struct TendParams {
 /// (RelVort*Inv, FVertex*Inv: one vertex array less to write and to gather)
 void launchVertexAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S,
                            bool StoreNorm = true, bool StoreInv = false);
+/// the vertices of a list only, storing RelVort and 1/LayerThickVertex (the vertices the merged level-1 kernel leaves out)
+void launchVertexAuxState1List(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, hipStream_t S,
+                               const I4 *Vertices, int N);
 void launchCellAuxState1(const MeshView &M, int K, const AuxPtrs &A, const Real *U, hipStream_t S);
 void launchEdgeAuxState1(const MeshView &M, const AuxPtrs &A, int Isotropic, hipStream_t S);
 void launchEdgeAuxState2(const MeshView &M, int K, const AuxPtrs &A, const Real *H, const Real *U, int FluxUpwind,

@@ -566,6 +566,26 @@ def spherical_voronoi(n_cells: int = 0, *, points=None, radius: float = 6371220.
     return m
 
 
+def permute_cell_slots(mesh: dict, fraction: float = 0.01, seed: int = 11) -> dict:
+    """A mesh file whose per-cell lists are consistent but NOT in ring order for some cells: for a random `fraction` of
+    the cells two (non-adjacent where possible) slots of edgesOnCell / cellsOnCell / verticesOnCell are swapped -- not a
+    cyclic shift: consecutive slots then no longer share a vertex.  The reference never relies on that order
+    (it only compacts the lists, components/omega/src/base/Decomp.cpp:2030-2064); the sums over a cell's edges run in
+    the file's slot order, which is what makes the order part of the result's bits."""
+    out = dict(mesh)
+    rng = np.random.default_rng(seed)
+    n = mesh["nEdgesOnCell"]
+    cells = np.flatnonzero(rng.random(mesh["nCells"]) < fraction)
+    eoc, coc, voc = (mesh[k].copy() for k in ("edgesOnCell", "cellsOnCell", "verticesOnCell"))
+    for c in cells:
+        a, b = 0, 2 if n[c] > 3 else 1          # slots 0 and 2: neither a shift nor a reflection of the ring
+        for arr in (eoc, coc, voc):
+            arr[c, a], arr[c, b] = arr[c, b], arr[c, a]
+    out["edgesOnCell"], out["cellsOnCell"], out["verticesOnCell"] = eoc, coc, voc
+    out["permutedCells"] = cells
+    return out
+
+
 def pad_max_edges(mesh: dict, max_edges: int) -> dict:
     """The same mesh stored with a larger ``maxEdges`` dimension (mesh files often carry maxEdges = 7
     or more than any cell uses); padding entries are -1 / 0 as in a file."""

@@ -4,13 +4,15 @@
     icoN                      icosahedral Voronoi sphere, level N (12 pentagons)
     fibN                      relaxed Fibonacci sphere with N cells (pentagons, hexagons, heptagons)
     <base>_pad8               the same mesh stored with maxEdges = 8
+    <base>_permN              N % of the cells with two slots of their per-cell lists swapped (not in ring order)
     <base>_coast_<kind>[_raw][_compact]
                               culled with omega_amd.meshgen.coast_mask(kind): island | channel | strait | lakes |
                               ragged | mixed; `raw` keeps [missing, cell] on boundary edges whose first cell was
                               removed (default: the culler's convention, surviving cell first); `compact` moves the
                               surviving EdgesOnEdge entries up instead of leaving holes in place
 """
-from omega_amd.meshgen import (planar_hex, spherical_voronoi, icosahedral_points, pad_max_edges, cull, coast_mask)
+from omega_amd.meshgen import (planar_hex, spherical_voronoi, icosahedral_points, pad_max_edges, cull, coast_mask,
+                               permute_cell_slots)
 
 _CACHE = {}
 
@@ -26,6 +28,9 @@ def named_mesh(name: str) -> dict:
         g0 = named_mesh(base)
         g = cull(g0, coast_mask(g0, parts[0]), first_cell_valid="raw" not in parts[1:],
                  compact_edges_on_edge="compact" in parts[1:])
+    elif "_perm" in name and name.rsplit("_perm", 1)[1].isdigit():
+        base, pct = name.rsplit("_perm", 1)
+        g = permute_cell_slots(named_mesh(base), int(pct) / 100.0)
     elif name.endswith("_pad8"):
         g = pad_max_edges(named_mesh(name[:-5]), 8)
     elif name.startswith("hex"):

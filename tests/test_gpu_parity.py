@@ -61,6 +61,12 @@ CASES = [
     ("ico3", 0, 0, 6, 1, {"WindForcingTendencyEnable": 1, "WindInterpIsotropic": 1}),   # same, on the sphere
     (20, 24, 30e3, 80, 37, {}),                                # BASELINE configs[4]: 80 levels, 37 BGC tracers
     ("ico3", 0, 0, 80, 37, {}),                                # 37 tracers with the pentagon ring launches
+    # meshes with cells whose per-cell lists are not in ring order (MeshView::BadCells: generic bodies over a list)
+    ("hex32x24_perm3", 0, 0, 8, 2, {}),
+    ("hex24x20_perm10", 0, 0, 80, 6, {}),
+    ("ico4_perm2", 0, 0, 12, 2, {}),
+    ("fib1500_perm5", 0, 0, 6, 1, {}),
+    ("hex24x20_coast_mixed_perm5", 0, 0, 6, 2, {"FluxThicknessUpwind": 1}),
     # land boundaries (culled meshes, as every real ocean mesh is: omega_amd/meshgen.py cull / coast_mask)
     ("hex32x24_coast_mixed", 0, 0, 8, 2, {}),                  # island + single-cell island + ragged patch
     ("hex24x20_coast_lakes", 0, 0, 6, 2, {}),                  # one- and two-cell lakes, one-cell-wide bays
@@ -204,6 +210,42 @@ def test_time_steppers(kind, okind, fuse):
         check(f"h step {step}", h, ost["h"][0], m.NCellsOwned)
         check(f"u step {step}", u, ost["u"][0], m.NEdgesOwned)
         check(f"tr step {step}", tr, ost["tr"][0], m.NCellsOwned)
+
+
+@pytest.mark.parametrize("name", ["hex32x24_perm3", "ico4_perm2", "fib1500_perm5"])
+def test_cells_out_of_ring_order_keep_the_fast_paths(name):
+    """A mesh file in which a few cells' per-cell lists are not in ring order (two slots swapped): the reference does not
+    care, so such cells must not cost the mesh its fast kernels (the flags used to be per mesh).  They are
+    served per cell -- generic level-1 / level-2 bodies over the list BadCells, their edges on the irregular-edge list --
+    while every ring-table flag stays on; fused RHS, reference-structured RHS and two stage-fused RK4 steps are bit-exact."""
+    g = sphere(name)
+    P = _mk((name, 0, 0, 8, 2, {}))
+    m = P.mesh
+    for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK", "Del2VertOK"):
+        assert m.get_int(f) == 1, f
+    nbad = len(g["permutedCells"])
+    assert nbad > 0 and m.get_int("NBadCells") == nbad
+    assert m.get_int("NIrregularEdges") >= 3 * nbad // 2       # every edge of a bad cell runs through the edge-centric list
+    for fused in (True, False):
+        P.tend.set_fused(fused)
+        P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+        oa.device_synchronize()
+        hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+        check("hTend", P.tend.get(0), hT, m.NCellsOwned)
+        check("uTend", P.tend.get(1), uT, m.NEdgesOwned)
+        check("trTend", P.tend.get(2), trT, m.NCellsOwned)
+    P.tend.set_fused(True)
+    dt = 600.0 if not name.startswith("fib") else 5.0
+    st = oa.TimeStepper("RungeKutta4", dt, P.tend, P.aux, P.mesh, None, P.tracers)
+    ost = P.oracle.make_state(P.h, P.u, P.tr)
+    for _ in range(2):
+        st.do_step(P.state)
+        P.oracle.step("rk4", ost, dt)
+    oa.device_synchronize()
+    h, u = P.state.copy_to_host(0)
+    check("h", h, ost["h"][0], m.NCellsOwned)
+    check("u", u, ost["u"][0], m.NEdgesOwned)
+    check("tr", P.tracers.copy_to_host(0), ost["tr"][0], m.NCellsOwned)
 
 
 @pytest.mark.parametrize("name", ["ico3", "fib1500", "ico3pad8"])
