@@ -379,7 +379,9 @@ def main():
                 if pmc.get("kernel_source_sha") != sha or wl != args.workload:
                     continue
                 def bases(n):     # "A<6, 6>+B<7, 7>" -> "A+B" (template arguments contain commas and, nested, '+' never)
-                    return "+".join(x.split("<")[0].strip() for x in n.split("+"))
+                    # (CellPVFinalTracerPatchBody is CellPVFinalTracerBody with its tracer loop through LDS patches: the
+                    # library reports both under the latter name)
+                    return "+".join(x.split("<")[0].strip().replace("TracerPatchBody", "TracerBody") for x in n.split("+"))
                 base = bases(name)
                 cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and bases(k) == base]
                 # the RK4 stage-fused instantiations of the same body move more bytes (accumulator, provisional
@@ -410,6 +412,12 @@ def main():
     overlap = N > 1 and not (args.no_overlap or args.no_fuse_stages or args.unfused)
     emitted = []
 
+    def mesh_int(name):     # (an older build of the library -- tools/ab_rounds.sh -- does not know every name)
+        try:
+            return mesh.get_int(name)
+        except oa.OmegaAmdError:
+            return None
+
     def emit(sypd, t_rk4, rk4_error, overlap_check, cpu=None):
         """rank 0: the ONE JSON line (also called by the watchdog below if the stepping part does not come back)"""
         if rank != 0 or emitted:
@@ -426,9 +434,9 @@ def main():
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
-                          "kernel_paths": {f: mesh.get_int(f) for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK",
-                                                                        "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1",
-                                                                        "NBadCells")},
+                          "kernel_paths": {f: mesh_int(f) for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK",
+                                                                    "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1",
+                                                                    "NBadCells")},
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
                           "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else

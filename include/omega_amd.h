@@ -256,7 +256,7 @@ int omg_halo_check(const omg_halo *h);
 /* ---- Measurement / test options (omega_amd/csrc/Tuning.h).  The library never reads the environment: every switch that
  *      changes the kernel structure or the tile geometry is set through this call.  Defaults are what production
  *      runs.  Names: W TX TY Sweeps ChunkSplit TailSplit (tile geometry); EdgeMode FuseFinal MergeL1 Pair FuseL3
- *      FoldLists InlineOther Alternate (structure of the fused RHS; read at every launch); SendBand BandOnComm
+ *      FoldLists InlineOther TracerPatch Alternate (structure of the fused RHS; read at every launch); SendBand BandOnComm
  *      ShrinkSweeps (what a rank leaves out inside an RK4 step; read at every stage); ForceGeneric KeepMaxEdges
  *      DomValence NarrowTables (mesh tables; read when a HorzMesh is created); WaveWindow (local numbering; read when a
  *      Decomp with a curve order is created); Graphs (-1 per object, 0 never, 1 default

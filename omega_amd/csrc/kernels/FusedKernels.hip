@@ -2262,16 +2262,17 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             }
          }
          B.SkipBad = M.NBadCells > 0;
-         launchTile(B, NSweepL1, K, S);
          if (M.NBadCells > 0) {
-            // the cells outside the ring tables: the generic level-1 cell body over their list (their edges are on the
-            // irregular-edge list), and the vertices no good cell stores through the vertex kernel
+            // the cells outside the ring tables: the generic level-1 cell body over their list, in the sweep's launch
+            // (their edges are on the irregular-edge list); the vertices no good cell stores through the vertex kernel
             FusedCell1Body<TME, Fast, EP> Bb{M, K, NT, P, DoDel2Tr, H, U, Tr, A.KineticEnergyCell, A.VelocityDivCell,
                                              HTend, A.Del2TracersCell, EH};
             Bb.List = M.BadCells;
-            launchTile(Bb, M.NBadCells, K, S);
+            launchTileV(K, S, B, NSweepL1, Bb, M.NBadCells);
             launchVertexAuxState1List(M, K, A, H, U, S, M.OrphanVertices, M.NOrphanVertices);
+            return;
          }
+         launchTile(B, NSweepL1, K, S);
       };
       auto LaunchL1 = [&](auto Epi) {
          if (InlineOther)
@@ -2331,7 +2332,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    // independent sweeps share a launch (KernelCommon.h: tileKernel2); option Pair = 0 launches them one by one
    const int PairEnv = Tn.Pair;
    const bool PairL2        = PairEnv && P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.Del2VertOK;
-   bool WideL2Done          = false;
+   bool WideL2Done = false, BadL2Done = false;
    FusedKernelNames[2] = FusedKernelNames[3] = "";
    if (PairL2) {
       FusedKernelNames[2] = "Del2CellRingBody+Del2VertexSelBody";
@@ -2345,6 +2346,11 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
             launchTileV(K, S, BC, M.NCellsAll, BV, M.NVerticesAll, BW, NWide);
             Launched = WideL2Done = true;
          }
+      }
+      if (!Launched && M.NBadCells > 0) { // (the cells outside the ring tables ride along: generic body over their list)
+         FusedDel2CellBody Bb{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell, M.BadCells};
+         launchTileV(K, S, BC, M.NCellsAll, BV, M.NVerticesAll, Bb, M.NBadCells);
+         Launched = BadL2Done = true;
       }
       if (!Launched)
          launchTile2(BC, M.NCellsAll, BV, M.NVerticesAll, K, S);
@@ -2376,7 +2382,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
          launchTile(BC, NWide, K, S);
       }
    }
-   if (P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.NBadCells > 0) { // the cells outside the ring tables
+   if (P.VelHyperDiffTendencyEnable && M.Del2RingOK && M.NBadCells > 0 && !BadL2Done) { // the cells outside the ring tables
       FusedDel2CellBody Bb{M, K, A.VelocityDivCell, A.RelVortVertex, A.Del2DivCell, M.BadCells};
       launchTile(Bb, M.NBadCells, K, S);
    }
@@ -2723,7 +2729,9 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                      const int NList = (CanWide && FoldL3 ? NWide : 0) + (FoldL3 ? NOther : 0) + (FoldChain ? M.NIrregularEdges : 0);
                      const Geom Gp   = makeGeom(M.NCellsAll + NList, K, 2, levelPitch(K), NT <= 8 ? 16 : 0);
                      const int Slot  = MeshView::patchSlot(Gp.Tile);
-                     if (Tn.TracerPatch && Gp.W == 2 && Gp.Block.x == 8 && Slot >= 0 && (int)Gp.Block.y == Gp.Tile) {
+                     // (from 4 tracers on: with 2 the transfers' set-up and the barriers cost more than they save --
+                     // EC30to60-sized, 2 tracers: level 3 +1.7 %, QU240-sized +7 %; an eighth of QU30, 6 tracers: -2.3 %)
+                     if (Tn.TracerPatch && NT >= 4 && Gp.W == 2 && Gp.Block.x == 8 && Slot >= 0 && (int)Gp.Block.y == Gp.Tile) {
                         CellPVFinalTracerPatchBody<TME, ND, FLS> BP{{BF}, M.PatchRows[Slot], M.PatchIdx[Slot], M.PatchOK[Slot],
                                                                    M.PatchNP[Slot]};
                         LaunchSweep(BP);
