@@ -1727,6 +1727,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
    static constexpr bool Cooperative = true; // the tile kernels call computeTile() with every thread of the workgroup
    const I4 *PRows, *PIdx, *POK; // the mesh's patch tables for this launch's tile size
    int NP;                       // rows per patch (multiple of 8)
+   int PatchTile;                // the tile size these tables were built for (checked against the launch's)
    int NWv = 4;                  // wavefronts per workgroup (KernelCommon.h: setWaves)
    struct Lds : Base::Lds {
       int *PRow;
@@ -1749,13 +1750,15 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
    __device__ void stage(const Lds &L, int First, int Cnt, int Tid, int NThr) const {
       Base::stage(L, First, Cnt, Tid, NThr);
       const int Tile = blockDim.y, Tl = First / Tile;
-      for (int I = Tid; I < NP; I += NThr)
-         L.PRow[I] = PRows[(size_t)Tl * NP + I];
-      const unsigned char *Src = reinterpret_cast<const unsigned char *>(PIdx) + (size_t)First * 8;
-      for (int I = Tid; I < Cnt * 8; I += NThr)
-         L.PIdxB[I] = Src[I];
-      if (Tid == 0)
-         L.OKp[0] = POK[Tl];
+      if (Tile == PatchTile) {
+         for (int I = Tid; I < NP; I += NThr)
+            L.PRow[I] = PRows[(size_t)Tl * NP + I];
+         const unsigned char *Src = reinterpret_cast<const unsigned char *>(PIdx) + (size_t)First * 8;
+         for (int I = Tid; I < Cnt * 8; I += NThr)
+            L.PIdxB[I] = Src[I];
+      }
+      if (Tid == 0) // (a launch whose geometry is not the tables': the per-thread gathers)
+         L.OKp[0] = (Tile == PatchTile && blockDim.x == 8) ? POK[Tl] : 0;
    }
    /// one 16-byte-per-lane transfer buffer -> LDS; LdsAddr = LDS byte address of the wavefront's 1 KiB destination
    __device__ __forceinline__ static void dma16(const Real *Plane, unsigned ByteOff, unsigned LdsAddr) {
@@ -1768,7 +1771,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
       __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                        :
                        : "s"(LdsAddr), "v"(ByteOff), "s"(Rs)
-                       : "memory");
+                       : "memory", "m0");
    }
    /// this wavefront's share of tracer Lt's rows into buffer (It & 1)
    template <class T> __device__ __forceinline__ void fetchTracer(const Lds &L, int Lt, unsigned It, int Kv, bool KvOK) const {
@@ -2733,7 +2736,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
                      // EC30to60-sized, 2 tracers: level 3 +1.7 %, QU240-sized +7 %; an eighth of QU30, 6 tracers: -2.3 %)
                      if (Tn.TracerPatch && NT >= 4 && Gp.W == 2 && Gp.Block.x == 8 && Slot >= 0 && (int)Gp.Block.y == Gp.Tile) {
                         CellPVFinalTracerPatchBody<TME, ND, FLS> BP{{BF}, M.PatchRows[Slot], M.PatchIdx[Slot], M.PatchOK[Slot],
-                                                                   M.PatchNP[Slot]};
+                                                                   M.PatchNP[Slot], Gp.Tile};
                         LaunchSweep(BP);
                         return;
                      }

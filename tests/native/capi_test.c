@@ -172,6 +172,22 @@ int main(int argc, char **argv) {
       if (st != 0)
          printf("FAIL: peer wire status %d\n", st), ++fails;
       OK(omg_stream_synchronize(stream));
+      /* round 4 entry points: the wire's verdict after a synchronisation, globalSum over the halo's wire (one task: the
+         combination alone), and the resource counter around a step (nothing is created inside doStep) */
+      OK(omg_halo_check(halo));
+      {
+         double pairs[4] = {1.0, 1e-17, 3.5, 0.0}, sums[4] = {0, 0, 0, 0};
+         OK(omg_halo_global_sum_dd(halo, pairs, 2, sums, stream));
+         if (sums[0] != 1.0 || sums[2] != 3.5)
+            printf("FAIL: omg_halo_global_sum_dd %g %g\n", sums[0], sums[2]), ++fails;
+         int64_t n0 = -1, n1 = -2;
+         OK(omg_device_resource_count(&n0));
+         OK(omg_stepper_do_step(stepper, state, stream));
+         OK(omg_stream_synchronize(stream));
+         OK(omg_device_resource_count(&n1));
+         if (n0 <= 0 || n0 != n1)
+            printf("FAIL: device resources created inside a step: %lld -> %lld\n", (long long)n0, (long long)n1), ++fails;
+      }
       OK(omg_halo_destroy(halo));
       OK(omg_peer_destroy(pw));
       OK(omg_device_free(di4));
