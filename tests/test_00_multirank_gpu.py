@@ -64,6 +64,9 @@ def test_two_ranks_one_gpu(extra):
     (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 3, "--eddy-diff4", 1.0e11]),
     (4, ["--halo-width", 4, "--mesh", "ico4", "--levels", 3, "--tracers", 2, "--eddy-diff4", 1.0e11, "--partition", "graph",
          "--local-order", "curve"]),
+    # (r4) k-d local numbering; cells out of ring order (MeshView::BadCells) next to the partition line and in the halo
+    (3, ["--halo-width", 4, "--mesh", "ico4", "--levels", 6, "--partition", "graph", "--local-order", "kd"]),
+    (2, ["--halo-width", 4, "--mesh", "hex48x24_perm5", "--levels", 6, "--tracers", 3, "--partition", "graph", "--local-order", "kd"]),
 ])
 def test_peer_wire_stream_ordered_exchanges(world, extra):
     """The same runs over the library's OTHER wire (PeerWire: HIP IPC mailboxes, device-to-device copies and flag
