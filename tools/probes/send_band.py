@@ -31,13 +31,14 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--halo-width", type=int, default=4)
+    ap.add_argument("--local-order", default="kd", choices=["curve", "hilbert", "kd", "global"])
     a = ap.parse_args()
     K, NT = a.levels, a.tracers
     oa.device_init(0)
     g = reorder_cells_morton(planar_hex(a.nx, a.nx, 30e3))
     gm = oa.GlobalMesh(g)
     cell_task, _ = oa.partition_cells(gm, a.parts, "graph")
-    decomp = oa.Decomp(gm, a.parts, a.rank, a.halo_width, cell_task=cell_task, local_order="curve")
+    decomp = oa.Decomp(gm, a.parts, a.rank, a.halo_width, cell_task=cell_task, local_order=a.local_order)
     mesh = oa.HorzMesh(decomp, K)
     halo = oa.Halo(decomp)
     halo.set_transport(lambda *args: 0)          # a wire that moves nothing
