@@ -13,7 +13,6 @@ Halo::Halo(const std::string &, const Decomp *D) {
    MyTask    = D->MyTask;
    NumTasks  = D->NumTasks;
    HaloWidth = D->HaloWidth;
-   const int NumTasks = D->NumTasks;
 
    // my halo elements, by kind: (NOwned, NAll, Loc)
    struct Kind {
