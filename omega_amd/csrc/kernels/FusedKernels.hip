@@ -319,9 +319,6 @@ template <int TME, bool Fast, bool EPI = false> struct FusedCell1Body {
 // side-0 half of PotentialVortHAdvOnEdge (CellPVBody<.., 0>) with the normalised vorticities still in registers.
 // Against VortVertexBody + FusedCell1Body + CellPVBody<side 0> this reads h and u once instead of three times and
 // never re-reads the two vertex arrays: 96 B per cell-level less HBM traffic and two launches less.
-#ifndef OMEGA_L1PV_MINW
-#define OMEGA_L1PV_MINW OMEGA_CELL_MINW
-#endif
 /// INLO: cells with NR - 1 edges (the pentagons of a hexagon mesh) do their side-0 sums here as well, with the ring code
 /// instantiated a second time, instead of through a list launch of CellPVBody (12 pentagons on a QU240-sized sphere:
 /// that launch was 9 % of the RHS).  Only instantiated for meshes that have such cells.
@@ -336,9 +333,13 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false,
       else
          return I;
    }
-   static constexpr int MinWaves = OMEGA_L1PV_MINW;
+   static constexpr int MinWaves = OMEGA_CELL_MINW;
    static constexpr int MaxW     = OMEGA_CELL_MAXW;
-   static constexpr int TM1      = TME - 1;
+   /// tile-local index opaque per chunk (KernelCommon.h: tileKernel): 240 -> 174 VGPRs at TME = 6, this launch - 2 %.
+   /// (Three waves per SIMD are then within reach -- 166 VGPRs with MinWaves = 3 -- and measured slower: + 4 % planar,
+   /// + 21 % with the inlined pentagon code spilling; the level-3 bodies lose 4 % with the opaque index.)
+   static constexpr bool OpaqueLe = true;
+   static constexpr int TM1       = TME - 1;
    MeshView M;
    int K, NT;
    TendParams P;
@@ -1485,7 +1486,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
    Real *TrTend;
    const int *List = nullptr;
    struct Lds {
-      Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *BDs, *FV, *MDvS, *Df2, *Df4, *InvA;
+      Real *Wt, *InvDc, *InvDvS, *C2, *C4, *BDn, *CellS, *FV, *MDvS, *Df2, *Df4; // CellS[2 Le] = BottomDepth, [2 Le + 1] = 1/Area
       int *Edge, *NbrF, *Ring, *Role, *N;
    };
    __host__ __device__ size_t ldsBytes(int Tile) const {
@@ -1505,8 +1506,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
       L.MDvS   = C.take<Real>(Tile * TME);
       L.Df2    = C.take<Real>(Tile * TME);
       L.Df4    = C.take<Real>(Tile * TME);
-      L.BDs    = C.take<Real>(Tile);
-      L.InvA   = C.take<Real>(Tile);
+      L.CellS  = C.take<Real>(Tile * 2);
       L.Edge   = C.take<int>(Tile * TME);
       L.NbrF   = C.take<int>(Tile * TME);
       L.Ring   = C.take<int>(Tile * TME);
@@ -1543,9 +1543,9 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
       }
       for (int I = Tid; I < Cnt; I += NThr) {
          const int C = cellOf(First + I);
-         L.BDs[I]    = M.BottomDepth[C];
-         L.N[I]      = M.NEdgesOnCell[C];
-         L.InvA[I]   = M.InvAreaCell[C];
+         L.CellS[2 * I]     = M.BottomDepth[C];
+         L.N[I]             = M.NEdgesOnCell[C];
+         L.CellS[2 * I + 1] = M.InvAreaCell[C];
       }
    }
    /// what the velocity part gathers and the tracer loop goes on with
@@ -1630,7 +1630,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
             R2[J] = ldo<T>(Del2RelVort, OffV[J]);
          }
          const T KEs = ldo<T>(KE, OffS), DivS = ldo<T>(Div, OffS), D2S = ldo<T>(Del2Div, OffS);
-         const T Ssh1 = Hs - L.BDs[Le];
+         const T Ssh1 = Hs - L.CellS[2 * Le];
 #pragma unroll
          for (int I = 0; I < N; ++I) {
             const int Li = Le * TME + I;
@@ -1663,7 +1663,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
       const T Hs = R.Hs;
       const T(&Hn)[TME] = R.Hn;
       const T(&Uj)[TME] = R.Uj;
-      const Real InvA      = L.InvA[Le];
+      const Real InvA      = L.CellS[2 * Le + 1];
       const size_t CStride = (size_t)M.NCellsSize * K;
 #ifndef OMEGA_L3_TRUNROLL
 #define OMEGA_L3_TRUNROLL 1
@@ -1771,7 +1771,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
       __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                        :
                        : "s"(LdsAddr), "v"(ByteOff), "s"(Rs)
-                       : "memory", "m0");
+                       : "memory");
    }
    /// this wavefront's share of tracer Lt's rows into buffer (It & 1)
    template <class T> __device__ __forceinline__ void fetchTracer(const Lds &L, int Lt, unsigned It, int Kv, bool KvOK) const {
@@ -1806,25 +1806,27 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
          const int Kv    = Kc * blockDim.x + threadIdx.x;
          const bool KvOK = Kv < KV;
          const bool Act  = Mine && KvOK;
-         if (!Patch) { // a tile whose patch does not fit: the per-thread gathers
-            if (Act)
-               Base::template compute<T>(L, Le, First + Le, Kv);
-            continue;
-         }
+         const int LeT = Le < Cnt ? Le : 0; // this thread's tile-local cell (0 for a thread without one)
          // the first tracer's rows travel while the velocity part runs (the buffer was last read two tracers ago, and
          // every wave has passed the barrier of the tracer in between)
-         fetchTracer<T>(L, 0, It, Kv, KvOK);
+         if (Patch)
+            fetchTracer<T>(L, 0, It, Kv, KvOK);
          typename Base::template RingVals<T> R;
          R.OffS = BufOOB, R.Hs = splat<T>(0.0);
 #pragma unroll
          for (int J = 0; J < TME; ++J)
             R.OffN[J] = BufOOB, R.Hn[J] = splat<T>(0.0), R.Uj[J] = splat<T>(0.0);
          if (Act)
-            Base::template velPart<T>(L, Le, ICell, Kv, R);
+            Base::template velPart<T>(L, LeT, ICell, Kv, R);
+         if (!Patch) { // a tile whose patch does not fit (one code path for the velocity part either way): per-thread gathers
+            if (Act)
+               Base::template tracerLoopDirect<T>(L, LeT, R);
+            continue;
+         }
          const unsigned OffS = Act ? R.OffS : BufOOB; // (inactive threads run the loop for its barriers; they store nothing)
-         const Real InvA      = L.InvA[Le < Cnt ? Le : 0];
+         const Real InvA      = L.CellS[2 * LeT + 1];
          const size_t CStride = (size_t)this->M.NCellsSize * this->K;
-         const unsigned char *PI = L.PIdxB + (Le < Cnt ? Le : 0) * 8;
+         const unsigned char *PI = L.PIdxB + LeT * 8;
          unsigned PO[TME + 1]; // byte offsets of this thread's 7 + 1 values inside a buffer plane
 #pragma unroll
          for (int J = 0; J < TME; ++J)
@@ -1854,7 +1856,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
             const T HsTs = R.Hs * Ts;
 #pragma unroll
             for (int J = 0; J < TME; ++J) {
-               const int I  = (Le < Cnt ? Le : 0) * TME + J;
+               const int I  = LeT * TME + J;
                const T HTr  = 0.5 * (HsTs + R.Hn[J] * Tn[J]);
                HAdvTmp -= L.MDvS[I] * HTr * R.Uj[J] * InvA;
                const T Mean = 0.5 * (R.Hs + R.Hn[J]);

@@ -200,6 +200,12 @@ template <class B> __device__ __forceinline__ void chunkFence() {
       __asm__ volatile("" ::: "memory");
 #endif
 }
+template <class B, class = void> struct BodyOpaqueLe {
+   static constexpr bool V = false;
+};
+template <class B> struct BodyOpaqueLe<B, std::enable_if_t<B::OpaqueLe>> {
+   static constexpr bool V = true;
+};
 template <class B, class = void> struct BodyCooperative {
    static constexpr bool V = false;
 };
@@ -257,7 +263,15 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
          for (int Kv = C0 * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * CS) {
             chunkFence<Body>();
-            B.template compute<T>(L, Le, First + Le, Kv);
+            if constexpr (BodyOpaqueLe<Body>::V) {
+               // the tile-local element index made opaque per chunk: the LDS table addresses derived from it are
+               // recomputed (a few VALU adds) instead of living in VGPRs across the chunks -- for a body at the
+               // register limit (profiles/r04_opaque_le.json)
+               int LeO = Le;
+               __asm__ volatile("" : "+v"(LeO));
+               B.template compute<T>(L, LeO, First + Le, Kv);
+            } else
+               B.template compute<T>(L, Le, First + Le, Kv);
          }
    }
 }
