@@ -418,6 +418,8 @@ def main():
         except oa.OmegaAmdError:
             return None
 
+    rhs_with_exchange = None
+
     def emit(sypd, t_rk4, rk4_error, overlap_check, cpu=None):
         """rank 0: the ONE JSON line (also called by the watchdog below if the stepping part does not come back)"""
         if rank != 0 or emitted:
@@ -430,7 +432,7 @@ def main():
                                "cells, WITHOUT a halo exchange inside the timed loop (a tendency evaluation has none; "
                                "config.rhs_excludes_halo_exchange); the strong-scaling figure that includes the two exchanges of "
                                "a step is rk4.cell_level_updates_per_sec (= cells x levels x 4 evaluations / rk4.ms_per_step) "
-                               "and sypd",
+                               "and sypd; rhs_with_halo_exchange = the same K evaluations, each preceded by the (not overlapped) exchange of its inputs",
                "data": "synthetic",
                "config": {"workload": desc, "cells": int(n_cells_global), "levels": K, "tracers": NT,
                           "boundary_edges": int(g["boundaryEdge"].sum()) if "boundaryEdge" in g else 0,
@@ -459,6 +461,7 @@ def main():
                        ("overlapped with the stage's interior cells" if overlap else "after the stage"),
                        "error": rk4_error, "overlap_check": overlap_check,
                        "state_checksums_after_2_steps": state_checksums},
+               "rhs_with_halo_exchange": rhs_with_exchange,
                "roofline": roofline, "cpu_baseline": cpu}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -679,6 +682,38 @@ def main():
             overlap_check = {"error": "; ".join(check_errs)[:600]}
             rk4_error = "the overlapped-vs-sequential cross-check failed (see rk4.overlap_check)"
             sypd = None
+
+    # ------------------------------------------------ N > 1: the evaluation WITH the exchange that feeds it
+    # `value` above has no exchange in its timed loop (a tendency evaluation has none).  What a model pays per evaluation is
+    # the halo update of its inputs first (RungeKutta4Stepper.cpp:95-101: h, u and the tracers after every stage): the same
+    # K steps again, each one = exchange of h, u and the NT tracers on the launch stream, then the evaluation (the
+    # sequential form: nothing overlapped, the upper bound of what the exchange costs).  Reported next to `value`.
+    if N > 1 and nrk > 0 and rk4_error is None:
+        x_err = None
+        try:
+            def one():
+                state.exchange_halo(0, stream=stream)
+                tracers.exchange_halo(0, stream=stream)
+                tend.compute_all_tendencies(state, aux, tracers, stream=stream)
+            for _ in range(args.warmup):
+                one()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one()
+            oa.device_synchronize()
+            t_x = time.perf_counter() - t1
+            barrier()
+            t_x = allmax(t_x) / args.steps
+            halo.check()
+            rhs_with_exchange = {"ms_per_step": 1e3 * t_x, "value": cell_levels / t_x, "unit": "cell-level-updates/s",
+                                 "step": "Halo exchange of h, u and the tracers (sequential, on the launch stream), then "
+                                         "computeAllTendencies; same W and K, barrier-bracketed, max over ranks"}
+        except Exception as exc:  # noqa: BLE001
+            x_err = f"rank {rank}: {type(exc).__name__}: {exc}"
+        x_errs = gather_errors(x_err)
+        if x_errs:
+            rhs_with_exchange = {"error": "; ".join(x_errs)[:600]}
 
     if watchdog is not None:
         watchdog.cancel()

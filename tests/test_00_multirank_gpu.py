@@ -228,3 +228,7 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert two["config"]["halo_wire_check"].endswith("ok on every rank")
     assert two["rk4"]["overlap_check"]["overlapped_equals_sequential"] is True
     assert two["rk4"]["state_checksums_after_2_steps"] == one["rk4"]["state_checksums_after_2_steps"]
+    # the evaluation with the exchange of its inputs in front: measured, and not faster than the evaluation alone
+    x = two["rhs_with_halo_exchange"]
+    assert "error" not in x and x["ms_per_step"] > 0 and x["value"] > 0
+    assert one["rhs_with_halo_exchange"] is None
