@@ -547,38 +547,46 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false,
       // ---- TracerAuxVars::computeVarsOnCells: exactly FusedCell1Body ----
       if (DoDel2Tr) {
          const size_t CStride = (size_t)M.NCellsSize * K;
-#ifndef OMEGA_L1_TRUNROLL
-#define OMEGA_L1_TRUNROLL 2
-#endif
          // TU tracers per trip: their gathers are asked for together (one memory round trip per trip); a tracer past
-         // the last one has its accesses switched off
-         constexpr int TU = OMEGA_L1_TRUNROLL; // (also for the 7-wide tables, where it costs 32 B of scratch: -6 %)
+         // the last one has its accesses switched off.  Three per trip where that divides the tracer count and the
+         // registers are there (6-slot tables: 174 VGPRs either way; level 1 -0.6 ... -2 %), two otherwise (also for the
+         // 7-wide tables, where it costs 32 B of scratch: -6 %)
+         auto TrLoop = [&](auto Unroll) {
+            constexpr int TU = decltype(Unroll)::value;
 #pragma nounroll
-         for (int Lt = 0; Lt < NT; Lt += TU) {
-            loopFence();
-            T Tn[TU][TME], Ts[TU];
+            for (int Lt = 0; Lt < NT; Lt += TU) {
+               loopFence();
+               T Tn[TU][TME], Ts[TU];
 #pragma unroll
-            for (int Q = 0; Q < TU; ++Q) {
-               const bool Valid = TU == 1 || Lt + Q < NT;
-               const Real *TrL  = uniformPtr(Tr + (Valid ? Lt + Q : Lt) * CStride);
+               for (int Q = 0; Q < TU; ++Q) {
+                  const bool Valid = TU == 1 || Lt + Q < NT;
+                  const Real *TrL  = uniformPtr(Tr + (Valid ? Lt + Q : Lt) * CStride);
 #pragma unroll
-               for (int J = 0; J < TME; ++J)
-                  Tn[Q][J] = ldoIf<T>(Valid, TrL, OffN[J]);
-               Ts[Q] = ldoIf<T>(Valid, TrL, OffS);
-            }
-#pragma unroll
-            for (int Q = 0; Q < TU; ++Q) {
-               const bool Valid = TU == 1 || Lt + Q < NT;
-               T Tmp            = splat<T>(0.0);
-#pragma unroll
-               for (int J = 0; J < TME; ++J) {
-                  const T Grad =
-                      Fast ? T(Tn[Q][J] - Ts[Q]) : T(pick(IsC0[J], Tn[Q][J], Ts[Q]) - pick(IsC0[J], Ts[Q], Tn[Q][J]));
-                  Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
+                  for (int J = 0; J < TME; ++J)
+                     Tn[Q][J] = ldoIf<T>(Valid, TrL, OffN[J]);
+                  Ts[Q] = ldoIf<T>(Valid, TrL, OffS);
                }
-               stntIf<T>(Valid, uniformPtr(Del2Tr + (Valid ? Lt + Q : Lt) * CStride), OffS, Tmp * InvA);
+#pragma unroll
+               for (int Q = 0; Q < TU; ++Q) {
+                  const bool Valid = TU == 1 || Lt + Q < NT;
+                  T Tmp            = splat<T>(0.0);
+#pragma unroll
+                  for (int J = 0; J < TME; ++J) {
+                     const T Grad =
+                         Fast ? T(Tn[Q][J] - Ts[Q]) : T(pick(IsC0[J], Tn[Q][J], Ts[Q]) - pick(IsC0[J], Ts[Q], Tn[Q][J]));
+                     Tmp -= L.D2T[Le * TME + J] * HMeanJ[J] * Grad;
+                  }
+                  stntIf<T>(Valid, uniformPtr(Del2Tr + (Valid ? Lt + Q : Lt) * CStride), OffS, Tmp * InvA);
+               }
+            }
+         };
+         if constexpr (TME <= 6 && Fast) {
+            if (NT % 3 == 0) {
+               TrLoop(std::integral_constant<int, 3>{});
+               return;
             }
          }
+         TrLoop(std::integral_constant<int, 2>{});
       }
    }
 };
@@ -1768,9 +1776,10 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
       Rs.y = __builtin_amdgcn_readfirstlane((unsigned)(V >> 32) & 0xffffu);
       Rs.z = BufOOB;
       Rs.w = 0x00020000u;
+      const unsigned A = __builtin_amdgcn_readfirstlane(LdsAddr); // (wave-uniform by construction; the compiler may hold it in a VGPR)
       __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                        :
-                       : "s"(LdsAddr), "v"(ByteOff), "s"(Rs)
+                       : "s"(A), "v"(ByteOff), "s"(Rs)
                        : "memory");
    }
    /// this wavefront's share of tracer Lt's rows into buffer (It & 1)
