@@ -61,6 +61,13 @@ CASES = [
     ("ico3", 0, 0, 6, 1, {"WindForcingTendencyEnable": 1, "WindInterpIsotropic": 1}),   # same, on the sphere
     (20, 24, 30e3, 80, 37, {}),                                # BASELINE configs[4]: 80 levels, 37 BGC tracers
     ("ico3", 0, 0, 80, 37, {}),                                # 37 tracers with the pentagon ring launches
+    # tracer counts around the switches of the tracer loops (LDS tile patches from 4 tracers on; three tracers per trip in
+    # level 1 where 3 divides the count and the tables are 6 wide; other thread geometry above 8 tracers)
+    (20, 24, 30e3, 80, 4, {}),
+    ("ico4", 0, 0, 20, 5, {}),
+    (24, 20, 30e3, 12, 9, {}),
+    ("fib1500", 0, 0, 16, 12, {}),
+    ("ico4", 0, 0, 80, 3, {}),
     # meshes with cells whose per-cell lists are not in ring order (MeshView::BadCells: generic bodies over a list)
     ("hex32x24_perm3", 0, 0, 8, 2, {}),
     ("hex24x20_perm10", 0, 0, 80, 6, {}),
