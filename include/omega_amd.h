@@ -248,6 +248,11 @@ int omg_halo_exchange_i4(omg_halo *h, int32_t *dev_array, int nt, int rows_size,
  * rank and for every partition.  Collective over all tasks of the decomposition; synchronises `stream`.  One task: the
  * combination alone.  Fails on a Halo whose wire is a caller-supplied transport. */
 int omg_halo_global_sum_dd(omg_halo *h, const double *local_hi_lo, int npairs, double *hi_lo, void *stream);
+/* h, u and the tracers of one exchange point as ONE message per neighbour: what the time steppers do after a stage
+ * (RungeKutta4Stepper.cpp:95-101 calls OceanState::exchangeHalo and Tracers::exchangeHalo -- three rounds of messages;
+ * here [h on cells][u on edges][tracers on cells] travel together).  `tracers` may be NULL.  Queued on `stream`. */
+int omg_halo_exchange_state(omg_halo *h, omg_state *state, int state_time_level, omg_tracers *tracers,
+                            int tracers_time_level, void *stream);
 /* The wire's verdict, to be asked after the host has synchronised with an exchange's stream (the exchange calls return
  * when the work is queued): 0 = fine; fails (message: omg_last_error) when a peer-wire wait gave up -- the unpack
  * kernel of that exchange then copied nothing, the halo is stale.  The time steppers ask at the start of every step. */

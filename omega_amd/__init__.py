@@ -589,6 +589,11 @@ class Halo:
         _chk(lib().omg_halo_global_sum_dd(self.h, _pd(p), p.shape[0], _pd(out), _sh(stream)))
         return [float(x) for x in out[:, 0]]
 
+    def exchange_state(self, state, tracers=None, time_level: int = 0, tracers_time_level: int | None = None, stream=None):
+        """omg_halo_exchange_state: h, u and the tracers as ONE message per neighbour (what the time steppers do after a stage)"""
+        _chk(lib().omg_halo_exchange_state(self.h, state.h, time_level, tracers.h if tracers is not None else None,
+                                           time_level if tracers_time_level is None else tracers_time_level, _sh(stream)))
+
     def check(self):
         """omg_halo_check: raises if a peer-wire wait of an earlier exchange gave up (ask after synchronising)"""
         _chk(lib().omg_halo_check(self.h))

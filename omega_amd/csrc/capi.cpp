@@ -911,6 +911,20 @@ int omg_state_exchange_halo(omg_state *s, int tl, void *stream) {
       OMEGA_ABORT("OceanState::exchangeHalo failed");
    OMG_CATCH
 }
+int omg_halo_exchange_state(omg_halo *h, omg_state *s, int tl, omg_tracers *t, int tl_tr, void *stream) {
+   OMG_TRY
+   OMG_ARG(h && s);
+   Array2DReal H, U;
+   Array3DReal Tr;
+   OMEGA_REQUIRE(s->S->getLayerThickness(H, tl) == 0 && s->S->getNormalVelocity(U, tl) == 0,
+                 "omg_halo_exchange_state: bad state time level");
+   const int NT = t ? t->T->NTracers : 0;
+   if (NT > 0)
+      OMEGA_REQUIRE(t->T->getAll(Tr, tl_tr) == 0, "omg_halo_exchange_state: bad tracer time level");
+   if (h->H->exchangeState(H, U, NT > 0 ? &Tr : nullptr, NT, (hipStream_t)stream) != 0)
+      OMEGA_ABORT("Halo::exchangeState failed" + h->H->wireError());
+   OMG_CATCH
+}
 int omg_state_update_time_levels(omg_state *s, void *stream) {
    OMG_TRY
    OMG_ARG(s);

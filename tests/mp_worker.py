@@ -206,6 +206,24 @@ def main():
                     got = bufs[j % 7].to_host().reshape(want.shape)
                     assert np.array_equal(got, want), f"rank {a.rank}: stress exchange {j} wrong"
 
+    # the steppers' exchange through the C ABI (omg_halo_exchange_state): h, u and the tracers as one message per
+    # neighbour; the halo rows, overwritten here, must come back from their owners (the state is a function of the
+    # global id, so the expected values are the rows uploaded at the start)
+    if gpu:
+        hp, up, tp = P.h.copy(), P.u.copy(), P.tr.copy()
+        hp[owned[0]: nall[0]] = -7.0
+        up[owned[1]: nall[1]] = -7.0
+        tp[:, owned[0]: nall[0]] = -7.0
+        P.state.copy_to_device(hp, up, 0)
+        P.tracers.copy_to_device(tp, 0)
+        halo.exchange_state(P.state, P.tracers if NT > 0 else None, 0)
+        oa.device_synchronize()
+        halo.check()
+        hb, ub = P.state.copy_to_host(0)
+        assert np.array_equal(hb[: nall[0]], P.h[: nall[0]]) and np.array_equal(ub[: nall[1]], P.u[: nall[1]])
+        if NT > 0:
+            assert np.array_equal(P.tracers.copy_to_host(0)[:NT, : nall[0]], P.tr[:NT, : nall[0]])
+
     # ---------------- (b) time stepping: partitioned run vs single-rank oracle ----------------
     okind = {"RungeKutta4": "rk4", "RungeKutta2": "rk2", "Forward-Backward": "fb"}[a.stepper]
     Mg = O.Mesh.single_rank(g, K)

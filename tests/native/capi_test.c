@@ -175,6 +175,9 @@ int main(int argc, char **argv) {
       /* round 4 entry points: the wire's verdict after a synchronisation, globalSum over the halo's wire (one task: the
          combination alone), and the resource counter around a step (nothing is created inside doStep) */
       OK(omg_halo_check(halo));
+      OK(omg_halo_exchange_state(halo, state, 0, tracers, 0, stream)); /* h, u, tracers: one message per neighbour */
+      OK(omg_stream_synchronize(stream));
+      OK(omg_halo_check(halo));
       {
          double pairs[4] = {1.0, 1e-17, 3.5, 0.0}, sums[4] = {0, 0, 0, 0};
          OK(omg_halo_global_sum_dd(halo, pairs, 2, sums, stream));
