@@ -23,6 +23,10 @@ import time
 
 import numpy as np
 
+# dmabuf IPC (the pool's hosts support no other): RCCL's and the peer wire's cross-process memory handles need it; the
+# image exports it, a launcher with a scrubbed environment may not -- set before anything loads the HIP runtime
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
