@@ -150,6 +150,29 @@ def test_compute_all_tendencies(case, fused):
     check("TracerTend", P.tend.get(2)[: case[4]], trT[: case[4]], m.NCellsOwned)
 
 
+@pytest.mark.parametrize("case", [(20, 24, 30e3, 80, 6, {}), ("ico4", 0, 0, 80, 6, {}), ("fib1500", 0, 0, 20, 5, {}),
+                                  ("hex24x20_coast_strait", 0, 0, 80, 6, {})], ids=lambda c: f"{c[0]}_K{c[3]}_NT{c[4]}")
+def test_both_forms_of_the_level3_tracer_loop(case):
+    """Option TracerPatch (Tuning.h): the level-3 kernel's tracer loop with the neighbour values through LDS tile
+    patches (default from 4 tracers on) and with per-thread gathers give the same bits -- each other's and the oracle's.
+    (The rest of the suite runs with the default; this is the only place the gather form of these cases is compared.)"""
+    P = _mk(case)
+    NT, m = case[4], P.mesh
+    _, _, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)
+    got = {}
+    P.tend.set_fused(True)
+    try:
+        for on in (1, 0):
+            oa.set_option("TracerPatch", on)
+            P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+            oa.device_synchronize()
+            got[on] = P.tend.get(2)[:NT].copy()
+            check(f"TracerTend (TracerPatch={on})", got[on], trT[:NT], m.NCellsOwned)
+    finally:
+        oa.set_option("TracerPatch", 1)
+    assert np.array_equal(got[0][:, : m.NCellsOwned], got[1][:, : m.NCellsOwned])
+
+
 def test_sphere_meshes_take_the_fast_paths():
     """Which kernel paths the spherical meshes exercise (HorzMesh table diagnostics): ring-form
     del2 everywhere; cell-centric PV with the pentagons' edges on the edge-centric list."""
