@@ -410,7 +410,7 @@ def test_manufactured_solution_converges_through_the_gpu_path():
     assert 1.8 < rate < 2.3, (errs, rate)
 
 
-def _random_cases(n, seed=1234):
+def _random_cases(n, seed=1234, tracer_counts=(0, 1, 2, 5)):
     rng = np.random.default_rng(seed)
     flags = ["ThicknessFluxTendencyEnable", "PVTendencyEnable", "KETendencyEnable", "SSHTendencyEnable",
              "VelDiffTendencyEnable", "VelHyperDiffTendencyEnable", "TracerHorzAdvTendencyEnable",
@@ -419,7 +419,7 @@ def _random_cases(n, seed=1234):
     out = []
     for i in range(n):
         K = int(rng.choice([1, 2, 3, 7, 16, 17, 32, 33, 48, 64, 96, 100, 128]))
-        NT = int(rng.choice([0, 1, 2, 5]))
+        NT = int(rng.choice(list(tracer_counts)))
         mesh = rng.choice(["hex", "hex", "ico2", "fib300"])
         cfg = {}
         if i % 3:                       # two thirds of the cases with random switches, one third Default.yml
@@ -432,7 +432,10 @@ def _random_cases(n, seed=1234):
     return out
 
 
-@pytest.mark.parametrize("case", _random_cases(64), ids=lambda c: f"{c[0]}_K{c[3]}_NT{c[4]}_{len(c[5])}opts")
+# (the second set: tracer counts on both sides of the tracer loops' switches -- tile patches from 4 tracers on, three
+# tracers per trip where 3 divides the count, another thread geometry above 8)
+@pytest.mark.parametrize("case", _random_cases(64) + _random_cases(32, seed=4321, tracer_counts=(3, 4, 6, 7, 9, 12)),
+                         ids=lambda c: f"{c[0]}_K{c[3]}_NT{c[4]}_{len(c[5])}opts")
 def test_randomised_configurations(case):
     """Random level counts (aligned / unaligned / odd / single), tracer counts (incl. none), meshes and
     option sets: fused RHS and one RK4 step against the oracle, bit for bit."""
