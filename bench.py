@@ -30,10 +30,23 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import omega_amd as oa  # noqa: E402
-oa.lib()   # load libomega_amd.so (and with it ROCm's own libamdhip64 / librccl) before anything imports torch
-from omega_amd.meshgen import (icosahedral_points, planar_hex, reorder_cells_blocked, reorder_cells_morton,  # noqa: E402
-                               spherical_voronoi, synthetic_state, synthetic_state_rows)
+oa = None   # omega_amd: loaded by load_library() in a process that computes, never by the launcher parent
+
+
+def load_library():
+    """libomega_amd.so (and with it ROCm's own libamdhip64 / librccl) before anything imports torch.  Called by the rank
+    processes only: the parent of a self-launched N > 1 run (launch_ranks) never loads the HIP runtime."""
+    global oa, icosahedral_points, planar_hex, reorder_cells_blocked, reorder_cells_morton
+    global spherical_voronoi, synthetic_state, synthetic_state_rows
+    import omega_amd
+    omega_amd.lib()
+    from omega_amd import meshgen
+    oa = omega_amd
+    icosahedral_points, planar_hex = meshgen.icosahedral_points, meshgen.planar_hex
+    reorder_cells_blocked, reorder_cells_morton = meshgen.reorder_cells_blocked, meshgen.reorder_cells_morton
+    spherical_voronoi, synthetic_state, synthetic_state_rows = (meshgen.spherical_voronoi, meshgen.synthetic_state,
+                                                                meshgen.synthetic_state_rows)
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -125,7 +138,7 @@ def algorithmic_bytes_per_cell_level(nt, kernel=None):
     return per_kernel[kernel]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -174,15 +187,99 @@ def main():
     ap.add_argument("--halo-width", type=int, default=0,
                     help="0 = 4 for N > 1 (partition-independent results with the del4 terms: two RHS evaluations per "
                          "exchange consume 2 x 2 layers), 3 for N = 1; the reference default is 3")
-    args = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launched N > 1 run (plain `python bench.py --gpus N`): seconds the rank processes may take "
+                         "altogether before the parent ends them; once one rank has left, the others get --rk4-timeout + 60 s")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the
+    launcher.  It starts N FRESH child processes of this same script -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set the way torch.distributed.run sets them, one rank per GPU --, passes rank 0's stdout (the ONE JSON
+    line) through, sends everybody's stderr to its own, and returns non-zero if any rank does.  The parent never loads
+    libomega_amd / the HIP runtime and never execs: every rank is a child created by subprocess.Popen before anything
+    in this process has touched a GPU.  Children are ended by their exact PIDs only (a rank that outlives the first
+    leaver by --rk4-timeout + 60 s, or the whole run --launch-timeout)."""
+    import socket
+    import subprocess
+    import threading
+    N = args.gpus
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMEGA_BENCH_LAUNCHER="self")
+        env.setdefault("OMP_NUM_THREADS", "1")      # what torch.distributed.run does for its workers
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    lines = []
+
+    def relay():        # rank 0's stdout: the record, relayed line by line as it comes
+        for raw in procs[0].stdout:
+            line = raw.decode(errors="replace")
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    t0 = time.time()
+    first_exit = None
+    killed = []
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        codes = [p.poll() for p in procs]
+        if first_exit is None and any(c is not None for c in codes):
+            first_exit = now
+        grace = 20.0 if any(c not in (None, 0) for c in codes) else (args.rk4_timeout + 60.0)
+        if now - t0 > args.launch_timeout or (first_exit is not None and now - first_exit > grace):
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    killed.append(r)
+                    p.terminate()
+            t1 = time.time()
+            while any(p.poll() is None for p in procs) and time.time() - t1 < 10.0:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    th.join(timeout=10.0)
+    codes = [p.returncode for p in procs]
+    if killed:
+        print(f"[bench launcher] ended rank(s) {killed}: exit codes {codes}", file=sys.stderr, flush=True)
+    elif any(codes):
+        print(f"[bench launcher] rank exit codes {codes}", file=sys.stderr, flush=True)
+    if not lines:
+        print("[bench launcher] rank 0 printed no record", file=sys.stderr, flush=True)
+        return 5
+    bad = [c for c in codes if c]
+    if not bad:
+        return 0
+    positive = [c for c in bad if c > 0]     # (a negative code = ended by a signal)
+    return positive[0] if positive else 1
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    world = max(world, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
     N = world
+    load_library()
+    launcher = ("bench.py itself (fresh child processes per rank)" if os.environ.get("OMEGA_BENCH_LAUNCHER") == "self" else
+                "torch.distributed.run (or an equivalent that sets WORLD_SIZE / RANK)" if "WORLD_SIZE" in os.environ else
+                "none (one process)")
 
     nx, ny, dc, K, NT, desc = WORKLOADS[args.workload]
     if args.workload == "orrs18to6" and N < 8:
@@ -444,6 +541,7 @@ def main():
                                                                     "Del2VertOK", "NIrregularEdges", "MaxEdges", "DomM1",
                                                                     "NBadCells")},
                           "terms": "Default.yml (del2+del4, center fluxes)", "fused_rhs": not args.unfused,
+                          "launcher": launcher,
                           "partition": f"{args.partition}{N}" + (f" (edge cut {edge_cut})" if N > 1 else ""), "halo_width": halo_width,
                           "halo_wire": "none (1 rank)" if N == 1 else
                           ("RCCL send/recv inside libomega_amd (" + json.dumps(comm.info()) + ")" if comm else

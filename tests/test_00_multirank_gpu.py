@@ -232,3 +232,23 @@ def test_bench_with_two_ranks_on_one_gpu():
     x = two["rhs_with_halo_exchange"]
     assert "error" not in x and x["ms_per_step"] > 0 and x["value"] > 0
     assert one["rhs_with_halo_exchange"] is None
+    assert two["config"]["launcher"].startswith("torch.distributed.run")
+    # the same run started PLAINLY (`python bench.py --gpus 2`, what the 1-GPU bench invocation looks like): bench.py
+    # launches its own ranks as fresh child processes; the environment carries nothing of a launcher
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                        "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID", "OMEGA_BENCH_LAUNCHER")}
+    r3 = subprocess.run([*base, "--gpus", "2", "--single-device"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=600)
+    assert r3.returncode == 0, r3.stderr.decode()[-3000:]
+    out_lines = r3.stdout.decode().strip().splitlines()
+    assert len(out_lines) == 1, out_lines          # stdout carries exactly the one record
+    plain = json.loads(out_lines[0])
+    assert plain["config"]["launcher"].startswith("bench.py itself")
+    assert plain["n_gpus"] == 2 and plain["value"] > 0 and plain["rk4"]["error"] is None
+    assert plain["config"]["halo_wire_check"].endswith("ok on every rank")
+    assert plain["rk4"]["overlap_check"]["overlapped_equals_sequential"] is True
+    assert plain["rk4"]["state_checksums_after_2_steps"] == one["rk4"]["state_checksums_after_2_steps"]
+    assert "error" not in plain["rhs_with_halo_exchange"]
+    for key in ("cells", "levels", "tracers", "partition", "halo_width", "kernel_paths", "mesh_order"):
+        assert plain["config"][key] == two["config"][key], key
