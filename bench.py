@@ -107,6 +107,34 @@ def cached_mesh(key, build):
     return g
 
 
+def workload_mesh(workload, block=1, max_edges=0):
+    """The global mesh of a named workload, as a mesh file would hold it (load_library() first).  Also what the parity
+    tests at bench size build their meshes with (tests/test_gpu_parity.py)."""
+    nx, ny, dc = WORKLOADS[workload][:3]
+    if workload.startswith("fib"):
+        g = cached_mesh(f"fib_{-ny}_l2", lambda: spherical_voronoi(-ny, lloyd=2))
+    elif workload.startswith("ico"):   # sphere: cells already numbered along a Morton curve in (lon, z)
+        g = cached_mesh(f"ico_{ny}", lambda: spherical_voronoi(points=icosahedral_points(ny), lloyd=0))
+    else:
+        g = planar_hex(nx, ny, dc)
+    if workload.startswith(("ico", "fib")):
+        pass
+    elif block <= 0:
+        g = reorder_cells_morton(g, hilbert=block < 0)
+    elif block > 1:
+        g = reorder_cells_blocked(g, block)
+    if workload.endswith("_coast"):
+        from omega_amd.meshgen import coast_mask, cull
+        g = cull(g, coast_mask(g, "continents"))
+    if workload.endswith("_perm1"):
+        from omega_amd.meshgen import permute_cell_slots
+        g = permute_cell_slots(g, 0.01)
+    if max_edges > g["maxEdges"]:
+        from omega_amd.meshgen import pad_max_edges
+        g = pad_max_edges(g, max_edges)
+    return g
+
+
 def algorithmic_bytes_per_cell_level(nt, kernel=None):
     """SURVEY.md 8(d) B_staged = 8*(39 + 5*NT) B per cell-level for the whole RHS (NE = 3NC,
     NV = 2NC); per kernel: the arrays that kernel must read / write once."""
@@ -316,27 +344,7 @@ def main():
     halo_width = args.halo_width if args.halo_width > 0 else (4 if N > 1 else 3)
 
     t0 = time.time()
-    if args.workload.startswith("fib"):
-        g = cached_mesh(f"fib_{-ny}_l2", lambda: spherical_voronoi(-ny, lloyd=2))
-    elif args.workload.startswith("ico"):   # sphere: cells already numbered along a Morton curve in (lon, z)
-        g = cached_mesh(f"ico_{ny}", lambda: spherical_voronoi(points=icosahedral_points(ny), lloyd=0))
-    else:
-        g = planar_hex(nx, ny, dc)
-    if args.workload.startswith(("ico", "fib")):
-        pass
-    elif args.block <= 0:
-        g = reorder_cells_morton(g, hilbert=args.block < 0)
-    elif args.block > 1:
-        g = reorder_cells_blocked(g, args.block)
-    if args.workload.endswith("_coast"):
-        from omega_amd.meshgen import coast_mask, cull
-        g = cull(g, coast_mask(g, "continents"))
-    if args.workload.endswith("_perm1"):
-        from omega_amd.meshgen import permute_cell_slots
-        g = permute_cell_slots(g, 0.01)
-    if args.max_edges > g["maxEdges"]:
-        from omega_amd.meshgen import pad_max_edges
-        g = pad_max_edges(g, args.max_edges)
+    g = workload_mesh(args.workload, block=args.block, max_edges=args.max_edges)
     gm = oa.GlobalMesh(g)
     cell_task, edge_cut = (oa.partition_cells(gm, N, args.partition) if N > 1 else (None, 0))
     decomp = oa.Decomp(gm, N, rank, halo_width, cell_task=cell_task, local_order=args.local_order)

@@ -224,7 +224,11 @@ int omg_peer_create(int nranks, int rank, size_t mailbox_bytes, omg_peer **out);
 int omg_peer_destroy(omg_peer *p);
 int omg_peer_local_handle(const omg_peer *p, char *out /* [OMG_PEER_HANDLE_BYTES] */);
 int omg_peer_connect(omg_peer *p, const char *all_handles /* [nranks][OMG_PEER_HANDLE_BYTES] */);
-/* exchanges issued so far; sticky status (0 = fine, else a wait on a peer gave up); wait bound in seconds */
+/* exchanges issued so far; sticky status (0 = fine, else a wait on a peer gave up: 1 = my previous message was never
+ * consumed, 2 = a neighbour's message never arrived, 4 = an all-gather of omg_halo_global_sum_dd never got a rank's
+ * values; bits may combine); wait bound in seconds.
+ * Lifetime: the wire and the Halo it serves (omg_halo_use_peer) may be destroyed in either order -- each releases the
+ * other; a Halo whose wire has been destroyed has no wire (its next multi-rank exchange returns an error). */
 int omg_peer_info(const omg_peer *p, int64_t *exchanges, int *status);
 int omg_peer_set_timeout(omg_peer *p, double seconds);
 int omg_halo_use_peer(omg_halo *h, omg_peer *p);

@@ -184,7 +184,7 @@ void Decomp::kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const {
       const auto [Lo, Hi] = Stack.back();
       Stack.pop_back();
       const size_t M = Hi - Lo;
-      if (M <= 8)
+      if (M <= 1)
          continue;
       int Ax    = 0;
       R8 BestEx = -1;
@@ -196,6 +196,14 @@ void Decomp::kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const {
             Mn = std::min(Mn, Cd[A][List[I]]), Mx = std::max(Mx, Cd[A][List[I]]);
          if (Mx - Mn > BestEx)
             BestEx = Mx - Mn, Ax = A;
+      }
+      if (M <= 8) {
+         // A leaf.  std::nth_element fixes which cells a side holds, not how it arranges them: the leaf is SORTED with the
+         // same (coordinate, global id) order, so the numbering is a function of the coordinates alone -- every rank
+         // derives every rank's numbering (CellLocAll, the halo lists) whatever its libstdc++ does inside nth_element.
+         const R8 *X = Cd[Ax];
+         std::sort(List.begin() + Lo, List.begin() + Hi, [X](I4 A, I4 B) { return X[A] < X[B] || (X[A] == X[B] && A < B); });
+         continue;
       }
       size_t NL;
       if (M > 32) {

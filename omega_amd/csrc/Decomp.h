@@ -52,7 +52,11 @@ enum PartMethod { PartMethodRCB, PartMethodUser };
 /// kernel's tile -- is a compact, roughly square patch ON THE SURFACE the cells live on.  On a sphere the 3-D Morton and
 /// Hilbert curves cut the surface with an axis-aligned grid: their 16-cell runs are 9.7 cell spacings across and touch
 /// 41.9 distinct cell rows (cell + neighbours) against 4.9 spacings / 35.0 rows for the k-d order and 4.7 / 34 for a
-/// planar 4 x 4 block (QU-sized icosahedral and Fibonacci spheres, 163 842 cells).
+/// planar 4 x 4 block (QU-sized icosahedral and Fibonacci spheres, 163 842 cells).  The alignment holds for the OWNED
+/// group, which starts at local index 0; every halo layer is a group of its own that starts where the previous group
+/// ends (not on a multiple of 32), so a kernel's tile in the halo range is a compact patch only up to that offset.
+/// The leaves (<= 8 cells) are sorted by (coordinate along the leaf's widest axis, global id): the numbering is a
+/// function of the coordinates alone, independent of the standard library's nth_element.
 enum class LocalOrder { GlobalID = 0, Curve = 1, Hilbert = 2, KdTree = 3 };
 
 /// Ordered local element lists of one rank (global 0-based ids) with layer bounds.

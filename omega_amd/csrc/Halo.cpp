@@ -107,9 +107,15 @@ Halo::~Halo() {
 }
 
 void Halo::unbindPeer() {
-   if (Peer)
-      Peer->Bound = false;
+   if (Peer && Peer->BoundTo == this)
+      Peer->BoundTo = nullptr;
    Peer = nullptr;
+}
+
+// ~PeerWire of the wire bound to this Halo: from here on the Halo has no wire
+void Halo::peerWireGone(const PeerWire *Wire) {
+   if (Peer == Wire)
+      Peer = nullptr;
 }
 
 void Halo::setTransport(HaloTransportFn Fn, void *Ctx) {
@@ -134,12 +140,12 @@ void Halo::usePeerWire(PeerWire *Wire) {
    OMEGA_REQUIRE(Wire != nullptr && Wire->connected(), "Halo::usePeerWire: the wire is not connected");
    OMEGA_REQUIRE(Wire->Rank == MyTask, "Halo::usePeerWire: the wire's rank is not this Halo's task");
    OMEGA_REQUIRE(NNghbr <= PeerWire::MaxPeers, "Halo::usePeerWire: too many neighbours");
-   OMEGA_REQUIRE(!Wire->Bound || Peer == Wire, "Halo::usePeerWire: this wire already serves another Halo");
+   OMEGA_REQUIRE(!Wire->bound() || Wire->BoundTo == this, "Halo::usePeerWire: this wire already serves another Halo");
    for (I4 T : NeighborList)
       OMEGA_REQUIRE(T < Wire->NRanks, "Halo::usePeerWire: a neighbour task is outside the wire");
    unbindPeer();
    ensureWireResources();
-   Wire->Bound  = true;
+   Wire->BoundTo = this;
    Peer         = Wire;
    Rccl         = nullptr;
    Transport    = nullptr;
@@ -193,8 +199,8 @@ std::string Halo::wireError() const {
       return ": " + Peer->lastError();
    if (int St = Peer->status())
       return ": PeerWire: a wait for a peer gave up (status " + std::to_string(St) +
-             ": bit 0 = my previous message was never consumed, bit 1 = a neighbour's message never arrived); the halo was "
-             "left as it was";
+             ": bit 0 (1) = my previous message was never consumed, bit 1 (2) = a neighbour's message never arrived, bit 2 (4) "
+             "= an all-gather of a global sum never got a rank's values); after bit 0 / 1 the halo was left as it was";
    return "";
 }
 

@@ -74,9 +74,6 @@ class Halo : public Registry<Halo> {
    I4 exchangeFullArrayHalo(const Array1DReal &A, MeshElement E, hipStream_t S);
    /// One aggregated message per neighbour: [h on cells][u on edges][tracers on cells].
    I4 exchangeState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT, hipStream_t S);
-   /// Initialisation-time half of exchangeState for arrays of these shapes: builds the job tables and allocates the
-   /// message buffers, so that the exchanges inside a time step allocate nothing (the reference allocates its buffers
-   /// in the Halo constructor, Halo.cpp:92-134; here their size depends on what travels together).
    /// globalSum of the reference (base/Reductions.h:71-88, 150-190: MPI_Allreduce with the double-double operator) for
    /// NPairs (<= 64) local double-double partial sums at once: the ranks' (hi, lo) pairs are all-gathered over this
    /// Halo's wire -- ncclAllGather on the RCCL communicator, PeerWire::allGather on the peer wire -- and combined in rank
@@ -86,6 +83,9 @@ class Halo : public Registry<Halo> {
    /// all-gather).
    I4 globalSumDD(const double *LocalPairs, int NPairs, double *HiLo, hipStream_t S);
    static constexpr int MaxSumPairs = 64;
+   /// Initialisation-time half of exchangeState for arrays of these shapes: builds the job tables and allocates the
+   /// message buffers, so that the exchanges inside a time step allocate nothing (the reference allocates its buffers
+   /// in the Halo constructor, Halo.cpp:92-134; here their size depends on what travels together).
    void reserveState(const Array2DReal &H, const Array2DReal &U, const Array3DReal *Tr, int NT);
    /// The wire's verdict after the host has synchronised with an exchange's stream: 0, or -1 when a peer-wire wait gave up
    /// (wireError() then names it).  exchange*() can only report what is known when the work is QUEUED.
@@ -113,6 +113,10 @@ class Halo : public Registry<Halo> {
    const Plan &planFor(const std::vector<Piece> &Pieces);
    I4 exchangePieces(const std::vector<Piece> &Pieces, hipStream_t S);
    void unbindPeer();
+ public:
+   /// called by ~PeerWire of the wire bound to this Halo (the binding is two-way: PeerWire.h)
+   void peerWireGone(const class PeerWire *Wire);
+ private:
    void ensureWireResources();
    void ensureBuffers(size_t SendBytes, size_t RecvBytes);
 

@@ -429,7 +429,10 @@ void HorzMesh::buildCoefficientTables() {
    HostChV = ChV, HostChF = ChF, HostChE = ChE, HostNbrF = NbrF;
    HostChW = ChW;
    CellBad.assign(NCellsSize, 0);
-   for (int Pass = 0; Pass < 8; ++Pass) { // (a pass that finds a new bad cell is followed by one that knows it)
+   // A pass that finds a new bad cell is followed by one that knows it; the set only grows, so the fixed point is
+   // reached after at most NCellsAll + 1 passes (in practice two).  The tables published below are those of a pass
+   // that found nothing new: a CellBad set the Del2 / CellPV / L1 tables do not reflect is never published.
+   for (I8 Pass = 0; Pass <= (I8)NCellsAll + 1; ++Pass) {
       NewBad = false;
       buildDel2Tables();
       buildCellPV();
@@ -437,6 +440,7 @@ void HorzMesh::buildCoefficientTables() {
       if (!NewBad)
          break;
    }
+   OMEGA_REQUIRE(!NewBad, "HorzMesh: the set of cells out of ring order did not reach its fixed point");
    publishBadCells();
    buildBandLists((I4)NCellsHaloH.size());
    buildPatchTables();
@@ -576,6 +580,9 @@ void HorzMesh::buildPatchTables() {
             Pos[Touched[I]] = -1;
          }
       }
+      NPatchTiles[S] = NTiles, NPatchFallback[S] = 0;
+      for (int Tl = 0; Tl < NTiles; ++Tl)
+         NPatchFallback[S] += OK[Tl] ? 0 : 1;
       PatchRowsD[S] = Array1DI4("PatchRows", (int)Rows.size());
       PatchOKD[S]   = Array1DI4("PatchOK", (int)OK.size());
       PatchIdxD[S]  = Array1DI4("PatchIdx", (int)(Idx.size() / 4));

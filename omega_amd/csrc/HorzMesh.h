@@ -234,6 +234,11 @@ class HorzMesh : public Registry<HorzMesh> {
    void publishBadCells();
    Array1DI4 BadCellsD, OrphanVerticesD, NEdgesOnCellRingD;
    std::vector<I4> Orphans;
+   /// tiles per patch size (8, 16, 32 cells) and how many of them do NOT fit the patch (their cells take the per-thread
+   /// gathers inside the same launch): diagnostics, omg_mesh_get_int "NPatchTiles16" / "NPatchFallback16" ...
+ public:
+   I4 NPatchTiles[MeshView::NPatchSizes] = {0, 0, 0}, NPatchFallback[MeshView::NPatchSizes] = {0, 0, 0};
+ private:
    Array1DI4 PatchRowsD[MeshView::NPatchSizes], PatchIdxD[MeshView::NPatchSizes], PatchOKD[MeshView::NPatchSizes];
    Array2DI4 NbrFlagOnCell, VertRingOnCell, NbrVertOnVertex, Del2SelOnVertex;
    Array2DReal Del2GradMaskSOnCell, InvDcOnCell, Del2CurlCoefOnCell, Del2MaskOnVertex, InvDcOnVertex, Del2CurlCoefOnVertex;

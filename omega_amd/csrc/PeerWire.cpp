@@ -1,5 +1,6 @@
 // PeerWire.cpp -- see PeerWire.h.
 #include "PeerWire.h"
+#include "Halo.h"
 
 #include <cstring>
 
@@ -40,6 +41,9 @@ PeerWire::PeerWire(int NRanks_, int Rank_, size_t MailboxBytes_)
 }
 
 PeerWire::~PeerWire() {
+   if (BoundTo)
+      BoundTo->peerWireGone(this);
+   BoundTo = nullptr;
    (void)hipDeviceSynchronize();
    for (int R = 0; R < NRanks; ++R) {
       if (PeerMailbox[R])

@@ -49,8 +49,12 @@ class PeerWire {
    /// the sense that every rank must call it before the first exchange; it does not communicate.
    void connect(const char *All);
    bool connected() const { return Connected; }
-   /// One wire serves ONE Halo (the exchange counter and the mailbox layout are that Halo's): set by Halo::usePeerWire
-   bool Bound = false;
+   /// One wire serves ONE Halo (the exchange counter and the mailbox layout are that Halo's).  The binding is kept from
+   /// both ends (Halo::usePeerWire sets it): whichever of the two objects is destroyed first releases the other, so
+   /// neither a Halo that outlives its wire nor a wire that outlives its Halo is left with a dangling pointer.  A Halo
+   /// whose wire is gone has no wire (its next exchange fails with "no transport"), it does not crash.
+   class Halo *BoundTo = nullptr;
+   bool bound() const { return BoundTo != nullptr; }
 
    void *mailbox() const { return Mailbox; }
    size_t mailboxBytes() const { return MailboxBytes; }
@@ -73,7 +77,8 @@ class PeerWire {
    int allGather(const void *In, int NVals, void *Out, hipStream_t S);
    I8 NGathers = 0;
 
-   /// 0, or the sticky failure raised by a wait kernel that gave up (bit 0: "consumed" wait, bit 1: "arrived" wait).
+   /// 0, or the sticky failure raised by a wait kernel that gave up (bit 0, value 1: "consumed" wait; bit 1, value 2:
+   /// "arrived" wait; bit 2, value 4: an allGather's wait for a rank's values -- the sum it fed is reported as failed).
    /// Once it is raised the unpack kernel of that exchange and of every later one copies nothing and no "consumed"
    /// signal leaves this rank (the neighbours' next exchange then gives up too: the failure spreads instead of a state
    /// with stale halos); the host sees it here after synchronising with the exchange's stream, and the next put() fails.

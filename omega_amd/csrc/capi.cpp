@@ -724,7 +724,13 @@ int omg_mesh_get_int(const omg_mesh *m, const char *name, int32_t *out) {
                                         {"Del2VertOK", W.Del2VertOK},
                                         {"NBandCells", W.NBandCells},
                                         {"NBandSendCells", W.NBandSendCells},
-                                        {"NInteriorCells", W.NInteriorCells}};
+                                        {"NInteriorCells", W.NInteriorCells},
+                                        {"NPatchTiles8", M.NPatchTiles[0]},
+                                        {"NPatchTiles16", M.NPatchTiles[1]},
+                                        {"NPatchTiles32", M.NPatchTiles[2]},
+                                        {"NPatchFallback8", M.NPatchFallback[0]},
+                                        {"NPatchFallback16", M.NPatchFallback[1]},
+                                        {"NPatchFallback32", M.NPatchFallback[2]}};
       auto Jt = D.find(name);
       if (Jt != D.end()) {
          *out = Jt->second;

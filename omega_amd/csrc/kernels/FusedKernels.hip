@@ -1780,7 +1780,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
       __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                        :
                        : "s"(A), "v"(ByteOff), "s"(Rs)
-                       : "memory");
+                       : "memory", "m0"); // (M0 is written: the compiler must not keep a value of its own in it across this)
    }
    /// this wavefront's share of tracer Lt's rows into buffer (It & 1)
    template <class T> __device__ __forceinline__ void fetchTracer(const Lds &L, int Lt, unsigned It, int Kv, bool KvOK) const {

@@ -1,6 +1,6 @@
 """BASELINE configs[4] -- the oRRS18to6-sized mesh (planar 1924 x 1924 = 3 701 776 cells), 80 levels, 37 tracers, 8 GPUs --
 assembled at its stated size: the 8-way graph partition, every rank's Decomp and Halo on the host (no device), and ONE real
-rank of it on the GPU (halo included, 37 tracers, ~ 60 GB of arrays) with a wire that moves nothing.
+rank of it on the GPU (halo included, 37 tracers, ~ 60 GB of arrays) with a wire that delivers the halo's initial-state rows.
 
 The reference reads and partitions the mesh in a distributed way and initialises the state per task
 (components/omega/src/base/Decomp.cpp:108-395 readMesh, :868-1000 partition + scatter; src/ocn/OceanState.cpp:65-117);
@@ -56,7 +56,6 @@ def test_one_real_rank_of_the_eight_on_the_gpu(big):
     d = oa.Decomp(gm, NPARTS, rank, HALO, cell_task=cell_task, local_order="kd")
     mesh = oa.HorzMesh(d, K)
     halo = oa.Halo(d)
-    halo.set_transport(lambda *a: 0)             # a wire that moves nothing (tools/probes/send_band.py)
     for f in ("CellL1OK", "CellPVOK", "CellPVFinalOK", "Del2RingOK", "Del2VertOK"):
         assert mesh.get_int(f) == 1
     cells0 = d.get_array("CellID")[: mesh.NCellsAll] - 1
@@ -99,20 +98,69 @@ def test_one_real_rank_of_the_eight_on_the_gpu(big):
     oa.device_synchronize()
     assert np.array_equal(tend.get(2)[[0, 17, 36], :nc], 4.0 * trT)
     upload()
-    # two overlapped RK4 steps of the rank: band / interior launches, pack and unpack of a 280 MB exchange on the
-    # communication stream.  Nothing arrives -- the unpack kernel copies the (zeroed) receive buffer into the halo, so zeros
-    # and then NaNs walk inwards from the rim, two cells per evaluation: 16 cells in two steps.  What is checked is that
-    # the sequence runs at this size with every resource created beforehand, and that the owned cells it cannot have
-    # reached (most of the 680-cell-wide part) hold a finite, positive thickness.
-    st = oa.TimeStepper("RungeKutta4", 120.0 * (6.0 / 30.0) ** 2, tend, aux, mesh, halo, tracers)
-    st.set_option("OverlapHaloExchange", True)
+
+    # ---- two RK4 steps of the rank, with a wire that can be checked -------------------------------------------------
+    # The other seven ranks do not exist here, but every row of the initial state is a function of its global id: the
+    # wire below delivers, at EVERY exchange, the initial-state rows of this rank's halo elements (a halo frozen at the
+    # initial state: a Dirichlet rim around the part) in the message layout of the real exchange -- per neighbour
+    # [h on its cell list][u on its edge list][37 tracers on its cell list], K values per row (Halo.cpp: planFor; the
+    # reference's layout, Halo.h:344-351).  The receive buffer is written once per buffer address (synchronous copy,
+    # complete before the unpack kernel is queued); every later exchange finds the same bytes.  With that, the band /
+    # interior split, the pack and unpack of a 280 MB exchange, 32-bit plane offsets at 37 tracers and the job table at
+    # this size are all on the path of a result that can be compared: every owned value must stay finite, overlapped
+    # exchanges must give the bits of sequential ones, and stage-fused kernels the bits of the reference-structured
+    # launch sequence.
+    nb = halo.neighbors
+    msgs = []
+    for i in range(len(nb)):
+        lc, le = halo.get_list(i, 0, True), halo.get_list(i, 1, True)
+        assert lc.min() >= nc and le.min() >= ne                    # halo elements only
+        hh_i, uu_i, _ = synthetic_state_rows(g, K, 0, cells0[lc], edges0[le], tracers=[])
+        parts = [hh_i, uu_i]
+        for l in range(NT):
+            parts.append(synthetic_state_rows(g, K, NT, cells0[lc], edges0[:0], tracers=[l])[2][0])
+        msgs.append(np.ascontiguousarray(np.concatenate(parts, axis=0)))
+    filled, calls = set(), []
+
+    def frozen_halo_wire(tasks, send_ptrs, send_bytes, recv_ptrs, recv_bytes, stream_handle):
+        assert list(tasks) == nb
+        for i, m in enumerate(msgs):
+            if recv_bytes[i] != m.nbytes:
+                raise RuntimeError(f"neighbour {tasks[i]}: the exchange expects {recv_bytes[i]} bytes, the state message has {m.nbytes}")
+            if recv_ptrs[i] not in filled:
+                oa.copy_to_device(recv_ptrs[i], m)
+                filled.add(recv_ptrs[i])
+        calls.append(sum(send_bytes))
+        return 0
+    halo.set_transport(frozen_halo_wire)
+    assert sum(m.nbytes for m in msgs) == halo.recv_rows(1 + NT, 1, 0) * K * 8 > 250e6
+
+    dt = 120.0 * (6.0 / 30.0) ** 2
     stream = oa.Stream()
-    n_res = oa.device_resource_count()
-    for _ in range(2):
-        st.do_step(state, stream=stream)
-    oa.device_synchronize()
-    assert oa.device_resource_count() == n_res
-    h1, _ = state.copy_to_host(0)
-    ok = np.isfinite(h1[:nc]).all(axis=1)
-    assert ok.mean() > 0.8, ok.mean()
-    assert h1[:nc][ok].min() > 0.5
+
+    def two_steps(overlap, fuse_stages):
+        state.copy_to_device(h, u, 0)
+        upload()
+        st = oa.TimeStepper("RungeKutta4", dt, tend, aux, mesh, halo, tracers)
+        st.set_option("FuseStageUpdates", fuse_stages)
+        st.set_option("OverlapHaloExchange", overlap)
+        n_res = oa.device_resource_count()
+        n_calls = len(calls)
+        for _ in range(2):
+            st.do_step(state, stream=stream)
+        oa.device_synchronize()
+        assert oa.device_resource_count() == n_res          # nothing is created inside a step
+        assert len(calls) - n_calls == 4                     # two exchange points per RK4 step (RungeKutta4Stepper.cpp:95-131)
+        h1, u1 = state.copy_to_host(0)
+        tr1 = tracers.copy_to_host(0)
+        del st
+        return h1[:nc].copy(), u1[:ne].copy(), tr1[:, :nc].copy()
+
+    ha, ua, ta = two_steps(True, True)
+    assert np.isfinite(ha).all() and np.isfinite(ua).all() and np.isfinite(ta).all()    # EVERY owned value
+    assert ha.min() > 0.5 and np.abs(ha - h[:nc]).max() > 0 and np.abs(ua - u[:ne]).max() > 0
+    hb, ub, tb = two_steps(False, True)
+    assert np.array_equal(ha, hb) and np.array_equal(ua, ub) and np.array_equal(ta, tb), "overlapped != sequential"
+    del hb, ub, tb
+    hc, uc, tc = two_steps(False, False)
+    assert np.array_equal(ha, hc) and np.array_equal(ua, uc) and np.array_equal(ta, tc), "stage-fused != reference-structured"
