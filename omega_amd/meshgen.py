@@ -440,27 +440,47 @@ def spherical_voronoi(n_cells: int = 0, *, points=None, radius: float = 6371220.
         r = np.sqrt(1.0 - z * z)
         pts = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
 
+    # Everything below is vectorised over padded [nCells, maxEdges] region tables; the arithmetic per element -- which
+    # operands, in which order -- is that of the loop-per-cell generator of rounds 1-4 (kept as tests/meshgen_loops.py),
+    # so the arrays are the same bit for bit (tests/test_meshgen_rows.py) at a tenth of the time.
     def regions_ccw(sv):
+        """(reg [nC, maxE] vertex ids CCW seen from outside, -1 padded; n [nC])"""
         sv.sort_vertices_of_regions()
-        out = []
-        for c, reg in enumerate(sv.regions):
-            v = sv.vertices[reg]
-            p = sv.points[c]
-            if np.dot(np.cross(v[0] - p, v[1] - p), p) < 0:
-                reg = reg[::-1]
-            out.append(list(reg))
-        return out
+        n = np.fromiter(map(len, sv.regions), dtype=np.int64, count=len(sv.regions))
+        flat = np.fromiter(chain.from_iterable(sv.regions), dtype=np.int64, count=int(n.sum()))
+        width = int(n.max())
+        j = np.arange(width)[None, :]
+        valid = j < n[:, None]
+        reg = np.full((len(n), width), -1, dtype=np.int64)
+        reg[valid] = flat
+        p = sv.points
+        v0, v1 = sv.vertices[reg[:, 0]], sv.vertices[reg[:, 1]]
+        flip = np.einsum("ij,ij->i", np.cross(v0 - p, v1 - p), p) < 0
+        src = np.where(flip[:, None] & valid, n[:, None] - 1 - j, j)
+        reg = np.where(valid, np.take_along_axis(reg, np.where(valid, src, 0), axis=1), -1)
+        return reg, n
 
+    def fan(pc, xvert, reg, n):
+        """per cell and slot j: the unit-sphere triangle (cell point, v_j, v_j+1) -> (v_j, v_j+1, area), masked slots 0"""
+        j = np.arange(reg.shape[1])[None, :]
+        valid = j < n[:, None]
+        nxt = np.take_along_axis(reg, np.where(valid, (j + 1) % n[:, None], 0), axis=1)
+        va, vb = xvert[np.where(valid, reg, 0)], xvert[np.where(valid, nxt, 0)]
+        w = _sph_tri_area(np.broadcast_to(pc[:, None, :], va.shape).reshape(-1, 3), va.reshape(-1, 3),
+                          vb.reshape(-1, 3)).reshape(valid.shape)
+        return va, vb, np.where(valid, w, 0.0), valid
+
+    from itertools import chain
     for _ in range(lloyd):
         sv = SphericalVoronoi(pts, 1.0)
-        new = np.empty_like(pts)
-        for c, reg in enumerate(regions_ccw(sv)):
-            v = sv.vertices[reg]
-            p = pts[c]
-            w = _sph_tri_area(p[None], v, np.roll(v, -1, axis=0))
-            cen = ((p[None] + v + np.roll(v, -1, axis=0)) * w[:, None]).sum(0)
-            new[c] = cen / np.linalg.norm(cen)
-        pts = new
+        reg, n = regions_ccw(sv)
+        va, vb, w, valid = fan(pts, sv.vertices, reg, n)
+        term = np.where(valid[:, :, None], (pts[:, None, :] + va + vb) * w[:, :, None], 0.0)
+        cen = term[:, 0, :].copy()
+        for j in range(1, reg.shape[1]):      # sequential over the slots, as a sum over axis 0 of [n, 3] runs
+            cen = np.where(valid[:, j, None], cen + term[:, j, :], cen)
+        # (the norm of ONE vector is sqrt(x.dot(x)) -- a BLAS dot, whose rounding np.linalg.norm(cen, axis=1) does not share)
+        pts = cen / np.sqrt(np.fromiter((x.dot(x) for x in cen), dtype=np.float64, count=len(cen)))[:, None]
     if sort:
         lon = np.arctan2(pts[:, 1], pts[:, 0]) + np.pi
         qa = np.minimum((lon / (2 * np.pi) * 1024).astype(np.int64), 1023)
@@ -471,65 +491,59 @@ def spherical_voronoi(n_cells: int = 0, *, points=None, radius: float = 6371220.
             key |= ((qb >> b) & 1) << (2 * b + 1)
         pts = pts[np.argsort(key, kind="stable")]
     sv = SphericalVoronoi(pts, 1.0)
-    regs = regions_ccw(sv)
+    reg, nreg = regions_ccw(sv)
     xv = sv.vertices
     nC, nV = n_cells, len(xv)
-    maxE = max(len(rg) for rg in regs)
-    nEoc = np.array([len(rg) for rg in regs], dtype=I4)
+    maxE = reg.shape[1]
+    nEoc = nreg.astype(I4)
+    jj = np.arange(maxE)[None, :]
+    valid = jj < nreg[:, None]
+    nxt = np.take_along_axis(reg, np.where(valid, (jj + 1) % nreg[:, None], 0), axis=1)
+    # edges in order of first encounter over (cell ascending, slot ascending); an edge = an unordered vertex pair
+    cc = np.broadcast_to(np.arange(nC, dtype=np.int64)[:, None], reg.shape)[valid]
+    fa, fb = reg[valid], nxt[valid]
+    pair = np.minimum(fa, fb) * nV + np.maximum(fa, fb)
+    _, first, inv = np.unique(pair, return_index=True, return_inverse=True)
+    nE = len(first)
+    rank = np.empty(nE, dtype=np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(nE)
+    e_flat = rank[inv]
+    assert nE == nC + nV - 2 and len(pair) == 2 * nE, "not a closed Voronoi tessellation"
+    occ = np.argsort(e_flat, kind="stable")            # the two occurrences of every edge, the first one first
+    assert np.array_equal(e_flat[occ[0::2]], np.arange(nE)) and np.array_equal(e_flat[occ[1::2]], np.arange(nE))
+    coe = np.stack([cc[occ[0::2]], cc[occ[1::2]]], axis=1).astype(I4)
+    voe = np.stack([fa[occ[0::2]], fb[occ[0::2]]], axis=1).astype(I4)   # CCW around cell 0 == along k x n
     eoc = np.full((nC, maxE), -1, dtype=I4)
     voc = np.full((nC, maxE), -1, dtype=I4)
     coc = np.full((nC, maxE), -1, dtype=I4)
-    edge_of = {}
-    coe, voe = [], []
-    for c, rg in enumerate(regs):
-        n = len(rg)
-        for j in range(n):
-            va, vb = rg[j], rg[(j + 1) % n]
-            key = (va, vb) if va < vb else (vb, va)
-            e = edge_of.get(key)
-            if e is None:
-                e = len(coe)
-                edge_of[key] = e
-                coe.append([c, -1])
-                voe.append([va, vb])     # CCW around cell 0 == along k x n
-            else:
-                coe[e][1] = c
-            eoc[c, j] = e
-            voc[c, j] = vb               # vertex between edge j and edge j+1
-    coe = np.array(coe, dtype=I4)
-    voe = np.array(voe, dtype=I4)
-    nE = len(coe)
-    assert (coe >= 0).all() and nE == nC + nV - 2, "not a closed Voronoi tessellation"
-    for c in range(nC):
-        for j in range(nEoc[c]):
-            e = eoc[c, j]
-            coc[c, j] = coe[e, 1] if coe[e, 0] == c else coe[e, 0]
+    eoc[valid] = e_flat
+    voc[valid] = fb                                     # vertex between edge j and edge j+1
+    coc[valid] = np.where(coe[e_flat, 0] == cc, coe[e_flat, 1], coe[e_flat, 0])
+    regs_valid, regs = valid, reg
     # vertices: the three edges / cells around, counter-clockwise
-    eov_l = [[] for _ in range(nV)]
-    for e in range(nE):
-        eov_l[voe[e, 0]].append(e)
-        eov_l[voe[e, 1]].append(e)
     xe = pts[coe[:, 0]] + pts[coe[:, 1]]
     xe /= np.linalg.norm(xe, axis=1)[:, None]
+    ev = np.concatenate([voe[:, 0], voe[:, 1]]).astype(np.int64)
+    ee = np.concatenate([np.arange(nE), np.arange(nE)])
+    o = np.lexsort((ee, ev))                            # by vertex, then by edge id
+    assert len(o) == 3 * nV and np.array_equal(ev[o].reshape(nV, 3)[:, 0], np.arange(nV)) \
+        and (ev[o].reshape(nV, 3) == np.arange(nV)[:, None]).all(), "degenerate Voronoi vertex"
+    es = ee[o].reshape(nV, 3)
+    ref = xe[es[:, 0]] - xv
+    ang = np.zeros((nV, 3))
+    for k in (1, 2):
+        d = xe[es[:, k]] - xv
+        ang[:, k] = np.arctan2(np.einsum("ij,ij->i", np.cross(ref, d), xv), np.einsum("ij,ij->i", ref, d)) % (2 * np.pi)
+    swap = ang[:, 2] < ang[:, 1]
+    es = np.where(swap[:, None], es[:, [0, 2, 1]], es)
+    eov = es.astype(I4)
     cov = np.empty((nV, 3), dtype=I4)
-    eov = np.empty((nV, 3), dtype=I4)
-    for v in range(nV):
-        es = eov_l[v]
-        assert len(es) == 3, "degenerate Voronoi vertex"
-        p = xv[v]
-        ref = xe[es[0]] - p
-        ang = []
-        for e in es:
-            d = xe[e] - p
-            ang.append(np.arctan2(np.dot(np.cross(ref, d), p), np.dot(ref, d)) % (2 * np.pi))
-        es = [es[k] for k in np.argsort(ang)]
-        # cell k lies between edge k-1 and edge k (CCW): the cell shared by both
-        for k in range(3):
-            ea, eb = es[(k + 2) % 3], es[k]
-            sh = set(coe[ea]) & set(coe[eb])
-            assert len(sh) == 1
-            cov[v, k] = sh.pop()
-        eov[v] = es
+    for k in range(3):    # cell k lies between edge k-1 and edge k (CCW): the cell shared by both
+        ca, cb = coe[es[:, (k + 2) % 3]], coe[es[:, k]]
+        hit0 = (ca[:, 0] == cb[:, 0]) | (ca[:, 0] == cb[:, 1])
+        hit1 = (ca[:, 1] == cb[:, 0]) | (ca[:, 1] == cb[:, 1])
+        assert (hit0 ^ hit1).all()
+        cov[:, k] = np.where(hit0, ca[:, 0], ca[:, 1])
     m = {"nCells": nC, "nEdges": nE, "nVertices": nV, "maxEdges": maxE, "vertexDegree": 3,
          "on_a_sphere": True, "sphere_radius": radius}
     m["nEdgesOnCell"], m["edgesOnCell"], m["verticesOnCell"], m["cellsOnCell"] = nEoc, eoc, voc, coc
@@ -541,10 +555,12 @@ def spherical_voronoi(n_cells: int = 0, *, points=None, radius: float = 6371220.
     R2 = radius * radius
     m["dcEdge"] = radius * _arc(pts[coe[:, 0]], pts[coe[:, 1]])
     m["dvEdge"] = radius * _arc(xv[voe[:, 0]], xv[voe[:, 1]])
-    area = np.zeros(nC)
-    for c, rg in enumerate(regs):
-        v = xv[rg]
-        area[c] = _sph_tri_area(pts[c][None], v, np.roll(v, -1, axis=0)).sum()
+    _, _, w, _ = fan(pts, xv, regs, nreg)
+    area = w[:, 0].copy()
+    for j in range(1, maxE):                  # a sum of < 8 numbers runs in order
+        area = np.where(regs_valid[:, j], area + w[:, j], area)
+    for c in np.flatnonzero(nreg >= 8):       # (numpy sums 8 and more in blocks: leave those cells to it)
+        area[c] = w[c, : nreg[c]].sum()
     m["areaCell"] = R2 * area
     m["areaTriangle"] = R2 * _sph_tri_area(pts[cov[:, 0]], pts[cov[:, 1]], pts[cov[:, 2]])
     kite = np.empty((nV, 3))
