@@ -38,6 +38,8 @@ const OptionName OptionTable[] = {
     {"SendBand", &TuningOptions::SendBand},
     {"BandOnComm", &TuningOptions::BandOnComm},
     {"ShrinkSweeps", &TuningOptions::ShrinkSweeps},
+    {"ProbeSlice", &TuningOptions::ProbeSlice},
+    {"ProbeBlocks", &TuningOptions::ProbeBlocks},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},

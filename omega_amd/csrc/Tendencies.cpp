@@ -1,6 +1,7 @@
 // Tendencies.cpp -- see Tendencies.h.
 #include "Tendencies.h"
 #include "Pacer.h"
+#include "kernels/KernelCommon.h"
 
 namespace OMEGA {
 
@@ -166,6 +167,29 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
                         NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
                         EdgeScratch.Ptr, nullptr, Mesh->narrowView());
       };
+      if (const int Probe = tuning().ProbeSlice; Probe > 0) {
+         // MEASUREMENT PROBE (KernelCommon.h: SliceWindow): the same kernels as (blocks x level chunks x levels) launches
+         SliceWindow &W  = sliceWindow();
+         const int NChunks = (levelPitch(NVertLayers) * 8 + 127) / 128, NBlk = std::max(1, tuning().ProbeBlocks);
+         W.Active = 1, W.CS = NChunks, W.NBlk = NBlk;
+         auto One = [&](int C, int B, int L) {
+            W.C0 = C, W.Blk = B, W.LevelMask = 1 << L;
+            Launch();
+         };
+         if (Probe == 1) { // cache-blocked order: a block's three levels back to back
+            for (int C = 0; C < NChunks; ++C)
+               for (int B = 0; B < NBlk; ++B)
+                  for (int L = 0; L < 3; ++L)
+                     One(C, B, L);
+         } else { // the same launches level by level: every intermediate makes the trip through HBM
+            for (int L = 0; L < 3; ++L)
+               for (int C = 0; C < NChunks; ++C)
+                  for (int B = 0; B < NBlk; ++B)
+                     One(C, B, L);
+         }
+         W = SliceWindow{};
+         return;
+      }
       // wind forcing reads the stress arrays through a non-tile kernel too, still plain launches: capturable
       if (graphsOn() && !Ev && !CustomThicknessTend && !CustomVelocityTend) {
          GraphCache::Key Key;

@@ -39,6 +39,9 @@ struct TuningOptions {
    int NarrowTables = 1; ///< hexagon-dominant meshes with heptagons: second, MaxEdges-1 wide set of cell tables
    // ---- local numbering (read when a Decomp is constructed with a curve order)
    int WaveWindow = 0; ///< >= 16: cells regrouped inside windows of this many consecutive cells so that a wave's 8 cells finish the same edge slots (Decomp.h)
+   // ---- measurement probe (KernelCommon.h: SliceWindow; timings only, rim values of the blocks are wrong)
+   int ProbeSlice  = 0; ///< 1: the plain fused RHS block by block, per block L1 -> L2 -> L3 (what a cache-blocked walk would read back from the memory-side cache); 2: the same launches level by level (nothing resident): the difference is what the residency is worth
+   int ProbeBlocks = 1; ///< blocks of tiles per level chunk under ProbeSlice
    // ---- HIP-graph replay: -1 = as each object's UseGraphs says, 0 = never, 1 = default on
    int Graphs = -1;
 };

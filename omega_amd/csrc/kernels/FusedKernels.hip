@@ -2216,6 +2216,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    Flip();
    // L1: replaces AuxState:vertexAuxState1, cellAuxState1, edgeAuxState1/2 (flux thickness), cellAuxState4 (Del2Tracers),
    // Tend:thicknessFluxDiv and the cell-0 half of Tend:potientialVortHAdv
+   sliceWindow().Level = 0;
    Pacer::start("Tend:fused:L1[AuxState:vertexAuxState1,cellAuxState1,edgeAuxState2,cellAuxState4;Tend:thicknessFluxDiv]", 2);
    Mark(0);
    // the vertex kernel stores RelVort and 1/LayerThickVertex; the two normalised vorticities are rebuilt from
@@ -2341,6 +2342,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    Pacer::stop("Tend:fused:L1", 2);
    Flip();
    // L2 (only the del4 term consumes it): replaces AuxState:edgeAuxState3 (Del2Edge), cellAuxState2, vertexAuxState2
+   sliceWindow().Level = 1;
    Pacer::start("Tend:fused:L2[AuxState:vertexAuxState2,cellAuxState2]", 2);
    Mark(2);
    // independent sweeps share a launch (KernelCommon.h: tileKernel2); option Pair = 0 launches them one by one
@@ -2404,6 +2406,7 @@ static void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, 
    Flip();
    // L3: replaces Tend:potientialVortHAdv, KEGrad, SSHGrad, velocityDiffusion, velocityHyperDiff, windForcing, bottomDrag,
    // AuxState:edgeAuxState4 (HTracersEdge) and Tend:tracerHorzAdv, tracerDiffusion, tracerHyperDiff
+   sliceWindow().Level = 2;
    Pacer::start("Tend:fused:L3[Tend:potientialVortHAdv,KEGrad,SSHGrad,velocityDiffusion,velocityHyperDiff,tracerHorzAdv,"
                 "tracerDiffusion,tracerHyperDiff]", 2);
    Mark(4);

@@ -225,19 +225,44 @@ template <class B> struct BodyMaxW<B, decltype((void)B::MaxW)> {
    static constexpr int V = B::MaxW;
 };
 
+/// MEASUREMENT PROBE (option ProbeSlice, Tendencies.cpp: computeAllTendencies; never on in production): the launches of
+/// the fused RHS restricted to ONE level chunk (C0 of CS) and to block Blk of NBlk of every sweep's tiles, and only the
+/// launches of the dependency levels in LevelMask.  Lets the three levels be walked block by block -- the order in which
+/// a block's intermediates would still sit in the 256 MiB memory-side cache when the next level reads them -- with the
+/// production kernels, to measure what that residency is worth before building a kernel architecture around it.
+/// The blocks ignore the neighbour dependencies across their rims: timings only, the rim values are wrong.
+struct SliceWindow {
+   int Active = 0, C0 = 0, CS = 1, Blk = 0, NBlk = 1, LevelMask = 7, Level = 0;
+};
+inline SliceWindow &sliceWindow() {
+   static thread_local SliceWindow W;
+   return W;
+}
+/// tiles [Begin, Begin + Count) of a sweep of NTiles tiles under the window
+inline void sliceTiles(int NTiles, int &Begin, int &Count) {
+   const SliceWindow &W = sliceWindow();
+   Begin = 0, Count = NTiles;
+   if (W.Active) {
+      Begin = (int)((long)NTiles * W.Blk / W.NBlk);
+      Count = (int)((long)NTiles * (W.Blk + 1) / W.NBlk) - Begin;
+   }
+}
+
 #ifndef OMEGA_LB
 #define OMEGA_LB 256
 #endif
 template <class Body, class T>
 __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
-    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit, int Rev) {
+    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit, int Rev, int TileBegin, int WinC0, int WinCS) {
    extern __shared__ __align__(16) unsigned char Lds[];
    // level chunks of this workgroup: C0, C0 + CS, ...  (whole tile: gridDim.y-way split; tail tile: one chunk each)
-   int TileId, C0 = blockIdx.y, CS = gridDim.y;
+   // (TileBegin, WinC0, WinCS = 0, 0, 1 except under the measurement probe: SliceWindow)
+   int TileId, C0 = blockIdx.y + WinC0, CS = gridDim.y * WinCS;
    if ((int)blockIdx.x < NFull) {
       TileId = xcdRemap(blockIdx.x, NFull);
       if (Rev) // (sweepDirection: this sweep walks the elements from the end, see launchTile)
          TileId = NFull - 1 - TileId;
+      TileId += TileBegin;
    } else {
       const int Bt = blockIdx.x - NFull;
       TileId       = NFull + Bt / TailSplit;
@@ -282,13 +307,14 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
 template <class BA, class BB, class T>
 __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<BB>::V ? BodyMinWaves<BA>::V
                                                                                        : BodyMinWaves<BB>::V))
-    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit, int Rev) {
+    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit, int Rev,
+                int TileBeginA, int TileBeginB, int WinC0, int WinCS) {
    extern __shared__ __align__(16) unsigned char Lds[];
    const int Tid  = threadIdx.y * blockDim.x + threadIdx.x;
    const int NThr = blockDim.x * blockDim.y;
    if ((int)blockIdx.x < NTilesA) {
       const int Ta    = xcdRemap(blockIdx.x, NTilesA);
-      const int First = (Rev ? NTilesA - 1 - Ta : Ta) * Tile;
+      const int First = (TileBeginA + (Rev ? NTilesA - 1 - Ta : Ta)) * Tile;
       const int Cnt   = NA - First < Tile ? NA - First : Tile;
       typename BA::Lds L = A.carve(Lds, Tile);
       if (Cnt > 0)
@@ -298,7 +324,7 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       return;
 #endif
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
+         for (int Kv = (blockIdx.y + WinC0) * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y * WinCS)
          {
             chunkFence<BA>();
             A.template compute<T>(L, Le, First + Le, Kv);
@@ -306,11 +332,12 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
    } else {
       // (the second body's last tiles are the launch's tail: one level chunk per workgroup, see Geom::TailSplit)
       const int Bb_ = blockIdx.x - NTilesA;
-      int TileId, C0 = blockIdx.y, CS = gridDim.y;
+      int TileId, C0 = blockIdx.y + WinC0, CS = gridDim.y * WinCS;
       if (Bb_ < NFullB) {
          TileId = xcdRemap(Bb_, NFullB);
          if (Rev)
             TileId = NFullB - 1 - TileId;
+         TileId += TileBeginB;
       } else {
          TileId = NFullB + (Bb_ - NFullB) / TailSplit;
          C0     = (Bb_ - NFullB) % TailSplit;
@@ -386,14 +413,27 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
    Geom G           = makeGeom(N, K, BodyMaxW<Body>::V, B.K, bodyMaxTY(B));
    setWaves(B, G);
    const size_t Lds = B.ldsBytes(G.Tile);
+   int TileBegin = 0, WinC0 = 0, WinCS = 1;
+   if (const SliceWindow &Win = sliceWindow(); Win.Active) { // measurement probe: one block of tiles, one level chunk
+      if (!(Win.LevelMask >> Win.Level & 1))
+         return;
+      int Cnt;
+      sliceTiles((N + G.Tile - 1) / G.Tile, TileBegin, Cnt);
+      if (Cnt <= 0)
+         return;
+      G.Grid = dim3(Cnt, 1, 1), G.NFull = Cnt, G.TailSplit = 1;
+      WinC0 = Win.C0, WinCS = Win.CS;
+   }
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev);
+         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev,
+                            TileBegin, WinC0, WinCS);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev);
+   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev,
+                      TileBegin, WinC0, WinCS);
    HIP_CHECK(hipGetLastError());
 }
 
@@ -431,16 +471,29 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
          Grid      = dim3(NTA + NFullB + R * TailSplit, 1, 1);
       }
    }
+   int NTAw = NTA, TileBeginA = 0, TileBeginB = 0, WinC0 = 0, WinCS = 1;
+   if (const SliceWindow &Win = sliceWindow(); Win.Active) { // measurement probe: one block of each sweep, one chunk
+      if (!(Win.LevelMask >> Win.Level & 1))
+         return;
+      int CntB;
+      sliceTiles(NTA, TileBeginA, NTAw);
+      sliceTiles(NTB, TileBeginB, CntB);
+      if (NTAw + CntB <= 0)
+         return;
+      NFullB = CntB, TailSplit = 1;
+      Grid   = dim3(NTAw + CntB, 1, 1);
+      WinC0 = Win.C0, WinCS = Win.CS;
+   }
    if constexpr (BodyMaxW<BA>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
-                            TailSplit, sweepDirection());
+         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTAw, NFullB,
+                            TailSplit, sweepDirection(), TileBeginA, TileBeginB, WinC0, WinCS);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
-                      TailSplit, sweepDirection());
+   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTAw, NFullB,
+                      TailSplit, sweepDirection(), TileBeginA, TileBeginB, WinC0, WinCS);
    HIP_CHECK(hipGetLastError());
 }
 
@@ -508,6 +561,7 @@ template <class B> inline void prepBody(B &Body, int K) {
 template <class B0, class B1> void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N1) {
    static_assert(BodyMaxW<B0>::V == BodyMaxW<B1>::V, "launchTileV: bodies must agree on the levels per thread");
    static_assert(sizeof(B0) + sizeof(B1) + sizeof(SweepPlan) <= 3900, "launchTileV: kernel arguments exceed 4 KiB");
+   OMEGA_REQUIRE(!sliceWindow().Active, "the ProbeSlice measurement covers list-free meshes only (launchTile / launchTile2)");
    B0 X0 = A0;
    B1 X1 = A1;
    detail::prepBody(X0, K), detail::prepBody(X1, K);
@@ -541,6 +595,7 @@ void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N
    static_assert(BodyMaxW<B0>::V == BodyMaxW<B1>::V && BodyMaxW<B0>::V == BodyMaxW<B2>::V,
                  "launchTileV: bodies must agree on the levels per thread");
    static_assert(sizeof(B0) + sizeof(B1) + sizeof(B2) + sizeof(SweepPlan) <= 3900, "launchTileV: kernel arguments exceed 4 KiB");
+   OMEGA_REQUIRE(!sliceWindow().Active, "the ProbeSlice measurement covers list-free meshes only (launchTile / launchTile2)");
    B0 X0 = A0;
    B1 X1 = A1;
    B2 X2 = A2;
