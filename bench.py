@@ -137,7 +137,7 @@ def workload_mesh(workload, block=1, max_edges=0):
 
 def algorithmic_bytes_per_cell_level(nt, kernel=None):
     """SURVEY.md 8(d) B_staged = 8*(39 + 5*NT) B per cell-level for the whole RHS (NE = 3NC,
-    NV = 2NC); per kernel: the arrays that kernel must read / write once (DESIGN.md section 5)."""
+    NV = 2NC); per kernel: the arrays that kernel must read / write once (DESIGN.md section 4)."""
     per_kernel = {
         "VortVertexBody": 8 * (1 + 3 + 2 * 2),                 # h, u -> RelVort, 1/LayerThickVertex
         "FusedCell1Body": 8 * (3 + 1 + nt + 3 + nt),            # u, h, tr -> KE, Div, hTend, Del2Tr
