@@ -189,6 +189,10 @@ def parse_args(argv=None):
                          "RHS -1..-3 %% planar, -2.8 %% on the icosahedral sphere), curve / hilbert = along a Morton / Hilbert "
                          "curve through the cell centres, global = the reference's global-id order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: skip the two rocprofv3 --pmc child runs (FETCH_SIZE; WRITE_SIZE) that measure roofline.traffic "
+                         "in this very run; traffic then comes from a committed profiles/*_pmc.json measured on the same kernel "
+                         "sources, or is null")
     ap.add_argument("--realistic", default="auto",
                     help="N = 1: after the headline measurement, the same W + K evaluations on a realistically shaped mesh "
                          "(record key `realistic`).  auto (default) = fib7_coast when the headline workload is qu30, none "
@@ -308,6 +312,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
     N = world
+    live = live_note = None
+    if N == 1 and not args.no_live_traffic:
+        live, live_note = live_traffic(args)      # (child processes; this one has not loaded the HIP runtime yet)
+        if live is None:
+            print(f"[bench] no live HBM-traffic measurement: {live_note}", file=sys.stderr, flush=True)
     load_library()
     launcher = ("bench.py itself (fresh child processes per rank)" if os.environ.get("OMEGA_BENCH_LAUNCHER") == "self" else
                 "torch.distributed.run (or an equivalent that sets WORLD_SIZE / RANK)" if "WORLD_SIZE" in os.environ else
@@ -478,7 +487,16 @@ def main():
         # measured on exactly the kernel sources that run here (hash recorded in the file) and on this workload
         # counts; otherwise traffic is null rather than stale.
         traffic = traffic_src = None
-        if N == 1 and not args.unfused:
+
+        def bases(n):     # "A<6, 6>+B<7, 7>" -> "A+B" (template arguments contain commas and, nested, '+' never)
+            # (CellPVFinalTracerPatchBody is CellPVFinalTracerBody with its tracer loop through LDS patches: the
+            # library reports both under the latter name)
+            return "+".join(x.split("<")[0].strip().replace("TracerPatchBody", "TracerBody") for x in n.split("+"))
+        if live:
+            cands = sorted((v for k, v in live.items() if bases(k) == bases(name)))
+            if cands:
+                traffic, traffic_src = cands[0], live_note
+        if traffic is None and N == 1 and not args.unfused:
             import glob
             from tools.summarise_profile import kernel_source_sha
             sha = kernel_source_sha()
@@ -491,10 +509,6 @@ def main():
                     wl = pa[pa.index("--workload") + 1]
                 if pmc.get("kernel_source_sha") != sha or wl != args.workload:
                     continue
-                def bases(n):     # "A<6, 6>+B<7, 7>" -> "A+B" (template arguments contain commas and, nested, '+' never)
-                    # (CellPVFinalTracerPatchBody is CellPVFinalTracerBody with its tracer loop through LDS patches: the
-                    # library reports both under the latter name)
-                    return "+".join(x.split("<")[0].strip().replace("TracerPatchBody", "TracerBody") for x in n.split("+"))
                 base = bases(name)
                 cands = [k for k, rec in pmc.items() if isinstance(rec, dict) and bases(k) == base]
                 # the RK4 stage-fused instantiations of the same body move more bytes (accumulator, provisional
@@ -512,6 +526,7 @@ def main():
                     "kernel_timing": "HIP events on the launch stream between the launches, in a second pass of the same "
                                      "steps right after the timed region",
                     "kernels_ms": {k: round(v, 4) for k, v in ktimes},
+                    "kernels_hbm_bytes_per_launch_live": ({k: round(v) for k, v in live.items()} if live else None),
                     "rhs": {"algorithmic_bytes_per_cell_level": algorithmic_bytes_per_cell_level(NT),
                             "ms": round(rhs_ms, 4), "kernels_sum_ms": round(kernels_sum_ms, 4), "achieved": round(rhs_ach, 1),
                             "frac": round(rhs_ach / HBM_PEAK_GBS, 4)}}
@@ -863,6 +878,56 @@ def main():
         dist.destroy_process_group()
     if N > 1 and rk4_error:
         sys.exit(3)   # the RHS record above stands; the stepping part failed and says so in rk4.error
+
+
+def live_traffic(args):
+    """roofline.traffic measured IN THIS RUN (N = 1): before this process loads the HIP runtime, two short child runs of
+    this same script under `rocprofv3 --pmc` -- FETCH_SIZE in one, WRITE_SIZE in the other: the two do not fit one pass,
+    and counters never share a run with the trace domains (MI355X_MICROARCH.md, HBM / rocprofv3 section) -- on the same
+    workload, numbering and options.  HBM bytes per launch = FETCH_SIZE [KB] x 1024 x 2 (gfx950 tallies the 128-byte
+    requests of 16-byte-per-lane loads at 64 B) + WRITE_SIZE [KB] x 1024, averaged over the launches of each kernel.
+    The children are ordinary child processes started with the program itself after `--` (no exec from a process that
+    has touched the GPU: this one has not yet).  Returns ({kernel: bytes per launch}, note) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    from tools.summarise_profile import counters
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1", "--rk4-steps", "0",
+             "--no-cpu-baseline", "--no-live-traffic", "--realistic", "none", "--settle-ms", "0", "--local-order", args.local_order,
+             "--block", str(args.block), "--max-edges", str(args.max_edges)] + (["--unfused"] if args.unfused else [])
+    work = tempfile.mkdtemp(prefix="omega_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    t0 = time.time()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, ctr)
+            with open(os.path.join(work, ctr + ".log"), "wb") as log:
+                r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", *child], env=env, cwd=ROOT,
+                                   stdout=log, stderr=subprocess.STDOUT, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} child run ended with code {r.returncode}"
+            rows = counters(d)
+            for k, v in rows.items():
+                if v.get(ctr):
+                    got.setdefault(k, {})[ctr] = (sum(v[ctr]) / len(v[ctr]), len(v[ctr]))
+    except subprocess.TimeoutExpired:
+        return None, "a rocprofv3 --pmc child run did not finish within 240 s"
+    except Exception as exc:  # noqa: BLE001  (the measurement proper must not depend on the profiler)
+        return None, f"{type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out = {k: 2.0 * 1024.0 * v["FETCH_SIZE"][0] + 1024.0 * v["WRITE_SIZE"][0] for k, v in got.items()
+           if "FETCH_SIZE" in v and "WRITE_SIZE" in v and "Body" in k}
+    if not out:
+        return None, "the PMC passes recorded none of the RHS kernels"
+    n = min(v["FETCH_SIZE"][1] for k, v in got.items() if k in out)
+    return out, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two child runs of `bench.py --workload "
+                 f"{args.workload} --steps 3 --warmup 1` before the timed process touched the GPU ({time.time() - t0:.0f} s, >= {n} launches "
+                 "per kernel); FETCH_SIZE x 2 (gfx950 half-count of 16-B-per-lane reads) + WRITE_SIZE")
 
 
 def staged_bytes_exact(nc, ne, nv, nt, k):

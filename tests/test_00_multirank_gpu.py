@@ -215,7 +215,7 @@ def test_bench_with_two_ranks_on_one_gpu():
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "small", "--no-cpu-baseline"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "small", "--no-cpu-baseline", "--no-live-traffic"]
     r1 = subprocess.run([*base, "--gpus", "1"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r1.returncode == 0, r1.stderr.decode()[-2000:]
     one = json.loads(r1.stdout.decode().strip().splitlines()[-1])

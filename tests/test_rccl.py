@@ -41,3 +41,37 @@ def test_self_exchange_on_a_user_stream():
     assert comm.info()["exchanges"] == 3
     with pytest.raises(oa.OmegaAmdError, match="bad peer"):
         comm.exchange([1], [src.ptr], [8], [dst.ptr], [8], stream=st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wire_first", [True, False])
+def test_halo_and_peer_wire_may_be_destroyed_in_either_order(wire_first):
+    """The binding Halo <-> PeerWire is kept from both ends (bench.py and the multi-rank workers close the wire
+    while the Halo it serves is still alive; the Halo's destructor then wrote into the freed wire).  One rank: a wire
+    connected to itself, bound, and both objects destroyed -- wire first, then Halo, and the other way round -- with the
+    survivor used in between: a Halo whose wire is gone simply has no wire, a wire whose Halo is gone can serve another."""
+    from omega_amd.meshgen import planar_hex
+    assert oa.device_count() > 0
+    oa.device_init(0)
+    gm = oa.GlobalMesh(planar_hex(8, 8, 30e3))
+    d = oa.Decomp(gm, 1, 0, 3)
+    halo = oa.Halo(d)
+    wire = oa.PeerWire(1, 0, 4096)
+    wire.connect([wire.handle()])
+    halo.use_peer(wire)
+    halo2 = oa.Halo(d)
+    with pytest.raises(oa.OmegaAmdError, match="already serves another Halo"):
+        halo2.use_peer(wire)
+    if wire_first:
+        wire.close()                      # omg_peer_destroy: the Halo is told (PeerWire.cpp: ~PeerWire)
+        halo.check()                      # no wire: nothing to report, and no dangling pointer is followed
+        oa.lib().omg_halo_destroy(halo.h)
+        halo.h = None
+    else:
+        oa.lib().omg_halo_destroy(halo.h)  # ~Halo releases the wire ...
+        halo.h = None
+        halo2.use_peer(wire)               # ... which can serve another Halo
+        assert wire.info()["status"] == 0
+        wire.close()
+        halo2.check()
+    oa.device_synchronize()

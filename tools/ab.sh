@@ -49,7 +49,7 @@ one() { # spec
    if [ $KS = 1 ]; then
       local d=gpurun_out/${TAG}_ks_$(echo "$name" | tr -c 'A-Za-z0-9_' _)
       OMEGA_AMD_LIB=$libpath OMEGA_AMD_OPTIONS=$opt rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- \
-         python3 bench.py --workload $W --steps 8 --warmup 2 --rk4-steps 0 --no-cpu-baseline --realistic none $COMMON $args > $d.log 2>&1
+         python3 bench.py --workload $W --steps 8 --warmup 2 --rk4-steps 0 --no-cpu-baseline --no-live-traffic --realistic none $COMMON $args > $d.log 2>&1
       AB_NAME="$name" AB_DIR="$d" python3 - <<'PY' | tee -a $OUT
 import csv, glob, json, os
 f = glob.glob(os.environ["AB_DIR"] + "/**/*kernel_stats.csv", recursive=True)[0]
@@ -57,7 +57,7 @@ rows = {r["Name"].replace("OMEGA::", "")[:160]: (int(r["Calls"]), float(r["Avera
 print(json.dumps({"variant": os.environ["AB_NAME"], "kernel_avg_ms": {k: round(v[1], 4) for k, v in rows.items()}, "calls": {k: v[0] for k, v in rows.items()}}))
 PY
    else
-      OMEGA_AMD_LIB=$libpath OMEGA_AMD_OPTIONS=$opt python3 bench.py --workload $W --no-cpu-baseline --realistic none $RHS $COMMON $args 2>/dev/null |
+      OMEGA_AMD_LIB=$libpath OMEGA_AMD_OPTIONS=$opt python3 bench.py --workload $W --no-cpu-baseline --no-live-traffic --realistic none $RHS $COMMON $args 2>/dev/null |
          AB_NAME="$name" python3 -c "
 import json, os, sys
 d = json.loads(sys.stdin.read())

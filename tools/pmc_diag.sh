@@ -7,7 +7,7 @@ TAG=${1:?tag}; shift || true
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
-ARGS="--steps 4 --warmup 1 --rk4-steps 0 --no-cpu-baseline $*"
+ARGS="--steps 4 --warmup 1 --rk4-steps 0 --no-cpu-baseline --no-live-traffic --realistic none $*"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_sq -o s -- python3 bench.py $ARGS > $OUT/${TAG}_sq.log 2>&1
 echo "[diag] SQ pass done"
 # (TCP / TA counters are collected by tools/pmc_diag2.sh, two counters of one block per pass: asking for more than the

@@ -8,7 +8,7 @@ TAG=${1:?tag}; shift || true
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
-ARGS="--steps 4 --warmup 1 --rk4-steps 0 --no-cpu-baseline $*"
+ARGS="--steps 4 --warmup 1 --rk4-steps 0 --no-cpu-baseline --no-live-traffic --realistic none $*"
 pass() { # name counters...
    n=$1; shift
    timeout -k 10 100 rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$n -o p -- python3 bench.py $ARGS > $OUT/${TAG}_$n.log 2>&1

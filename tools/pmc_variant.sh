@@ -3,7 +3,7 @@ set -e -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 export OMEGA_AMD_LIB=$PWD/omega_amd/lib/libomega_amd_x.so
-ARGS="--steps 8 --warmup 2 --rk4-steps 0 --no-cpu-baseline --workload qu30"
+ARGS="--steps 8 --warmup 2 --rk4-steps 0 --no-cpu-baseline --no-live-traffic --realistic none --workload qu30"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r04ac_fetch -o f -- python3 bench.py $ARGS > gpurun_out/r04ac_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/r04ac_write -o w -- python3 bench.py $ARGS > gpurun_out/r04ac_write.log 2>&1
 python3 - <<'PY'

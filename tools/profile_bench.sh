@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
 # (the profiled runs measure the named workload only: no realistic block, whose kernels would enter the per-kernel averages)
-ARGS="--steps 8 --warmup 2 --rk4-steps 2 --no-cpu-baseline --realistic none $*"
+ARGS="--steps 8 --warmup 2 --rk4-steps 2 --no-cpu-baseline --no-live-traffic --realistic none $*"
 python3 bench.py --steps 20 --warmup 3 $* > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "[profile] bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1

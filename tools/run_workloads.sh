@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 for w in $WL; do
    extra=""
    case "$w" in orrs18to6_eighth|fib7|fib7_coast) extra="--rk4-steps 0";; esac
-   timeout -k 10 900 python3 bench.py --workload $w --no-cpu-baseline $extra > gpurun_out/${TAG}_wl_$w.json 2> gpurun_out/${TAG}_wl_$w.err
+   timeout -k 10 900 python3 bench.py --workload $w --no-cpu-baseline --no-live-traffic --realistic none $extra > gpurun_out/${TAG}_wl_$w.json 2> gpurun_out/${TAG}_wl_$w.err
    python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_wl_$w.json").read())
