@@ -70,11 +70,15 @@ def test_one_real_rank_of_the_eight_on_the_gpu(big):
     tend = oa.Tendencies(mesh, K, NT, oa.default_config())
     state.copy_to_device(h, u, 0)
 
+    # the rank's 37 tracers synthesised ONCE on the host (11 GB, in the device's row pitch; bench.py, which has no reason to
+    # upload them six times, builds and uploads one tracer at a time)
+    tr_host = np.zeros((NT, mesh.NCellsSize, kp))
+    for l in range(NT):
+        tr_host[l, : mesh.NCellsAll, :K] = synthetic_state_rows(g, K, NT, cells0, edges0[:0], tracers=[l])[2][0]
+
     def upload(scale=1.0):
-        for l in range(NT):   # one tracer at a time: 37 of them are 11 GB
-            t2 = synthetic_state_rows(g, K, NT, cells0, edges0[:0], tracers=[l])[2][0]
-            buf = np.zeros((mesh.NCellsSize, kp)); buf[: t2.shape[0], :K] = t2 * scale
-            oa.copy_to_device(tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp, buf)
+        for l in range(NT):
+            oa.copy_to_device(tracers.device_ptr(0) + 8 * l * mesh.NCellsSize * kp, tr_host[l] if scale == 1.0 else tr_host[l] * scale)
     upload()
     nc, ne = mesh.NCellsOwned, mesh.NEdgesOwned
     tend.compute_all_tendencies(state, aux, tracers)
