@@ -871,13 +871,26 @@ def main():
                 realistic = {"workload": wl, "error": f"{type(exc).__name__}: {exc}"}
     emit(sypd, t_rk4, rk4_error, overlap_check, cpu)
     if N > 1:
+        # Ordered teardown, with a bound: the record is out; a rank must not hang in the destructors of RCCL / gloo / HIP
+        # racing its peers' exits (that would keep the launcher -- and whoever timed it -- waiting).  Explicit closes while
+        # every peer is still there, then the process leaves without interpreter finalisation; if a close itself does not
+        # come back within a minute, the timer ends the process with the same code.
+        import threading
+        code = 3 if rk4_error else 0   # (3: the RHS record above stands; the stepping part failed and says so in rk4.error)
+        bound = threading.Timer(60.0, lambda: os._exit(code))
+        bound.daemon = True
+        bound.start()
         oa.device_synchronize()
         dist.barrier()      # every rank's GPU work is complete: the wires may be taken down
         if wire is not None:
             wire.close()
+        if comm is not None:
+            comm.close()
+        dist.barrier()
         dist.destroy_process_group()
-    if N > 1 and rk4_error:
-        sys.exit(3)   # the RHS record above stands; the stepping part failed and says so in rk4.error
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
 
 
 def live_traffic(args):

@@ -490,9 +490,16 @@ class RcclComm:
                                      (C.c_size_t * n)(*send_bytes), (C.c_void_p * n)(*recv_ptrs),
                                      (C.c_size_t * n)(*recv_bytes), _sh(stream)))
 
+    def close(self):
+        """omg_rccl_destroy (ncclCommDestroy): explicitly, while the peers are still there -- not left to a destructor at
+        interpreter exit"""
+        if self.h:
+            lib().omg_rccl_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            lib().omg_rccl_destroy(self.h)
+            self.close()
         except Exception:
             pass
 
