@@ -125,6 +125,7 @@ class Decomp : public Registry<Decomp> {
    void buildSlotMasks();
    /// k-d order of List[Begin, End) in place (LocalOrder::KdTree)
    void kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const;
+   void kdOrderRange(std::vector<I4> &List, size_t Begin, size_t End) const;
    /// what is applied to every group (owned cells of a task, a halo layer) after the sequence order
    void orderGroup(std::vector<I4> &List, size_t Begin, size_t End) const {
       if (Order == LocalOrder::KdTree)

@@ -40,6 +40,7 @@ const OptionName OptionTable[] = {
     {"ShrinkSweeps", &TuningOptions::ShrinkSweeps},
     {"ProbeSlice", &TuningOptions::ProbeSlice},
     {"ProbeBlocks", &TuningOptions::ProbeBlocks},
+    {"ValenceSort", &TuningOptions::ValenceSort},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"DomValence", &TuningOptions::DomValence},

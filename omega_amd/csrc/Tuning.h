@@ -44,6 +44,8 @@ struct TuningOptions {
    int ProbeBlocks = 1; ///< blocks of tiles per level chunk under ProbeSlice
    // ---- HIP-graph replay: -1 = as each object's UseGraphs says, 0 = never, 1 = default on
    int Graphs = -1;
+   // ---- (appended last: the layout above is what already-built kernel objects index)
+   int ValenceSort = 0; ///< 1: k-d local order with the cells of each group's dominant valence first (k-d ordered among themselves), the others after them -- the sweeps' tiles then hold no cell the sweep skips (Decomp.cpp: kdOrder).  Measured: +-0.3 % on the Fibonacci and icosahedral spheres (profiles/r05_ab_valence_sort_*.jsonl): off
 };
 
 TuningOptions &tuning();
