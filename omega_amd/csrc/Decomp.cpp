@@ -178,7 +178,7 @@ void Decomp::clusterWaves(std::vector<I4> &List, size_t Begin, size_t End) const
 void Decomp::kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const {
    OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: k-d ordering needs cell coordinates");
    // Valence sort (option ValenceSort, default OFF: measured +-0.3 % on the spheres, profiles/r05_ab_valence_sort_*.jsonl): the cell sweeps of the kernels are instantiated for the valence most
-   // cells have and skip the others, which run as list launches (FusedKernels.hip: launchFusedT) -- a pentagon or heptagon
+   // cells have and skip the others, which run as list launches (FusedKernelsImpl.h: launchFusedT) -- a pentagon or heptagon
    // inside a tile of hexagons is a row of idle lanes for the tile's whole life.  So inside every group the cells of the
    // group's dominant valence come first, k-d ordered among themselves, and the rest after them (k-d ordered too):
    // tiles of the first part are full, the list cells' own rows are contiguous.  A function of the group's contents

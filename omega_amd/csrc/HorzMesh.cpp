@@ -543,7 +543,7 @@ void HorzMesh::publishBadCells() {
 void HorzMesh::buildPatchTables() {
    MeshView &W         = View;
    const int Tiles[3]  = {8, 16, 32};
-   const int NPs[3]    = {24, 48, 96}; // what the kernel's LDS budget holds (FusedKernels.hip: CellPVFinalTracerPatchBody)
+   const int NPs[3]    = {24, 48, 96}; // what the kernel's LDS budget holds (FusedKernelsImpl.h: CellPVFinalTracerPatchBody)
    const int ME        = MaxEdges;
    std::vector<I4> Pos(NCellsSize, -1);
    for (int S = 0; S < MeshView::NPatchSizes; ++S) {

@@ -1,0 +1,8 @@
+// FusedInst5.hip -- explicit instantiations of launchFusedT (FusedKernelsImpl.h): one of the translation units the fused RHS
+// is compiled in.
+#include "FusedKernelsImpl.h"
+
+namespace OMEGA {
+OMEGA_FUSED_INSTANCES_5(OMEGA_FUSED_DEFINE)
+OMEGA_FUSED_INSTANCES_5N(OMEGA_FUSED_DEFINE)
+} // namespace OMEGA

@@ -40,7 +40,7 @@ def test_eight_way_partition_decomp_and_halo_of_the_full_mesh_on_the_host(big):
         mailbox = rows * K * 8
         assert 0 < mailbox < 1 << 30, mailbox                                        # ~ 280 MB per rank: one hipMalloc, one IPC handle
         # 32-bit job table of the pack / unpack kernels (Halo.cpp: plane = tracer * RowsSize + row) and the fused RHS's
-        # 32-bit byte offsets inside one array plane (FusedKernels.hip: BufOOB)
+        # 32-bit byte offsets inside one array plane (FusedKernelsImpl.h: BufOOB)
         assert NT * (d.get_int("NCellsAll") + 1) < 1 << 31
         assert (d.get_int("NEdgesAll") + 1) * K * 8 < 0xffffff00
         assert d.get_int("NCellsAll") < 1.05 * d.get_int("NCellsOwned")             # HaloWidth 4: ~ 2.3 % more cells
