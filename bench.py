@@ -907,6 +907,8 @@ def live_traffic(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler (its environment would reach the child runs)"
     from tools.summarise_profile import counters
     child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1", "--rk4-steps", "0",
              "--no-cpu-baseline", "--no-live-traffic", "--realistic", "none", "--settle-ms", "0", "--local-order", args.local_order,
