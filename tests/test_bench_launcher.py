@@ -44,3 +44,27 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "small"], cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE = 2" in r.stderr.decode()
+
+
+def test_tool_scripts_parse():
+    """tools/*.sh are only ever run on the GPU box: at least their syntax is checked here."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))):
+        r = subprocess.run(["bash", "-n", f], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, (f, r.stderr.decode())
+
+
+def test_live_traffic_degrades_to_a_reason(monkeypatch):
+    """bench.live_traffic (roofline.traffic measured inside the run through two rocprofv3 --pmc child runs) must never
+    take the measurement down with it: under a profiler it declines, and where the child runs cannot succeed (no GPU
+    here) it returns the reason instead of raising."""
+    import bench
+    args = bench.parse_args(["--workload", "small"])
+    monkeypatch.setenv("ROCPROFILER_TEST_MARK", "1")
+    out, why = bench.live_traffic(args)
+    assert out is None and "profiler" in why
+    monkeypatch.delenv("ROCPROFILER_TEST_MARK")
+    import omega_amd as oa
+    if oa.device_count() == 0:
+        out, why = bench.live_traffic(args)
+        assert out is None and isinstance(why, str) and why
