@@ -55,6 +55,11 @@ def main():
     ap.add_argument("--peer-timeout-test", action="store_true",
                     help="--wire ipc: rank 0 exchanges while the others never do: its wait kernel must give up after the "
                          "wire's time limit, raise the sticky status and make the next exchange fail loudly -- no hang")
+    ap.add_argument("--against-partitioned", action="store_true",
+                    help="gpu mode: the comparison is with the PARTITIONED oracle of the same world size and halo width "
+                         "(this rank's oracle on this rank's local mesh, its exchanges over gloo at the reference's two "
+                         "exchange points, RungeKutta4Stepper.cpp:107-113,127-131) -- what Omega itself prints at N ranks, "
+                         "partition-dependent bits included -- on EVERY local element, owned and halo, bit for bit")
     ap.add_argument("--mesh", default="hex", help="hex (planar nx x ny) | any name of tests/meshes.py: icoN, fibN, "
                                                   "hexNXxNY, <base>_coast_<kind>[_raw][_compact], <base>_pad8")
     a = ap.parse_args()
@@ -238,6 +243,19 @@ def main():
     for _ in range(a.steps):
         og.step(okind, stg, dt)
 
+    def partitioned_oracle_run():
+        stl = P.oracle.make_state(P.h, P.u, P.tr)
+
+        def ex(hh, uu, tt):
+            host_exchange(hh, 0)
+            host_exchange(uu, 1)
+            host_exchange(tt, 0)
+        for _ in range(a.steps):
+            P.oracle.step(okind, stl, dt, exchange=ex)
+        return stl["h"][0], stl["u"][0], stl["tr"][0]
+
+    if gpu and a.against_partitioned:
+        ph, pu, ptr = partitioned_oracle_run()     # before the GPU run: the gloo group is idle, nothing else uses it yet
     if gpu:
         st = oa.TimeStepper(a.stepper, dt, P.tend, P.aux, P.mesh, halo, P.tracers)
         if a.stepper == "RungeKutta4":
@@ -261,15 +279,32 @@ def main():
         h, u = P.state.copy_to_host(0)
         tr = P.tracers.copy_to_host(0)
     else:
-        stl = P.oracle.make_state(P.h, P.u, P.tr)
+        h, u, tr = partitioned_oracle_run()
 
-        def ex(hh, uu, tt):
-            host_exchange(hh, 0)
-            host_exchange(uu, 1)
-            host_exchange(tt, 0)
-        for _ in range(a.steps):
-            P.oracle.step(okind, stl, dt, exchange=ex)
-        h, u, tr = stl["h"][0], stl["u"][0], stl["tr"][0]
+    if gpu and a.against_partitioned:
+        # the reference's own N-rank result (its default HaloWidth 3 with del4 on is not partition independent,
+        # RungeKutta4Stepper.cpp:107: what has to be reproduced is the N-rank run, not the 1-rank one)
+        na, nea = m.NCellsAll, m.NEdgesAll
+        bad = []
+        for name, got, want in (("h", h[:na], ph[:na]), ("u", u[:nea], pu[:nea]), ("tracers", tr[:NT, :na], ptr[:NT, :na])):
+            if not np.array_equal(got, want):
+                w = np.argwhere(got != want)
+                bad.append(f"{name}: {len(w)} values differ, first at {w[0].tolist()} (owned cells {m.NCellsOwned}, edges "
+                           f"{m.NEdgesOwned}), max |diff| {np.abs(got - want).max():.3e}")
+        assert not bad, f"rank {a.rank}: GPU run differs from the partitioned oracle: " + "; ".join(bad)
+        nc, ne = m.NCellsOwned, m.NEdgesOwned
+        gh, gu = stg["h"][0][P.cell_id[:nc] - 1], stg["u"][0][P.edge_id[:ne] - 1]
+        dev = max(np.abs(h[:nc] - gh).max() / np.abs(gh).max(), np.abs(u[:ne] - gu).max() / np.abs(gu).max())
+        devs = [None] * a.world
+        dist.all_gather_object(devs, float(dev))
+        dist.barrier()
+        if wire is not None:
+            halo.check()
+            wire.close()
+        dist.destroy_process_group()
+        print(f"rank {a.rank}/{a.world} OK ({a.mode}, {a.stepper}, {len(nbrs)} neighbours, equal to the partitioned oracle "
+              f"on all {na} cells / {nea} edges; deviation from the 1-rank run {max(devs):.3e})")
+        return
 
     nc, ne = m.NCellsOwned, m.NEdgesOwned
     gh = stg["h"][0][P.cell_id[:nc] - 1]

@@ -102,6 +102,37 @@ def test_halo_width_3_with_del4_bound_on_the_gpu():
     assert all("OK" in o and "max deviation" in o for o in outs)
 
 
+HALO3 = ["--halo-width", 3, "--against-partitioned", "--eddy-diff4", 1.0e11]
+
+
+@pytest.mark.parametrize("options", ["", "SendBand=0,BandOnComm=0,ShrinkSweeps=0"])
+@pytest.mark.parametrize("world,extra", [
+    (2, [*HALO3, "--nx", 24, "--ny", 24, "--tracers", 2]),                                  # overlapped, host-staged wire
+    (2, [*HALO3, "--nx", 24, "--ny", 24, "--tracers", 2, "--no-overlap"]),                  # sequential
+    (2, [*HALO3, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6, "--wire", "ipc"]),  # band AND interior launches
+    (4, [*HALO3, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 3, "--wire", "ipc"]),
+    (4, [*HALO3, "--nx", 48, "--ny", 48, "--levels", 3, "--tracers", 3, "--wire", "ipc", "--no-overlap"]),
+    (4, [*HALO3, "--mesh", "ico4", "--levels", 3, "--tracers", 2, "--partition", "graph", "--local-order", "kd", "--wire", "ipc"]),
+    (2, [*HALO3, "--mesh", "hex48x24_coast_mixed", "--levels", 6, "--partition", "graph", "--local-order", "kd"]),
+])
+def test_reference_default_halo_width_3_reproduces_the_partitioned_reference_run(world, extra, options, monkeypatch):
+    """The reference's own N > 1 configuration (Default.yml:15 HaloWidth 3, del4 on, RK4 exchanging after every second
+    evaluation, RungeKutta4Stepper.cpp:107-113): its result depends on the partition -- the second evaluation after an
+    exchange reads halo rows the first one computed from incomplete stencils.  What the product has to print there is
+    what Omega prints at the same N: the PARTITIONED oracle (each rank's oracle on its local mesh, sweeping NCellsAll /
+    NEdgesAll / NVerticesAll like Tendencies.cpp:281-564 and TimeStepper.cpp:395-520, exchanging at the reference's two
+    points) -- every local element, owned and halo, bit for bit, in overlapped and sequential mode, with the stage
+    shortcuts (SendBand / ShrinkSweeps) on and off."""
+    if options:
+        monkeypatch.setenv("OMEGA_AMD_OPTIONS", options)
+    outs = run_ranks("gpu", world, extra, timeout=900)
+    assert all("OK" in o and "equal to the partitioned oracle" in o for o in outs)
+    # ... and those bits ARE partition dependent here (otherwise the case would show nothing the HaloWidth 4 cases do not)
+    import re
+    dev = [float(re.search(r"deviation from the 1-rank run ([0-9.eE+-]+)", o).group(1)) for o in outs]
+    assert 0.0 < max(dev) < 1.0e-5, dev
+
+
 @pytest.mark.parametrize("world,extra", [
     (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6]),                 # overlapped
     (2, ["--halo-width", 4, "--nx", 64, "--ny", 24, "--levels", 4, "--tracers", 6, "--no-overlap"]),
