@@ -288,9 +288,11 @@ def launch_ranks(args, argv):
     th.join(timeout=10.0)
     codes = [p.returncode for p in procs]
     if killed:
-        print(f"[bench launcher] ended rank(s) {killed}: exit codes {codes}", file=sys.stderr, flush=True)
+        print(f"[bench launcher] ended rank(s) {killed}: exit codes {codes} (rendezvous 127.0.0.1:{port})", file=sys.stderr, flush=True)
     elif any(codes):
-        print(f"[bench launcher] rank exit codes {codes}", file=sys.stderr, flush=True)
+        # (the port was free when probed a moment before the ranks started; a rendezvous failure right at the start of
+        # rank 0's log means another process took it in between: run again)
+        print(f"[bench launcher] rank exit codes {codes} (rendezvous 127.0.0.1:{port})", file=sys.stderr, flush=True)
     if not lines:
         print("[bench launcher] rank 0 printed no record", file=sys.stderr, flush=True)
         return 5
@@ -912,7 +914,10 @@ def live_traffic(args):
     from tools.summarise_profile import counters
     child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1", "--rk4-steps", "0",
              "--no-cpu-baseline", "--no-live-traffic", "--realistic", "none", "--settle-ms", "0", "--local-order", args.local_order,
-             "--block", str(args.block), "--max-edges", str(args.max_edges)] + (["--unfused"] if args.unfused else [])
+             "--block", str(args.block), "--max-edges", str(args.max_edges), "--halo-width", str(args.halo_width)] + (["--unfused"] if args.unfused else [])
+    # (forwarded: every argument that changes the mesh, its numbering or the kernels -- workload, local order, input
+    # order, table width, halo width, fused / unfused; not forwarded: step counts, dt and the stepping part, which the
+    # child runs do not have)
     work = tempfile.mkdtemp(prefix="omega_bench_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     got = {}
@@ -922,7 +927,7 @@ def live_traffic(args):
             d = os.path.join(work, ctr)
             with open(os.path.join(work, ctr + ".log"), "wb") as log:
                 r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", *child], env=env, cwd=ROOT,
-                                   stdout=log, stderr=subprocess.STDOUT, timeout=240)
+                                   stdout=log, stderr=subprocess.STDOUT, timeout=120)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} child run ended with code {r.returncode}"
             rows = counters(d)
@@ -930,7 +935,7 @@ def live_traffic(args):
                 if v.get(ctr):
                     got.setdefault(k, {})[ctr] = (sum(v[ctr]) / len(v[ctr]), len(v[ctr]))
     except subprocess.TimeoutExpired:
-        return None, "a rocprofv3 --pmc child run did not finish within 240 s"
+        return None, "a rocprofv3 --pmc child run did not finish within 120 s (a pass takes ~ 10 s)"
     except Exception as exc:  # noqa: BLE001  (the measurement proper must not depend on the profiler)
         return None, f"{type(exc).__name__}: {exc}"
     finally:

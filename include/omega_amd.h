@@ -262,14 +262,13 @@ int omg_halo_exchange_state(omg_halo *h, omg_state *state, int state_time_level,
  * kernel of that exchange then copied nothing, the halo is stale.  The time steppers ask at the start of every step. */
 int omg_halo_check(const omg_halo *h);
 
-/* ---- Measurement / test options (omega_amd/csrc/Tuning.h).  The library never reads the environment: every switch that
- *      changes the kernel structure or the tile geometry is set through this call.  Defaults are what production
- *      runs.  Names: W TX TY Sweeps ChunkSplit TailSplit (tile geometry); EdgeMode FuseFinal MergeL1 Pair FuseL3
- *      FoldLists InlineOther TracerPatch Alternate (structure of the fused RHS; read at every launch); SendBand BandOnComm
- *      ShrinkSweeps (what a rank leaves out inside an RK4 step; read at every stage); ForceGeneric KeepMaxEdges
- *      DomValence NarrowTables (mesh tables; read when a HorzMesh is created); WaveWindow (local numbering; read when a
- *      Decomp with a curve order is created); Graphs (-1 per object, 0 never, 1 default
- *      on).  Unknown names fail.
+/* ---- Test options (omega_amd/csrc/Tuning.h).  The library never reads the environment.  Defaults are what production
+ *      runs; every option forces a kernel / table structure that some mesh class reaches by itself (named in Tuning.h), so
+ *      that tests can drive generated meshes through it -- no option can make a result wrong, and there is no measurement
+ *      probe in the library.  Names: MergeL1 Pair TracerPatch (structure of the fused RHS; read at every launch); SendBand
+ *      BandOnComm ShrinkSweeps (what a rank leaves out inside an RK4 step; read at every stage); ForceGeneric KeepMaxEdges
+ *      NarrowTables (mesh tables; read when a HorzMesh is created); ValenceSort (local numbering; read when a Decomp with
+ *      the k-d order is created); Graphs (-1 per object, 0 never, 1 default on).  Unknown names fail.
  *      omg_set_timing_level: roctx ranges named after the reference's Pacer timers ("Tend:...", "AuxState:...",
  *      "RK4:haloExch"; share/pacer/Pacer.cpp:138-200) are emitted for timers up to this level (default 3 = all). ---- */
 int omg_set_option(const char *name, int value);
@@ -352,7 +351,17 @@ int omg_aux_copy_to_device(omg_aux *a, const char *name, const double *host, siz
 int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t *n);
 
 /* ---- Tendencies (O/src/ocn/Tendencies.h:73-102; Tendencies.cpp:257-600) ---- */
+/* omg_tend_create FAILS (message: omg_last_error, naming the limit) for a mesh outside the fused RHS: an array plane of
+ * 4 GiB or more (32-bit buffer offsets: ~ 2.2 M cells x 80 levels per rank -- several ranks may share a GPU) or MaxEdges
+ * outside 5..8.  omg_tend_create_reference_structured accepts such a mesh: computeAllTendencies then takes the
+ * reference-structured 23-launch path (~ 5 x the time) -- the caller's decision, not a surprise.
+ * omg_tend_fused_limit asks beforehand, on sizes alone (rows incl. the sentinel; no mesh, no device): *supported = 1, or 0
+ * with the reason in `why`. */
 int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out);
+int omg_tend_create_reference_structured(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c,
+                                         omg_tend **out);
+int omg_tend_fused_limit(int64_t ncells_size, int64_t nedges_size, int64_t nvertices_size, int max_edges, int nvertlayers,
+                         int *supported, char *why, size_t why_bytes);
 int omg_tend_destroy(omg_tend *t);
 int omg_tend_set_fused(omg_tend *t, int use_fused_rhs);
 /* HIP-graph replay of launch-bound sequences (default off: measured without gain on MI355X; OMEGA_GRAPHS=1 or these

@@ -876,12 +876,25 @@ class AuxiliaryState:
             pass
 
 
+def fused_limit(ncells_size: int, nedges_size: int, nvertices_size: int, max_edges: int, nvertlayers: int):
+    """omg_tend_fused_limit: (True, "") if the fused RHS covers arrays of these row counts (sentinel row included), else
+    (False, reason).  Sizes only: needs neither a mesh nor a device."""
+    ok, why = C.c_int(), C.create_string_buffer(1024)
+    _chk(lib().omg_tend_fused_limit(C.c_int64(ncells_size), C.c_int64(nedges_size), C.c_int64(nvertices_size), int(max_edges),
+                                    int(nvertlayers), C.byref(ok), why, C.c_size_t(1024)))
+    return bool(ok.value), why.value.decode()
+
+
 class Tendencies:
-    def __init__(self, mesh: HorzMesh, nvertlayers: int, ntracers: int, config: TendConfig | None = None):
+    def __init__(self, mesh: HorzMesh, nvertlayers: int, ntracers: int, config: TendConfig | None = None,
+                 allow_reference_structured: bool = False):
+        """Raises for a mesh outside the fused RHS (fused_limit) unless allow_reference_structured: then
+        compute_all_tendencies takes the reference-structured 23-launch path."""
         self.mesh, self.K, self.NT = mesh, nvertlayers, ntracers
         self.config = config if config is not None else default_config()
         h = C.c_void_p()
-        _chk(lib().omg_tend_create(mesh.h, nvertlayers, ntracers, C.byref(self.config), C.byref(h)))
+        create = lib().omg_tend_create_reference_structured if allow_reference_structured else lib().omg_tend_create
+        _chk(create(mesh.h, nvertlayers, ntracers, C.byref(self.config), C.byref(h)))
         self.h = h
 
     def set_fused(self, on: bool):

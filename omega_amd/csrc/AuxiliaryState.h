@@ -56,6 +56,15 @@ class AuxiliaryState : public Registry<AuxiliaryState> {
                    hipStream_t S) const;
    /// exchange of the non-computed aux variables (AuxiliaryState.cpp:312-323)
    I4 exchangeHalo(hipStream_t S);
+   // ---- the reference's signatures (AuxiliaryState.h:74-85): on this object's `Stream` (default: the null stream)
+   hipStream_t Stream = nullptr;
+   void computeMomAux(const OceanState *State, int ThickTimeLevel, int VelTimeLevel) const {
+      computeMomAux(State, ThickTimeLevel, VelTimeLevel, Stream);
+   }
+   void computeAll(const OceanState *State, const Array3DReal &TracerArray, int ThickTimeLevel, int VelTimeLevel) const {
+      computeAll(State, TracerArray, ThickTimeLevel, VelTimeLevel, Stream);
+   }
+   I4 exchangeHalo() { return exchangeHalo(Stream); }
 
    AuxPtrs ptrs() const;
    const HorzMesh *Mesh;

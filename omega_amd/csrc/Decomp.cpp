@@ -101,77 +101,6 @@ void Decomp::buildCellOrder() {
       CellRank[CellSeq[I]] = I;
 }
 
-void Decomp::buildSlotMasks() {
-   SlotMask.assign(NCellsGlobal, 0);
-   NSlots.assign(NCellsGlobal, 0);
-   for (I4 C = 0; C < NCellsGlobal; ++C) {
-      int N = 0;
-      unsigned M = 0;
-      for (int J = 0; J < MaxEdges && N < 8; ++J) {
-         const I4 E = G.EdgesOnCell[(size_t)C * MaxEdges + J];
-         if (E < 0 || E >= NEdgesGlobal)
-            continue; // (slots are compacted to the active edges: buildLocalConnectivity)
-         if (G.CellsOnEdge[2 * (size_t)E + 1] == C)
-            M |= 1u << N;
-         ++N;
-      }
-      SlotMask[C] = (unsigned char)M;
-      NSlots[C]   = (unsigned char)N;
-   }
-}
-
-// Greedy regrouping inside windows: a wave (8 consecutive local cells, aligned to multiples of 8 of the local index) is
-// seeded with the first cell of the window not yet placed and filled with the cells that add the fewest new "second
-// cell" slots and the fewest new "first cell" slots to the wave's unions (ties: curve order).  Deterministic: every
-// rank derives every rank's numbering.
-void Decomp::clusterWaves(std::vector<I4> &List, size_t Begin, size_t End) const {
-   if (WaveWindow < 16 || End - Begin < 16)
-      return;
-   static const auto Pop = [] {
-      std::array<unsigned char, 256> P{};
-      for (int I = 0; I < 256; ++I)
-         P[I] = (unsigned char)__builtin_popcount(I);
-      return P;
-   }();
-   const size_t W = (size_t)WaveWindow;
-   std::vector<I4> Rem, Out;
-   for (size_t W0 = Begin; W0 < End;) {
-      // windows end on multiples of WaveWindow of the local index, waves on multiples of 8
-      size_t W1 = (W0 / W + 1) * W;
-      if (W1 > End)
-         W1 = End;
-      Rem.assign(List.begin() + W0, List.begin() + W1);
-      Out.clear();
-      size_t Pos = W0;
-      while (!Rem.empty()) {
-         const size_t GroupEnd = std::min(W1, (Pos / 8 + 1) * 8);
-         const I4 Seed         = Rem.front();
-         Rem.erase(Rem.begin());
-         Out.push_back(Seed);
-         ++Pos;
-         unsigned U2 = SlotMask[Seed], U1 = (~SlotMask[Seed]) & ((1u << NSlots[Seed]) - 1);
-         while (Pos < GroupEnd && !Rem.empty()) {
-            size_t Best = 0;
-            int BestCost = 1 << 30;
-            for (size_t J = 0; J < Rem.size(); ++J) {
-               const I4 C2      = Rem[J];
-               const unsigned A = U2 | SlotMask[C2], B = U1 | ((~SlotMask[C2]) & ((1u << NSlots[C2]) - 1));
-               const int Cost   = Pop[A & 255] + Pop[B & 255];
-               if (Cost < BestCost)
-                  BestCost = Cost, Best = J;
-            }
-            const I4 C2 = Rem[Best];
-            Rem.erase(Rem.begin() + Best);
-            Out.push_back(C2);
-            U2 |= SlotMask[C2], U1 |= (~SlotMask[C2]) & ((1u << NSlots[C2]) - 1);
-            ++Pos;
-         }
-      }
-      std::copy(Out.begin(), Out.end(), List.begin() + W0);
-      W0 = W1;
-   }
-}
-
 // Recursive median bisection along the widest axis (see LocalOrder::KdTree).  Splits of more than 32 cells fall on a
 // multiple of 32 nearest to the middle, 32 -> 16 + 16, 16 -> 8 + 8: aligned runs of 8, 16 and 32 cells are subtrees.
 // Deterministic (ties by global id): every rank derives every rank's numbering.
@@ -496,10 +425,6 @@ Decomp::Decomp(const GlobalMeshDesc &Mesh, I4 NParts, I4 MyTask_, I4 HaloWidth_,
       partitionRCB();
    }
    buildCellOrder();
-   if (Order != LocalOrder::GlobalID && tuning().WaveWindow >= 16) {
-      WaveWindow = tuning().WaveWindow / 8 * 8;
-      buildSlotMasks();
-   }
    computeOwnership();
 
    LocalSets S    = computeLocalSets(MyTask);

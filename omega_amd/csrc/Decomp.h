@@ -111,18 +111,7 @@ class Decomp : public Registry<Decomp> {
    GlobalMeshDesc G;
    std::vector<I4> CellSeq;  ///< cells in the order that numbers them (identity, or along the curve)
    std::vector<I4> CellRank; ///< position of each cell in CellSeq
-   /// Wave clustering (curve orders only; option WaveWindow, Tuning.h).  The cell kernels give one wavefront 8
-   /// consecutive local cells, and the cell-centric PV code finishes an edge in the thread of its second cell
-   /// (CellsOnEdge(e,1)): per edge slot a block only the lanes of "second cells" execute.  On a structured mesh every cell
-   /// has the same slots; on an unstructured one the orientation of CellsOnEdge is arbitrary and a wave of 8 curve
-   /// neighbours executes almost all 6 blocks instead of 3, each a dependent memory round trip.  Inside windows of
-   /// WaveWindow consecutive cells of a group the cells are therefore regrouped so that the 8 cells of a wave have
-   /// similar slot patterns.  Per global id nothing changes; only the local numbering does.
-   std::vector<unsigned char> SlotMask; ///< per global cell: bit j = the cell is CellsOnEdge(e,1) of its j-th active edge
-   std::vector<unsigned char> NSlots;   ///< per global cell: number of active edges
-   int WaveWindow = 0;
    std::vector<std::vector<I4>> OwnedSeq; ///< per task: its owned cells in numbering order
-   void buildSlotMasks();
    /// k-d order of List[Begin, End) in place (LocalOrder::KdTree)
    void kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const;
    void kdOrderRange(std::vector<I4> &List, size_t Begin, size_t End) const;
@@ -130,10 +119,7 @@ class Decomp : public Registry<Decomp> {
    void orderGroup(std::vector<I4> &List, size_t Begin, size_t End) const {
       if (Order == LocalOrder::KdTree)
          kdOrder(List, Begin, End);
-      clusterWaves(List, Begin, End);
    }
-   /// regroup List[Begin, End) -- local indices Begin.. -- in place
-   void clusterWaves(std::vector<I4> &List, size_t Begin, size_t End) const;
    void buildCellOrder();
    void partitionRCB();
    void computeOwnership();

@@ -20,32 +20,16 @@ struct OptionName {
    int TuningOptions::*Field;
 };
 const OptionName OptionTable[] = {
-    {"W", &TuningOptions::W},
-    {"TX", &TuningOptions::TX},
-    {"TY", &TuningOptions::TY},
-    {"Sweeps", &TuningOptions::Sweeps},
-    {"ChunkSplit", &TuningOptions::ChunkSplit},
-    {"TailSplit", &TuningOptions::TailSplit},
-    {"EdgeMode", &TuningOptions::EdgeMode},
-    {"FuseFinal", &TuningOptions::FuseFinal},
     {"MergeL1", &TuningOptions::MergeL1},
     {"Pair", &TuningOptions::Pair},
-    {"FuseL3", &TuningOptions::FuseL3},
-    {"FoldLists", &TuningOptions::FoldLists},
     {"TracerPatch", &TuningOptions::TracerPatch},
-    {"InlineOther", &TuningOptions::InlineOther},
-    {"Alternate", &TuningOptions::Alternate},
     {"SendBand", &TuningOptions::SendBand},
     {"BandOnComm", &TuningOptions::BandOnComm},
     {"ShrinkSweeps", &TuningOptions::ShrinkSweeps},
-    {"ProbeSlice", &TuningOptions::ProbeSlice},
-    {"ProbeBlocks", &TuningOptions::ProbeBlocks},
-    {"ValenceSort", &TuningOptions::ValenceSort},
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
-    {"DomValence", &TuningOptions::DomValence},
     {"NarrowTables", &TuningOptions::NarrowTables},
-    {"WaveWindow", &TuningOptions::WaveWindow},
+    {"ValenceSort", &TuningOptions::ValenceSort},
     {"Graphs", &TuningOptions::Graphs},
 };
 } // namespace
@@ -54,7 +38,7 @@ TuningOptions &tuning() {
    static TuningOptions T = [] {
       TuningOptions X;
 #ifdef OMEGA_TUNING_ENV
-      // measurement builds only: OMEGA_TX, OMEGA_MERGEL1, ... (upper-cased option names)
+      // measurement builds only: OMEGA_MERGEL1, OMEGA_PAIR, ... (upper-cased option names)
       for (const OptionName &O : OptionTable) {
          std::string Var = "OMEGA_";
          for (const char *C = O.Name; *C; ++C)

@@ -63,6 +63,10 @@ class Halo : public Registry<Halo> {
 
    I4 exchangeFullArrayHalo(const Array2DReal &A, MeshElement E, hipStream_t S);
    I4 exchangeFullArrayHalo(const Array3DReal &A, MeshElement E, hipStream_t S);
+   /// the reference's signature (Halo.h:767: exchangeFullArrayHalo(Array, MeshElement)) for every array type above and
+   /// below: queued on this Halo's `Stream` (default: the null stream, where the reference's Kokkos kernels run)
+   hipStream_t Stream = nullptr;
+   template <class ArrayT> I4 exchangeFullArrayHalo(const ArrayT &A, MeshElement E) { return exchangeFullArrayHalo(A, E, Stream); }
    /// caller-owned raw device array [NT][RowsSize][Pitch] of which K values per row are levels
    I4 exchangeRaw(Real *Ptr, int NT, int RowsSize, int K, int Pitch, MeshElement E, hipStream_t S);
    /// the same for the reference's other element types (Halo.h:304-760 packs I4 / I8 / R4 / R8 arrays of rank 1-5): an

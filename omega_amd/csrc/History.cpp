@@ -135,7 +135,7 @@ std::vector<unsigned char> header(const std::vector<HistoryField> &F, const I8 N
 }
 } // namespace
 
-int writeHistory(const std::string &Path, const Decomp *D, const OceanState *State, const Tracers *Trc,
+int writeHistory(const std::string &Path, const Decomp *D, const OceanState *State, const TracerStore *Trc,
                  AuxiliaryState *Aux, const std::string &Csv, R8 SimTime, int TimeLevel, bool CreateFile, hipStream_t S) {
    OMEGA_REQUIRE(D && State && Aux, "writeHistory: missing object");
    const std::vector<HistoryField> F = expandHistoryContents(Csv);

@@ -36,7 +36,7 @@ std::vector<HistoryField> expandHistoryContents(const std::string &ContentsCsv);
 /// One dump.  CreateFile: this rank writes the header first (rank 0; the caller synchronises the ranks between
 /// the creation and the other ranks' calls).  Recomputes the auxiliary state from (State, Tracers) at time level
 /// `TimeLevel` on stream S and synchronises it.  Returns the number of variables written.
-int writeHistory(const std::string &Path, const Decomp *D, const OceanState *State, const Tracers *Trc,
+int writeHistory(const std::string &Path, const Decomp *D, const OceanState *State, const TracerStore *Trc,
                  AuxiliaryState *Aux, const std::string &ContentsCsv, R8 SimTimeSeconds, int TimeLevel, bool CreateFile,
                  hipStream_t S);
 

@@ -964,8 +964,7 @@ void HorzMesh::buildCellPV() {
    W.NRingCellsM0 = (I4)CellsM0.size(), W.NRingCellsM1 = (I4)CellsM1.size(), W.NRingCellsM2 = (I4)CellsM2.size();
    W.RingCellsM0 = RingCellsM0.Ptr, W.RingCellsM1 = RingCellsM1.Ptr, W.RingCellsM2 = RingCellsM2.Ptr;
    // (the kernels' full sweeps are instantiated for the valence most cells have: MaxEdges or MaxEdges-1)
-   const int DomEnv = tuning().DomValence;
-   W.DomM1 = (DomEnv != 0 && ME >= 6 && CellsM1.size() > CellsM0.size()) ? 1 : 0;
+   W.DomM1 = (ME >= 6 && CellsM1.size() > CellsM0.size()) ? 1 : 0;
    W.CellPVOK = OK ? 1 : 0, W.NIrregularEdges = (I4)Irregular.size();
    W.NIrregularOwned = (I4)(std::lower_bound(Irregular.begin(), Irregular.end(), NEdgesOwned) - Irregular.begin());
    // (Decomp: NEdgesHalo(i) = edges of the cells through halo layer i; the numbering is ascending in the layers)

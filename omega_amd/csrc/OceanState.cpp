@@ -79,7 +79,7 @@ I4 OceanState::copyToHost(Real *HH, Real *HU, I4 TimeLevel) const {
    return 0;
 }
 
-Tracers::Tracers(const HorzMesh *Mesh, Halo *MeshHalo_, int NVertLayers_, int NTracers_, int NTimeLevels_)
+TracerStore::TracerStore(const HorzMesh *Mesh, Halo *MeshHalo_, int NVertLayers_, int NTracers_, int NTimeLevels_)
     : MeshHalo(MeshHalo_) {
    OMEGA_REQUIRE(NTimeLevels_ >= 1 && NTracers_ >= 0, "Tracers: bad sizes");
    NTracers = NTracers_, NTimeLevels = NTimeLevels_, NVertLayers = NVertLayers_;
@@ -88,20 +88,20 @@ Tracers::Tracers(const HorzMesh *Mesh, Halo *MeshHalo_, int NVertLayers_, int NT
       TracerArrays.push_back(Array3DReal::levels("TracerArrays" + std::to_string(I), NTracers > 0 ? NTracers : 1,
                                                  NCellsSize, NVertLayers));
 }
-I4 Tracers::getTimeIndex(I4 &TimeIndex, I4 TimeLevel) const {
+I4 TracerStore::getTimeIndex(I4 &TimeIndex, I4 TimeLevel) const {
    if (NTimeLevels > 1 && (TimeLevel > 1 || (TimeLevel + NTimeLevels) <= 1))
       return -1;
    TimeIndex = (TimeLevel + CurTimeIndex + NTimeLevels) % NTimeLevels;
    return 0;
 }
-I4 Tracers::getAll(Array3DReal &A, I4 TimeLevel) const {
+I4 TracerStore::getAll(Array3DReal &A, I4 TimeLevel) const {
    I4 Idx;
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
    A = TracerArrays[Idx];
    return 0;
 }
-I4 Tracers::exchangeHalo(I4 TimeLevel, hipStream_t S) {
+I4 TracerStore::exchangeHalo(I4 TimeLevel, hipStream_t S) {
    I4 Idx;
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
@@ -109,13 +109,13 @@ I4 Tracers::exchangeHalo(I4 TimeLevel, hipStream_t S) {
       return 0;
    return MeshHalo->exchangeFullArrayHalo(TracerArrays[Idx], OnCell, S);
 }
-void Tracers::updateTimeLevels(hipStream_t S) {
+void TracerStore::updateTimeLevels(hipStream_t S) {
    OMEGA_REQUIRE(NTimeLevels > 1, "Tracers: can't update time levels for NTimeLevels == 1");
    exchangeHalo(1, S);
    rotateTimeLevels();
 }
-void Tracers::rotateTimeLevels() { CurTimeIndex = (CurTimeIndex + 1) % NTimeLevels; }
-I4 Tracers::copyToDevice(const Real *H, I4 TimeLevel) {
+void TracerStore::rotateTimeLevels() { CurTimeIndex = (CurTimeIndex + 1) % NTimeLevels; }
+I4 TracerStore::copyToDevice(const Real *H, I4 TimeLevel) {
    I4 Idx;
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
@@ -123,13 +123,54 @@ I4 Tracers::copyToDevice(const Real *H, I4 TimeLevel) {
       OMEGA::copyToDevice(TracerArrays[Idx], H);
    return 0;
 }
-I4 Tracers::copyToHost(Real *H, I4 TimeLevel) const {
+I4 TracerStore::copyToHost(Real *H, I4 TimeLevel) const {
    I4 Idx;
    if (getTimeIndex(Idx, TimeLevel) != 0)
       return -1;
    if (NTracers > 0)
       OMEGA::copyToHost(H, TracerArrays[Idx]);
    return 0;
+}
+
+// ---- the reference's static interface (Tracers.h), on the default store ----
+namespace {
+std::unique_ptr<TracerStore> &ownedDefaultStore() {
+   static std::unique_ptr<TracerStore> P;
+   return P;
+}
+TracerStore *&defaultStore() {
+   static TracerStore *P = nullptr;
+   return P;
+}
+} // namespace
+TracerStore *Tracers::init(const HorzMesh *Mesh, Halo *MeshHalo, int NVertLayers, int NTracers, int NTimeLevels) {
+   ownedDefaultStore().reset(new TracerStore(Mesh, MeshHalo, NVertLayers, NTracers, NTimeLevels));
+   return defaultStore() = ownedDefaultStore().get();
+}
+void Tracers::setDefault(TracerStore *Store) {
+   if (Store != ownedDefaultStore().get())
+      ownedDefaultStore().reset();
+   defaultStore() = Store;
+}
+TracerStore *Tracers::getDefault() { return defaultStore(); }
+I4 Tracers::clear() {
+   ownedDefaultStore().reset();
+   defaultStore() = nullptr;
+   return 0;
+}
+I4 Tracers::getNumTracers() { return defaultStore() ? defaultStore()->NTracers : 0; }
+I4 Tracers::getTimeIndex(I4 &TimeIndex, I4 TimeLevel) {
+   return defaultStore() ? defaultStore()->getTimeIndex(TimeIndex, TimeLevel) : -1;
+}
+I4 Tracers::getAll(Array3DReal &TracerArray, I4 TimeLevel) {
+   return defaultStore() ? defaultStore()->getAll(TracerArray, TimeLevel) : -1;
+}
+I4 Tracers::exchangeHalo(I4 TimeLevel) {
+   return defaultStore() ? defaultStore()->exchangeHalo(TimeLevel, defaultStore()->Stream) : -1;
+}
+void Tracers::updateTimeLevels() {
+   OMEGA_REQUIRE(defaultStore(), "Tracers::updateTimeLevels: no default tracer store (Tracers::init / setDefault)");
+   defaultStore()->updateTimeLevels(defaultStore()->Stream);
 }
 
 } // namespace OMEGA

@@ -5,8 +5,30 @@
 
 namespace OMEGA {
 
-Tendencies::Tendencies(const std::string &, const HorzMesh *Mesh_, int K, int NT, const TendParams &Options)
+std::string Tendencies::fusedLimit(size_t NCellsSize, size_t NEdgesSize, size_t NVerticesSize, int MaxEdges, int K) {
+   if (MaxEdges < 5 || MaxEdges > 8)
+      return "MaxEdges = " + std::to_string(MaxEdges) + " is outside 5..8, the table widths the fused RHS is instantiated for";
+   const size_t Rows = std::max(NCellsSize, std::max(NEdgesSize, NVerticesSize)), RowBytes = (size_t)levelPitch(K) * 8;
+   if (Rows * RowBytes > (size_t)FusedMaxPlaneBytes)
+      return "an array plane of " + std::to_string(Rows) + " rows x " + std::to_string(RowBytes) + " B exceeds the 4 GiB that the fused "
+             "kernels' 32-bit buffer offsets address: at most " + std::to_string((size_t)FusedMaxPlaneBytes / RowBytes) + " rows (cells, "
+             "edges or vertices, halo included) per rank at " + std::to_string(K) + " levels -- ~ " +
+             std::to_string((size_t)FusedMaxPlaneBytes / RowBytes / 3) + " cells of a hexagon mesh; partition the mesh over more ranks "
+             "(several ranks may share one GPU)";
+   return "";
+}
+
+Tendencies::Tendencies(const std::string &, const HorzMesh *Mesh_, int K, int NT, const TendParams &Options,
+                       bool AllowReferenceStructured)
     : Params(Options), Mesh(Mesh_), NVertLayers(K), NTracers(NT) {
+   if (!fusedRHSSupported(Mesh->view(), K)) {
+      const std::string Why = fusedLimit((size_t)Mesh->NCellsSize, (size_t)Mesh->NEdgesSize, (size_t)Mesh->NVerticesSize,
+                                         Mesh->view().MaxEdges, K);
+      OMEGA_REQUIRE(AllowReferenceStructured,
+                    "Tendencies: this mesh is outside the fused RHS (" + Why + "); pass AllowReferenceStructured "
+                    "(omg_tend_create_reference_structured) to accept the reference-structured 23-launch path, ~ 5 x slower");
+      UseFusedRHS = false;
+   }
    // Tendency arrays (Tendencies.cpp:233-238)
    LayerThicknessTend = Array2DReal::levels("LayerThicknessTend", Mesh->NCellsSize, K);
    NormalVelocityTend = Array2DReal::levels("NormalVelocityTend", Mesh->NEdgesSize, K);
@@ -142,13 +164,8 @@ bool Tendencies::computeAllTendenciesStage(const OceanState *State, const Auxili
 void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliaryState *Aux, const Array3DReal &TracerArray,
                                       int ThickLvl, int VelLvl, hipStream_t S) {
    Pacer::Range Timer("Tend:computeAllTendencies", 1);
-   if (UseFusedRHS && !fusedRHSSupported(Mesh->view(), NVertLayers) && !WarnedUnfused) {
-      // (32-bit byte offsets inside an array plane: more than ~2.2 M cells x 80 levels per GPU, or MaxEdges outside 5..8)
-      std::fprintf(stderr,
-                   "[omega_amd] Tendencies: this mesh / level count is outside the fused RHS (array planes of 4 GiB or "
-                   "more, or MaxEdges outside 5..8): computeAllTendencies uses the reference-structured 23-launch path\n");
-      WarnedUnfused = true;
-   }
+   // (a mesh outside the fused RHS -- Tendencies::fusedLimit -- only gets here if the caller accepted the 23-launch path
+   // when the object was made: the constructor fails otherwise)
    if (UseFusedRHS && fusedRHSSupported(Mesh->view(), NVertLayers)) {
       Array2DReal LayerThick, NormVel;
       OMEGA_REQUIRE(State->getLayerThickness(LayerThick, ThickLvl) == 0 &&
@@ -167,29 +184,6 @@ void Tendencies::computeAllTendencies(const OceanState *State, const AuxiliarySt
                         NormalVelocityTend.Ptr, TracerTend.Ptr, LayerThick.Ptr, NormVel.Ptr, TracerArray.Ptr, S, Ev,
                         EdgeScratch.Ptr, nullptr, Mesh->narrowView());
       };
-      if (const int Probe = tuning().ProbeSlice; Probe > 0) {
-         // MEASUREMENT PROBE (KernelCommon.h: SliceWindow): the same kernels as (blocks x level chunks x levels) launches
-         SliceWindow &W  = sliceWindow();
-         const int NChunks = (levelPitch(NVertLayers) * 8 + 127) / 128, NBlk = std::max(1, tuning().ProbeBlocks);
-         W.Active = 1, W.CS = NChunks, W.NBlk = NBlk;
-         auto One = [&](int C, int B, int L) {
-            W.C0 = C, W.Blk = B, W.LevelMask = 1 << L;
-            Launch();
-         };
-         if (Probe == 1) { // cache-blocked order: a block's three levels back to back
-            for (int C = 0; C < NChunks; ++C)
-               for (int B = 0; B < NBlk; ++B)
-                  for (int L = 0; L < 3; ++L)
-                     One(C, B, L);
-         } else { // the same launches level by level: every intermediate makes the trip through HBM
-            for (int L = 0; L < 3; ++L)
-               for (int C = 0; C < NChunks; ++C)
-                  for (int B = 0; B < NBlk; ++B)
-                     One(C, B, L);
-         }
-         W = SliceWindow{};
-         return;
-      }
       // wind forcing reads the stress arrays through a non-tile kernel too, still plain launches: capturable
       if (graphsOn() && !Ev && !CustomThicknessTend && !CustomVelocityTend) {
          GraphCache::Key Key;

@@ -8,12 +8,8 @@
 
 namespace OMEGA {
 
-// ---- TimeFrac arithmetic of the reference's TimeMgr, restricted to what `Real *
-// TimeInterval` and TimeInterval::get(seconds) need ----
+// ---- TimeFrac arithmetic of the reference's TimeMgr (TimeMgr.h) ----
 namespace {
-struct TimeFrac {
-   I8 Whole = 0, Numer = 0, Denom = 1;
-};
 I8 fracGCD(I8 A, I8 B) {
    A = std::llabs(A);
    B = std::llabs(B);
@@ -28,30 +24,32 @@ I8 fracGCD(I8 A, I8 B) {
    }
    return A;
 }
+} // namespace
 // TimeFrac::simplify (TimeMgr.cpp:956-1000)
-void simplify(TimeFrac &F) {
+void TimeFrac::simplify() {
+   OMEGA_REQUIRE(Denom != 0, "TimeFrac: zero denominator");
    I8 W;
-   if (std::llabs((W = F.Numer / F.Denom)) >= 1) {
-      F.Whole += W;
-      F.Numer %= F.Denom;
+   if (std::llabs((W = Numer / Denom)) >= 1) {
+      Whole += W;
+      Numer %= Denom;
    }
-   if (F.Whole > 0 && ((F.Numer < 0 && F.Denom > 0) || (F.Denom < 0 && F.Numer > 0))) {
-      F.Whole--;
-      F.Numer += F.Denom;
-   } else if ((F.Whole < 0 && (F.Numer > 0 && F.Denom > 0)) || (F.Denom < 0 && F.Numer < 0)) {
-      F.Whole++;
-      F.Numer -= F.Denom;
+   if (Whole > 0 && ((Numer < 0 && Denom > 0) || (Denom < 0 && Numer > 0))) {
+      Whole--;
+      Numer += Denom;
+   } else if ((Whole < 0 && (Numer > 0 && Denom > 0)) || (Denom < 0 && Numer < 0)) {
+      Whole++;
+      Numer -= Denom;
    }
-   if (F.Denom < 0) {
-      F.Denom *= -1;
-      F.Numer *= -1;
+   if (Denom < 0) {
+      Denom *= -1;
+      Numer *= -1;
    }
-   const I8 G = fracGCD(F.Numer, F.Denom);
-   F.Numer /= G;
-   F.Denom /= G;
+   const I8 G = fracGCD(Numer, Denom);
+   Numer /= G;
+   Denom /= G;
 }
 // TimeFrac::setSeconds (TimeMgr.cpp:193-283): continued-fraction conversion
-TimeFrac fromSeconds(R8 Seconds) {
+TimeFrac TimeFrac::fromSeconds(R8 Seconds) {
    TimeFrac F;
    const R8 Rabs = std::fabs(Seconds);
    OMEGA_REQUIRE(!((Rabs > 0.0 && Rabs < 1e-17) || Rabs > 1e18), "TimeStepper: time value out of range");
@@ -86,23 +84,80 @@ TimeFrac fromSeconds(R8 Seconds) {
    }
    F.Numer = N * Sign;
    F.Denom = D;
-   simplify(F);
+   F.simplify();
    return F;
 }
-} // namespace
+// TimeFrac::operator+ / operator- (TimeMgr.cpp:625-679): over the least common denominator
+TimeFrac TimeFrac::operator+(const TimeFrac &O) const {
+   TimeFrac S;
+   S.Denom = Denom / fracGCD(Denom, O.Denom) * O.Denom;
+   S.Numer = Numer * (S.Denom / Denom) + O.Numer * (S.Denom / O.Denom);
+   S.Whole = Whole + O.Whole;
+   S.simplify();
+   return S;
+}
+TimeFrac TimeFrac::operator-(const TimeFrac &O) const {
+   TimeFrac S;
+   S.Denom = Denom / fracGCD(Denom, O.Denom) * O.Denom;
+   S.Numer = Numer * (S.Denom / Denom) - O.Numer * (S.Denom / O.Denom);
+   S.Whole = Whole - O.Whole;
+   S.simplify();
+   return S;
+}
+// TimeFrac::operator*(R8) (TimeMgr.cpp:747-767)
+TimeFrac TimeFrac::operator*(R8 Multiplier) const {
+   const TimeFrac M = fromSeconds(Multiplier);
+   TimeFrac P;
+   P.Denom = Denom * M.Denom;
+   P.Numer = (Whole * Denom + Numer) * (M.Whole * M.Denom + M.Numer);
+   P.simplify();
+   return P;
+}
+TimeFrac TimeFrac::operator*(I4 Multiplier) const {
+   TimeFrac P;
+   P.Whole = Whole * Multiplier;
+   P.Numer = Numer * Multiplier;
+   P.Denom = Denom;
+   P.simplify();
+   return P;
+}
+void TimeInterval::set(R8 Length, TimeUnits Units) {
+   OMEGA_REQUIRE(Units == TimeUnits::Seconds || Units == TimeUnits::Minutes || Units == TimeUnits::Hours,
+                 "TimeInterval: only non-calendar units (seconds, minutes, hours) are supported");
+   Interval = TimeFrac::fromSeconds(Length);
+   if (Units == TimeUnits::Minutes)
+      Interval = Interval * (I4)60;
+   else if (Units == TimeUnits::Hours)
+      Interval = Interval * (I4)3600;
+}
+void TimeInterval::get(R8 &Length, TimeUnits Units) const {
+   OMEGA_REQUIRE(Units == TimeUnits::Seconds || Units == TimeUnits::Minutes || Units == TimeUnits::Hours,
+                 "TimeInterval: only non-calendar units (seconds, minutes, hours) are supported");
+   Length = Interval.getSeconds();
+   if (Units == TimeUnits::Minutes)
+      Length /= 60.0;
+   else if (Units == TimeUnits::Hours)
+      Length /= 3600.0;
+}
 
 R8 TimeStepper::coeffSeconds(R8 Mult, R8 TimeStepSeconds) {
-   const TimeFrac T = fromSeconds(TimeStepSeconds), M = fromSeconds(Mult);
-   TimeFrac P; // TimeFrac::operator*(R8) (TimeMgr.cpp:747-767)
-   P.Denom = T.Denom * M.Denom;
-   P.Numer = (T.Whole * T.Denom + T.Numer) * (M.Whole * M.Denom + M.Numer);
-   simplify(P);
-   return (R8)P.Whole + (R8)P.Numer / (R8)P.Denom; // TimeFrac::getSeconds (:382-391)
+   // (Real * TimeInterval, then TimeInterval::get(seconds): TimeStepper.cpp:392-393)
+   return (TimeFrac::fromSeconds(TimeStepSeconds) * Mult).getSeconds();
 }
 
 TimeStepper::TimeStepper(const std::string &Name_, TimeStepperType Type_, int NTimeLevels_, R8 Dt)
-    : Name(Name_), Type(Type_), NTimeLevels(NTimeLevels_), TimeStep(Dt) {
+    : Name(Name_), Type(Type_), NTimeLevels(NTimeLevels_), TimeStep(Dt, TimeUnits::Seconds), TimeStepSeconds(Dt) {
    OMEGA_REQUIRE(Dt > 0, "TimeStepper: time step must be positive");
+}
+
+// TimeStepper.h:82-84.  The model time of the stages is SimTime + RKC * TimeStep in the reference; here the schemes
+// derive it from StartTime + NStepsDone * TimeStep, so the step is anchored at SimTime first.
+void TimeStepper::doStep(OceanState *State, TimeInstant &SimTime) const {
+   TimeStepper *Self = const_cast<TimeStepper *>(this);
+   Self->StartTime   = SimTime.getSeconds();
+   Self->NStepsDone  = 0;
+   Self->doStep(State, Stream);
+   SimTime += TimeStep;
 }
 
 TimeStepperType TimeStepper::getFromStr(const std::string &In) {
@@ -122,7 +177,7 @@ std::map<std::string, std::unique_ptr<TimeStepper>> &allSteppers() {
 }
 } // namespace
 TimeStepper *TimeStepper::create(const std::string &Name, TimeStepperType Type, R8 Dt, Tendencies *T, AuxiliaryState *A,
-                                 const HorzMesh *M, Halo *H, Tracers *Tr) {
+                                 const HorzMesh *M, Halo *H, TracerStore *Tr) {
    auto &All = allSteppers();
    if (All.find(Name) != All.end())
       return nullptr;
@@ -152,12 +207,12 @@ TimeStepper *TimeStepper::make(const std::string &Name, TimeStepperType Type, R8
    }
 }
 
-void TimeStepper::attachData(Tendencies *T, AuxiliaryState *A, const HorzMesh *M, Halo *H, Tracers *Tr) {
+void TimeStepper::attachData(Tendencies *T, AuxiliaryState *A, const HorzMesh *M, Halo *H, TracerStore *Tr) {
    Tend     = T;
    AuxState = A;
    Mesh     = M;
    MeshHalo = H;
-   Trc      = Tr;
+   Trc      = Tr ? Tr : Tracers::getDefault();
 }
 
 void TimeStepper::finalizeInit() {
@@ -442,7 +497,7 @@ bool RungeKutta4Stepper::doStepFused(OceanState *State, hipStream_t S) {
       GraphCache::Key Key;
       GraphCache::add(Key, State), GraphCache::add(Key, CurH.Ptr), GraphCache::add(Key, NextH.Ptr);
       GraphCache::add(Key, CurU.Ptr), GraphCache::add(Key, NextU.Ptr), GraphCache::add(Key, CurTr.Ptr);
-      GraphCache::add(Key, NextTr.Ptr), GraphCache::add(Key, TimeStep), GraphCache::add(Key, (int)StoreStageTendencies);
+      GraphCache::add(Key, NextTr.Ptr), GraphCache::add(Key, TimeStepSeconds), GraphCache::add(Key, (int)StoreStageTendencies);
       GraphCache::add(Key, Tend), GraphCache::add(Key, AuxState), GraphCache::add(Key, Tend->Params), GraphCache::add(Key, S);
       GraphCache::add(Key, (int)Tend->UseFusedRHS);
       GraphCache::add(Key, tuningGeneration()); // (the kernel structure options are read at every launch)

@@ -3,8 +3,12 @@
 // doStep, the six update kernels, and the ForwardBackward / RungeKutta2 / RungeKutta4
 // schemes (ForwardBackwardStepper.cpp:27-82, RungeKutta2Stepper.cpp:27-73,
 // RungeKutta4Stepper.cpp:25-137).  The clock / alarm machinery of the reference is out of
-// scope: the step is `TimeStepSeconds`, and `Real * TimeInterval` coefficients go through
+// scope: the step is a TimeInterval (TimeMgr.h), and `Real * TimeInterval` coefficients go through
 // the same integer-fraction arithmetic as the reference's TimeMgr so they are bit-equal.
+// Every method exists in the native form (coefficient in seconds + the HIP stream) and with the
+// REFERENCE'S OWN SIGNATURE (TimeInterval coefficient / TimeInstant &SimTime, no stream: the
+// object's `Stream`), so that a reference call site -- ocnRun's `Stepper->doStep(State, SimTime)`,
+// a stepper subclass written like RungeKutta4Stepper.cpp:68-137 -- compiles unchanged.
 #ifndef OMEGA_AMD_TIMESTEPPER_H
 #define OMEGA_AMD_TIMESTEPPER_H
 
@@ -13,6 +17,7 @@
 #include "Halo.h"
 #include "OceanState.h"
 #include "Tendencies.h"
+#include "TimeMgr.h"
 
 namespace OMEGA {
 
@@ -28,7 +33,7 @@ class TimeStepper {
    /// the reference's registry (TimeStepper::create / get / getDefault / erase / clear, TimeStepper.h:87-139):
    /// create makes the scheme, attaches the data and finalises it; the registry owns it
    static TimeStepper *create(const std::string &Name, TimeStepperType Type, R8 TimeStepSeconds, Tendencies *Tend,
-                              AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, Tracers *Trc);
+                              AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, TracerStore *Trc);
    static TimeStepper *get(const std::string &Name);
    static TimeStepper *getDefault() { return get("Default"); }
    static void erase(const std::string &Name);
@@ -36,13 +41,19 @@ class TimeStepper {
    static TimeStepperType getFromStr(const std::string &In); ///< TimeStepper.h:64-75
 
    /// attach the objects the scheme works on (TimeStepper::attachData)
-   void attachData(Tendencies *Tend, AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, Tracers *Trc);
+   /// (Trc == nullptr: the default store of the static Tracers interface, as in the reference)
+   void attachData(Tendencies *Tend, AuxiliaryState *AuxState, const HorzMesh *Mesh, Halo *MeshHalo, TracerStore *Trc);
    /// after attachData: creates whatever a step needs, so that doStep allocates nothing (base: the halo's job tables
    /// and message buffers for the end-of-step exchange of h, u and the tracers)
    virtual void finalizeInit();
 
-   /// advance State (and the attached Tracers) by one step on stream S
+   /// advance State (and the attached tracers) by one step on stream S
    virtual void doStep(OceanState *State, hipStream_t S) = 0;
+   /// the reference's signature (TimeStepper.h:82-84): one step from SimTime on this object's `Stream`; SimTime is
+   /// advanced by TimeStep (the reference advances its StepClock and reads the time back, RungeKutta4Stepper.cpp:134-135).
+   /// const as in the reference: the step counter and the launch caches a step touches are bookkeeping, not state.
+   void doStep(OceanState *State, TimeInstant &SimTime) const;
+   hipStream_t Stream = nullptr; ///< stream of the reference-signature methods (default: the null stream, as Kokkos')
 
    // update kernels (TimeStepper.cpp:378-524); Coeff is a multiple of the time step
    void updateThicknessByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2, R8 CoeffSeconds,
@@ -57,28 +68,58 @@ class TimeStepper {
                       int TimeLevel1, hipStream_t S) const;
    void accumulateTracersUpdate(const Array3DReal &AccumTracer, R8 CoeffSeconds, hipStream_t S) const;
    void finalizeTracersUpdate(const Array3DReal &NextTracers, OceanState *State, int TimeLevel, hipStream_t S) const;
+   // ... and with the reference's signatures (TimeStepper.h:174-237): Coeff.get(seconds), this object's `Stream`
+   void updateStateByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2, TimeInterval Coeff) const {
+      updateStateByTend(State1, TimeLevel1, State2, TimeLevel2, Coeff.getSeconds(), Stream);
+   }
+   void updateThicknessByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2,
+                              TimeInterval Coeff) const {
+      updateThicknessByTend(State1, TimeLevel1, State2, TimeLevel2, Coeff.getSeconds(), Stream);
+   }
+   void updateVelocityByTend(OceanState *State1, int TimeLevel1, OceanState *State2, int TimeLevel2,
+                             TimeInterval Coeff) const {
+      updateVelocityByTend(State1, TimeLevel1, State2, TimeLevel2, Coeff.getSeconds(), Stream);
+   }
+   void updateTracersByTend(const Array3DReal &NextTracers, const Array3DReal &CurTracers, OceanState *State1,
+                            int TimeLevel1, OceanState *State2, int TimeLevel2, TimeInterval Coeff) const {
+      updateTracersByTend(NextTracers, CurTracers, State1, TimeLevel1, State2, TimeLevel2, Coeff.getSeconds(), Stream);
+   }
+   void weightTracers(const Array3DReal &NextTracers, const Array3DReal &CurTracers, OceanState *CurState,
+                      int TimeLevel1) const {
+      weightTracers(NextTracers, CurTracers, CurState, TimeLevel1, Stream);
+   }
+   void accumulateTracersUpdate(const Array3DReal &AccumTracer, TimeInterval Coeff) const {
+      accumulateTracersUpdate(AccumTracer, Coeff.getSeconds(), Stream);
+   }
+   void finalizeTracersUpdate(const Array3DReal &NextTracers, OceanState *State, int TimeLevel) const {
+      finalizeTracersUpdate(NextTracers, State, TimeLevel, Stream);
+   }
 
    /// seconds of (Mult * TimeStep), through TimeFrac arithmetic
    /// (components/omega/src/infra/TimeMgr.cpp:193-283, 747-767, 956-1000, 382-391)
    static R8 coeffSeconds(R8 Mult, R8 TimeStepSeconds);
-   R8 coeff(R8 Mult) const { return coeffSeconds(Mult, TimeStep); }
+   R8 coeff(R8 Mult) const { return (Mult * TimeStep).getSeconds(); }
 
    std::string Name;
    TimeStepperType Type;
    int NTimeLevels;
-   R8 TimeStep;
+   TimeInterval TimeStep;  ///< (TimeStepper.h:247) `RKB[Stage] * TimeStep` is a TimeInterval, as in the reference
+   R8 TimeStepSeconds;     ///< TimeStep in seconds
+   TimeInterval getTimeStep() const { return TimeStep; } ///< TimeStepper.h:129
    I8 NStepsDone = 0;
    /// model time in seconds since the reference time: StartTime + NStepsDone*TimeStep.  The schemes
    /// hand the stage times to Tendencies::ModelTime (the reference passes a TimeInstant).
    R8 StartTime = 0.0;
-   R8 simTime() const { return StartTime + (R8)NStepsDone * TimeStep; }
+   R8 simTime() const { return StartTime + (R8)NStepsDone * TimeStepSeconds; }
    /// TimeStepper::changeTimeStep (TimeStepper.h:141-143): the model time reached so far is kept
    void changeTimeStep(R8 NewTimeStepSeconds) {
       OMEGA_REQUIRE(NewTimeStepSeconds > 0, "TimeStepper: time step must be positive");
       StartTime  = simTime();
       NStepsDone = 0;
-      TimeStep   = NewTimeStepSeconds;
+      TimeStepSeconds = NewTimeStepSeconds;
+      TimeStep        = TimeInterval(NewTimeStepSeconds, TimeUnits::Seconds);
    }
+   void changeTimeStep(const TimeInterval &NewTimeStep) { changeTimeStep(NewTimeStep.getSeconds()); } ///< TimeStepper.h:141
 
  protected:
    /// end-of-step: halo exchange of the new level, then rotate (State->updateTimeLevels();
@@ -91,19 +132,21 @@ class TimeStepper {
    AuxiliaryState *AuxState = nullptr;
    const HorzMesh *Mesh     = nullptr;
    Halo *MeshHalo           = nullptr;
-   Tracers *Trc             = nullptr;
+   TracerStore *Trc         = nullptr;
 };
 
 class ForwardBackwardStepper : public TimeStepper {
  public:
    ForwardBackwardStepper(const std::string &Name, R8 Dt) : TimeStepper(Name, TimeStepperType::ForwardBackward, 2, Dt) {}
    void doStep(OceanState *State, hipStream_t S) override;
+   using TimeStepper::doStep;
 };
 
 class RungeKutta2Stepper : public TimeStepper {
  public:
    RungeKutta2Stepper(const std::string &Name, R8 Dt) : TimeStepper(Name, TimeStepperType::RungeKutta2, 2, Dt) {}
    void doStep(OceanState *State, hipStream_t S) override;
+   using TimeStepper::doStep;
 };
 
 class RungeKutta4Stepper : public TimeStepper {
@@ -111,6 +154,7 @@ class RungeKutta4Stepper : public TimeStepper {
    RungeKutta4Stepper(const std::string &Name, R8 Dt);
    void finalizeInit() override;
    void doStep(OceanState *State, hipStream_t S) override;
+   using TimeStepper::doStep;
 
  protected:
    static constexpr int NStages = 4;

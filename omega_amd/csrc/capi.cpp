@@ -43,7 +43,7 @@ struct omg_state {
    std::unique_ptr<OceanState> S;
 };
 struct omg_tracers {
-   std::unique_ptr<Tracers> T;
+   std::unique_ptr<TracerStore> T;
 };
 struct omg_aux {
    std::unique_ptr<AuxiliaryState> A;
@@ -946,7 +946,7 @@ int omg_tracers_create(const omg_mesh *m, omg_halo *halo, int nvertlayers, int n
    requireDevice(m->M.get());
    auto *R = new omg_tracers;
    try {
-      R->T.reset(new Tracers(m->M.get(), halo ? halo->H.get() : nullptr, nvertlayers, ntracers, ntimelevels));
+      R->T.reset(new TracerStore(m->M.get(), halo ? halo->H.get() : nullptr, nvertlayers, ntracers, ntimelevels));
    } catch (...) {
       delete R;
       throw;
@@ -1096,18 +1096,38 @@ int omg_aux_device_ptr(const omg_aux *a, const char *name, double **dev, size_t 
 }
 
 // ---------------------------------------------------------------- Tendencies
-int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out) {
+static int tendCreate(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out, bool Allow) {
    OMG_TRY
    OMG_ARG(m && out);
    requireDevice(m->M.get());
    auto *R = new omg_tend;
    try {
-      R->T.reset(new Tendencies("Default", m->M.get(), nvertlayers, ntracers, c ? toParams(c) : TendParams()));
+      R->T.reset(new Tendencies("Default", m->M.get(), nvertlayers, ntracers, c ? toParams(c) : TendParams(), Allow));
    } catch (...) {
       delete R;
       throw;
    }
    *out = R;
+   OMG_CATCH
+}
+int omg_tend_create(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c, omg_tend **out) {
+   return tendCreate(m, nvertlayers, ntracers, c, out, false);
+}
+int omg_tend_create_reference_structured(const omg_mesh *m, int nvertlayers, int ntracers, const omg_tend_config *c,
+                                         omg_tend **out) {
+   return tendCreate(m, nvertlayers, ntracers, c, out, true);
+}
+int omg_tend_fused_limit(int64_t ncells_size, int64_t nedges_size, int64_t nvertices_size, int max_edges, int nvertlayers,
+                         int *supported, char *why, size_t why_bytes) {
+   OMG_TRY
+   OMG_ARG(supported && ncells_size >= 0 && nedges_size >= 0 && nvertices_size >= 0 && nvertlayers > 0);
+   const std::string W = Tendencies::fusedLimit((size_t)ncells_size, (size_t)nedges_size, (size_t)nvertices_size, max_edges,
+                                                nvertlayers);
+   if (why && why_bytes > 0) {
+      std::strncpy(why, W.c_str(), why_bytes - 1);
+      why[why_bytes - 1] = 0;
+   }
+   *supported = W.empty() ? 1 : 0;
    OMG_CATCH
 }
 int omg_tend_destroy(omg_tend *t) {
@@ -1329,7 +1349,7 @@ int omg_update_by_tend(double *out, const double *in, const double *tend, double
 int omg_stepper_set_start_time(omg_stepper *st, double seconds) {
    OMG_TRY
    OMG_ARG(st);
-   st->St->StartTime = seconds - (double)st->St->NStepsDone * st->St->TimeStep;
+   st->St->StartTime = seconds - (double)st->St->NStepsDone * st->St->TimeStepSeconds;
    OMG_CATCH
 }
 int omg_stepper_get_time(const omg_stepper *st, double *seconds) {

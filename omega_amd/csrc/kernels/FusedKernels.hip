@@ -24,8 +24,7 @@ OMEGA_FUSED_INSTANCES_8(OMEGA_FUSED_DECLARE)
 /// does the stage-fused variant cover this mesh / option set?  (same conditions launchFusedT checks
 /// on its way to CellPVFinalBody)
 static bool stageFusedSupported(const MeshView &M, const TendParams &P, Real *EdgeScratch) {
-   const int EdgeMode = tuning().EdgeMode, FuseFinal = tuning().FuseFinal;
-   return isDefaultTermSet(P) && EdgeMode == 0 && FuseFinal && M.CellPVOK && M.CellPVFinalOK && EdgeScratch;
+   return isDefaultTermSet(P) && M.CellPVOK && M.CellPVFinalOK && EdgeScratch;
 }
 
 bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const AuxPtrs &A, Real *HTend, Real *UTend,
@@ -37,7 +36,7 @@ bool launchFusedRHS(const MeshView &M, int K, int NT, const TendParams &P, const
    // narrow cell tables (HorzMesh::narrowView): the sweeps run the (MaxEdges-1)-slot kernels on them, the cells with
    // MaxEdges edges go through list launches on M.  (Not with run-time option flags and 8 slots: the merged level-1
    // kernel is not instantiated for that, and both widths must take the same level-1 structure.)
-   if (Narrow && tuning().NarrowTables != 0 && EdgeScratch && tuning().EdgeMode == 0 && (Fast || Narrow->MaxEdges <= 6)) {
+   if (Narrow && tuning().NarrowTables != 0 && EdgeScratch && (Fast || Narrow->MaxEdges <= 6)) {
       switch (Narrow->MaxEdges) {
 #define OMEGA_NARROW_CASE(MN_)                                                                                     \
    case MN_:                                                                                                       \

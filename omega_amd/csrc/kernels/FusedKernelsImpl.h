@@ -65,7 +65,7 @@ namespace OMEGA {
 // Every resource has the size BufOOB: offsets below it are in range for any plane; a lane whose offset IS BufOOB is
 // out of range -- its load returns 0 without touching memory (checked on the hardware).  ldoIf uses that to switch a
 // load off by a (wave-uniform or per-lane) condition without a branch, so it can be issued early with the others.
-constexpr unsigned BufOOB = 0xffffff00u;
+constexpr unsigned BufOOB = FusedMaxPlaneBytes;
 typedef unsigned BufV4 __attribute__((ext_vector_type(4)));
 typedef unsigned BufV2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bufRsrc(const Real *Base) {
@@ -2204,17 +2204,8 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
       if (Ev)
          (void)hipEventRecord(Ev[I], S);
    };
-   // every dependency level sweeps in the opposite direction to the one before it (KernelCommon.h: sweepDirection)
-   auto Flip = [&]() {
-      if (tuning().Alternate)
-         sweepDirection() ^= 1;
-      else
-         sweepDirection() = 0;
-   };
-   Flip();
    // L1: replaces AuxState:vertexAuxState1, cellAuxState1, edgeAuxState1/2 (flux thickness), cellAuxState4 (Del2Tracers),
    // Tend:thicknessFluxDiv and the cell-0 half of Tend:potientialVortHAdv
-   sliceWindow().Level = 0;
    Pacer::start("Tend:fused:L1[AuxState:vertexAuxState1,cellAuxState1,edgeAuxState2,cellAuxState4;Tend:thicknessFluxDiv]", 2);
    Mark(0);
    // the vertex kernel stores RelVort and 1/LayerThickVertex; the two normalised vorticities are rebuilt from
@@ -2243,8 +2234,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
       }
       return Stage->BandStream;
    };
-   const int EdgeModeV     = Tn.EdgeMode;
-   const bool CellCentric     = EdgeModeV == 0 && M.CellPVOK && EdgeScratch;
+   const bool CellCentric     = M.CellPVOK && EdgeScratch;
    // vertex pass and side-0 PV sums inside the L1 cell kernel (option MergeL1 = 0: the three separate kernels)
    const int MergeL1Env = Tn.MergeL1;
    const bool MergeL1 = CellCentric && M.CellL1OK && P.PVTendencyEnable && MergeL1Env != 0 &&
@@ -2257,7 +2247,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
    const int DoDel2Tr = (NT > 0 && P.TracerHyperDiffTendencyEnable) ? 1 : 0;
    bool Cell1Done = false;
    // the merged kernel can take the side-0 sums of the cells with one edge fewer than the sweep's valence along (INLO)
-   const bool InlineOther = MergeL1 && ND == TME && NOther > 0 && Tn.InlineOther != 0;
+   const bool InlineOther = MergeL1 && ND == TME && NOther > 0;
    if (MergeL1) {
       auto LaunchL1x = [&](auto Epi, auto Inl) {
          constexpr bool EP = decltype(Epi)::value, IL = decltype(Inl)::value && ND == TME;
@@ -2338,9 +2328,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
    if (P.WindForcingTendencyEnable)
       launchEdgeAuxState1(Wide ? *Wide : M, A, P.WindInterpIsotropic, S);
    Pacer::stop("Tend:fused:L1", 2);
-   Flip();
    // L2 (only the del4 term consumes it): replaces AuxState:edgeAuxState3 (Del2Edge), cellAuxState2, vertexAuxState2
-   sliceWindow().Level = 1;
    Pacer::start("Tend:fused:L2[AuxState:vertexAuxState2,cellAuxState2]", 2);
    Mark(2);
    // independent sweeps share a launch (KernelCommon.h: tileKernel2); option Pair = 0 launches them one by one
@@ -2401,33 +2389,28 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
       launchTile(Bb, M.NBadCells, K, S);
    }
    Pacer::stop("Tend:fused:L2", 2);
-   Flip();
    // L3: replaces Tend:potientialVortHAdv, KEGrad, SSHGrad, velocityDiffusion, velocityHyperDiff, windForcing, bottomDrag,
    // AuxState:edgeAuxState4 (HTracersEdge) and Tend:tracerHorzAdv, tracerDiffusion, tracerHyperDiff
-   sliceWindow().Level = 2;
    Pacer::start("Tend:fused:L3[Tend:potientialVortHAdv,KEGrad,SSHGrad,velocityDiffusion,velocityHyperDiff,tracerHorzAdv,"
                 "tracerDiffusion,tracerHyperDiff]", 2);
    Mark(4);
    bool Marked5        = false;
    std::function<void()> LaunchFinalInterior; // set when the side-1 sweep is split for an overlapped exchange
    FusedKernelNames[4] = "FusedEdgeChainBody", FusedKernelNames[5] = "";
-   // option EdgeMode = 1 forces the edge-centric chain kernel (the fallback of meshes without the
-   // cell-centric PV tables) for A/B measurements
-   const int EdgeMode = Tn.EdgeMode, FuseFinalEnv = Tn.FuseFinal;
    // the side-1 PV + velocity kernel and the tracer kernel are independent: their main sweeps share a launch
-   const bool PairL3 = PairEnv && Fast && EdgeMode == 0 && M.CellPVOK && EdgeScratch && P.PVTendencyEnable &&
-                       FuseFinalEnv && M.CellPVFinalOK && NT > 0 && NMain > 0;
-   // option FuseL3 = 0: the plain RHS keeps the paired launch too (A/B measurements)
-   const bool FuseL3 = PairL3 && Tn.FuseL3 && !Stage;
+   const bool PairL3 = PairEnv && Fast && M.CellPVOK && EdgeScratch && P.PVTendencyEnable && M.CellPVFinalOK && NT > 0 &&
+                       NMain > 0;
+   // the plain RHS does both in ONE thread per (cell, levels): h and u gathered once (CellPVFinalTracerBody)
+   const bool FuseL3 = PairL3 && !Stage;
    // narrow tables, plain RHS: the wide cells' level-3 work (one thread does velocity + tracers, as the sweep's) and the
    // final pass of the other valence's list join the sweep's launch instead of being launches of their own
    // (measured on a QU240-sized sphere, 12 pentagons: their final-pass list inside the sweep's launch: RHS 109 -> 102 us;
    // the same for the stage pair, as a third body, and the side-0 list folded into the level-2 launch: both slower)
-   const bool FoldL3 = FuseL3 && ((CanWide && NWide > 0) || (NOther > 0 && Tn.FoldLists != 0));
+   const bool FoldL3 = FuseL3 && ((CanWide && NWide > 0) || NOther > 0);
    // plain RHS, one table width: the irregular-edge list (coast lines; the masked rim of a partition's halo) joins the
    // sweep's launch too (an eighth of the QU30-sized mesh with its halo: one launch of ~10 us less per RHS)
-   const bool FoldChain = FuseL3 && !Wide && M.NIrregularEdges > 0 && Tn.FoldLists != 0;
-   if (EdgeMode == 0 && M.CellPVOK && EdgeScratch) {
+   const bool FoldChain = FuseL3 && !Wide && M.NIrregularEdges > 0;
+   if (M.CellPVOK && EdgeScratch) {
       const bool PVOn = P.PVTendencyEnable != 0;
       bool Finished   = false;
       FusedKernelNames[4] = "";
@@ -2459,8 +2442,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
          }
          Mark(5);
          Marked5 = true;
-         const int FuseFinal = Tn.FuseFinal;
-         if (Fast && FuseFinal && M.CellPVFinalOK) {
+         if (Fast && M.CellPVFinalOK) {
             // Overlap == true: the full sweep is split into the band list now and the interior list after
             // the exchange has been started (Stage->AfterBand), see Kernels.h: StageUpdate
             const bool Overlap = Stage && Stage->AfterBand && M.NBandCells > 0;
@@ -2696,7 +2678,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
                                              EU};
             FusedCell3Body<TME, true, EP, FLL> B3{M, K, NT, P, H, U, Tr, A.Del2TracersCell, TrTend, ET};
             if constexpr (!EP) {
-               if (FuseL3) { // one thread per (cell, levels) does both: h and u gathered once
+               { // plain RHS (FuseL3): one thread per (cell, levels) does both, h and u gathered once
                   CellPVFinalTracerBody<TME, ND, FLS> BF{M, K, NT, P, H, U, A.RelVortVertex, A.InvThickVertex, EdgeScratch,
                                                 A.RelVortVertex, A.KineticEnergyCell, A.VelocityDivCell, A.Del2DivCell,
                                                 A.Del2RelVortVertex, UTend, Tr, A.Del2TracersCell, TrTend};
@@ -2756,8 +2738,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
                   LaunchSweep(BF);
                   return;
                }
-            }
-            if (EP && Stage && Stage->AfterBand && M.NBandCells > 0) {
+            } else if (Stage->AfterBand && M.NBandCells > 0) { // RK4 stages: the two bodies as a paired launch
                B1.List = B3.List = BandList;
                launchTile2(B1, NBandList, B3, NBandList, K, BandS());
                Stage->AfterBand(Stage->AfterBandCtx); // u, h and the tracers of every sent element are final
@@ -2765,7 +2746,7 @@ void launchFusedT(const MeshView &M, int K, int NT, const TendParams &P, const A
                B1.List = B3.List = M.InteriorCells;
                launchTile2(B1, M.NInteriorCells, B3, M.NInteriorCells, K, S);
             } else {
-               launchTile2(B1, EP ? NSweepVel : M.NCellsAll, B3, EP ? NSweepTr : M.NCellsAll, K, S);
+               launchTile2(B1, NSweepVel, B3, NSweepTr, K, S);
             }
          };
          if (Stage)

@@ -112,9 +112,7 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    if (Pitch <= 0)
       Pitch = K;
    Geom G;
-   const TuningOptions &Tn = tuning();
-   const int EnvW          = Tn.W;
-   G.W  = (K % 2 == 0 && MaxW >= 2 && EnvW >= 2) ? 2 : 1;
+   G.W  = (K % 2 == 0 && MaxW >= 2) ? 2 : 1;
    G.KV = K / G.W;
    // threadIdx.x spans ONE 128-byte line of a column (8 level-pairs, or 16 single levels) and
    // threadIdx.y the elements of the tile, so a workgroup issues every gather of its tile for one
@@ -128,9 +126,6 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    const int LineTX   = 128 / (8 * G.W);
    const bool Aligned = (Pitch * 8) % 128 == 0; // rows start on line boundaries (levelPitch pads K >= 16 to lines)
    int TX             = Aligned ? (G.KV < LineTX ? G.KV : LineTX) : (G.KV < 64 ? G.KV : 64);
-   const int EnvTX = Tn.TX, EnvTY = Tn.TY, EnvSW = Tn.Sweeps;
-   if (EnvTX > 0)
-      TX = EnvTX < G.KV ? EnvTX : G.KV;
    int TY = 256 / TX;
    // bodies with a short tracer loop run a little better on half-size tiles (QU30-sized, 6 tracers: -0.6..-1 %,
    // EC30to60-sized, 2 tracers: -1.3 %); with 37 tracers the full tile is better (+3.5 % for the half tile): the
@@ -141,35 +136,26 @@ inline Geom makeGeom(int N, int K, int MaxW = 2, int Pitch = 0, int MaxTY = 0) {
    // workgroups on 256 CUs): smaller tiles even out the tail (measured 0.884 -> 0.860 ms at that size)
    while (TY > 8 && (N + TY - 1) / TY < 4096)
       TY /= 2;
-   if (EnvTY > 0)
-      TY = EnvTY;
    if (TY < 1)
       TY = 1;
    G.Block = dim3(TX, TY, 1);
-   G.Tile  = TY * (EnvSW > 0 ? EnvSW : 1);
-   if (G.Tile > 256)
-      G.Tile = 256;
+   G.Tile  = TY;
    int NTiles = (N + G.Tile - 1) / G.Tile;
    // Small sweeps (QU240-sized meshes, the per-GPU share of a partitioned mesh): a workgroup walking its level
    // chunks one after the other is a chain of dependent memory round trips with too few workgroups in flight to
    // hide it, so the chunks go to separate workgroups (gridDim.y) -- more, shorter workgroups; each stages its own
    // copy of the tile's tables.
    int NChunks = (G.KV + TX - 1) / TX, Split = 1;
-   const int EnvSplit = Tn.ChunkSplit;
-   if (EnvSplit >= 0)
-      Split = EnvSplit > 0 ? (EnvSplit < NChunks ? EnvSplit : NChunks) : 1;
-   else
-      while (Split < NChunks && (long)NTiles * Split < 1200) // measured: QU240-sized (882 tiles) 77 -> 64 us at 2,
-         Split *= 2;                                         // 74 us at 4; an eighth of QU30 (7225 tiles) loses at any
+   while (Split < NChunks && (long)NTiles * Split < 1200) // measured: QU240-sized (882 tiles) 77 -> 64 us at 2,
+      Split *= 2;                                         // 74 us at 4; an eighth of QU30 (7225 tiles) loses at any
    if (Split > NChunks)
       Split = NChunks;
    G.Grid  = dim3(NTiles > 0 ? NTiles : 1, Split > 0 ? Split : 1, 1);
    G.NFull = NTiles;
    // (wave slots: 8 waves per CU for the kernels that matter -- two per SIMD; the tail is what the last round leaves)
-   const int EnvTail        = Tn.TailSplit;
    const int WavesPerWG     = (TX * TY + 63) / 64;
    const int Cap            = 256 * 8 / (WavesPerWG > 0 ? WavesPerWG : 1);
-   if (EnvTail && Split == 1 && NChunks > 1 && NTiles >= Cap) {
+   if (Split == 1 && NChunks > 1 && NTiles >= Cap) {
       const int R = NTiles % Cap;
       if (R > 0) {
          G.NFull     = NTiles - R;
@@ -225,44 +211,17 @@ template <class B> struct BodyMaxW<B, decltype((void)B::MaxW)> {
    static constexpr int V = B::MaxW;
 };
 
-/// MEASUREMENT PROBE (option ProbeSlice, Tendencies.cpp: computeAllTendencies; never on in production): the launches of
-/// the fused RHS restricted to ONE level chunk (C0 of CS) and to block Blk of NBlk of every sweep's tiles, and only the
-/// launches of the dependency levels in LevelMask.  Lets the three levels be walked block by block -- the order in which
-/// a block's intermediates would still sit in the 256 MiB memory-side cache when the next level reads them -- with the
-/// production kernels, to measure what that residency is worth before building a kernel architecture around it.
-/// The blocks ignore the neighbour dependencies across their rims: timings only, the rim values are wrong.
-struct SliceWindow {
-   int Active = 0, C0 = 0, CS = 1, Blk = 0, NBlk = 1, LevelMask = 7, Level = 0;
-};
-inline SliceWindow &sliceWindow() {
-   static thread_local SliceWindow W;
-   return W;
-}
-/// tiles [Begin, Begin + Count) of a sweep of NTiles tiles under the window
-inline void sliceTiles(int NTiles, int &Begin, int &Count) {
-   const SliceWindow &W = sliceWindow();
-   Begin = 0, Count = NTiles;
-   if (W.Active) {
-      Begin = (int)((long)NTiles * W.Blk / W.NBlk);
-      Count = (int)((long)NTiles * (W.Blk + 1) / W.NBlk) - Begin;
-   }
-}
-
 #ifndef OMEGA_LB
 #define OMEGA_LB 256
 #endif
 template <class Body, class T>
 __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
-    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit, int Rev, int TileBegin, int WinC0, int WinCS) {
+    tileKernel(Body B, int N, int KV, int Tile, int NFull, int TailSplit) {
    extern __shared__ __align__(16) unsigned char Lds[];
    // level chunks of this workgroup: C0, C0 + CS, ...  (whole tile: gridDim.y-way split; tail tile: one chunk each)
-   // (TileBegin, WinC0, WinCS = 0, 0, 1 except under the measurement probe: SliceWindow)
-   int TileId, C0 = blockIdx.y + WinC0, CS = gridDim.y * WinCS;
+   int TileId, C0 = blockIdx.y, CS = gridDim.y;
    if ((int)blockIdx.x < NFull) {
       TileId = xcdRemap(blockIdx.x, NFull);
-      if (Rev) // (sweepDirection: this sweep walks the elements from the end, see launchTile)
-         TileId = NFull - 1 - TileId;
-      TileId += TileBegin;
    } else {
       const int Bt = blockIdx.x - NFull;
       TileId       = NFull + Bt / TailSplit;
@@ -307,14 +266,13 @@ __global__ void __launch_bounds__(OMEGA_LB, BodyMinWaves<Body>::V)
 template <class BA, class BB, class T>
 __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<BB>::V ? BodyMinWaves<BA>::V
                                                                                        : BodyMinWaves<BB>::V))
-    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit, int Rev,
-                int TileBeginA, int TileBeginB, int WinC0, int WinCS) {
+    tileKernel2(BA A, BB Bb, int NA, int NB, int KV, int Tile, int NTilesA, int NFullB, int TailSplit) {
    extern __shared__ __align__(16) unsigned char Lds[];
    const int Tid  = threadIdx.y * blockDim.x + threadIdx.x;
    const int NThr = blockDim.x * blockDim.y;
    if ((int)blockIdx.x < NTilesA) {
       const int Ta    = xcdRemap(blockIdx.x, NTilesA);
-      const int First = (TileBeginA + (Rev ? NTilesA - 1 - Ta : Ta)) * Tile;
+      const int First = Ta * Tile;
       const int Cnt   = NA - First < Tile ? NA - First : Tile;
       typename BA::Lds L = A.carve(Lds, Tile);
       if (Cnt > 0)
@@ -324,7 +282,7 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
       return;
 #endif
       for (int Le = threadIdx.y; Le < Cnt; Le += blockDim.y)
-         for (int Kv = (blockIdx.y + WinC0) * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y * WinCS)
+         for (int Kv = blockIdx.y * blockDim.x + threadIdx.x; Kv < KV; Kv += blockDim.x * gridDim.y)
          {
             chunkFence<BA>();
             A.template compute<T>(L, Le, First + Le, Kv);
@@ -332,12 +290,9 @@ __global__ void __launch_bounds__(OMEGA_LB, (BodyMinWaves<BA>::V < BodyMinWaves<
    } else {
       // (the second body's last tiles are the launch's tail: one level chunk per workgroup, see Geom::TailSplit)
       const int Bb_ = blockIdx.x - NTilesA;
-      int TileId, C0 = blockIdx.y + WinC0, CS = gridDim.y * WinCS;
+      int TileId, C0 = blockIdx.y, CS = gridDim.y;
       if (Bb_ < NFullB) {
          TileId = xcdRemap(Bb_, NFullB);
-         if (Rev)
-            TileId = NFullB - 1 - TileId;
-         TileId += TileBeginB;
       } else {
          TileId = NFullB + (Bb_ - NFullB) / TailSplit;
          C0     = (Bb_ - NFullB) % TailSplit;
@@ -395,17 +350,9 @@ template <class B> inline void setWaves(B &Body, const Geom &G) {
 /// sets to the row pitch of the arrays (levelPitch(K) for the library's own arrays; Pitch >= K for caller-owned
 /// ones, e.g. compact raw arrays of the C ABI); bodies that also need the level COUNT (bottom level of the drag
 /// term) declare `int KLog`.
-/// Direction of the sweeps launched from now on (launchFusedT flips it between dependency levels): a sweep that walks
-/// the elements in the opposite direction to the one before it starts on what that one touched last -- the part of
-/// its inputs most likely to still sit in the 256 MiB memory-side cache.  Results do not depend on the order.
-inline int &sweepDirection() {
-   static thread_local int Rev = 0;
-   return Rev;
-}
 template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t S, int Pitch = -1) {
    if (N <= 0)
       return;
-   const int Rev = sweepDirection();
    Body B = B0;
    B.K    = Pitch > 0 ? Pitch : levelPitch(K);
    if constexpr (BodyHasKLog<Body>::V)
@@ -413,27 +360,14 @@ template <class Body> void launchTile(const Body &B0, int N, int K, hipStream_t 
    Geom G           = makeGeom(N, K, BodyMaxW<Body>::V, B.K, bodyMaxTY(B));
    setWaves(B, G);
    const size_t Lds = B.ldsBytes(G.Tile);
-   int TileBegin = 0, WinC0 = 0, WinCS = 1;
-   if (const SliceWindow &Win = sliceWindow(); Win.Active) { // measurement probe: one block of tiles, one level chunk
-      if (!(Win.LevelMask >> Win.Level & 1))
-         return;
-      int Cnt;
-      sliceTiles((N + G.Tile - 1) / G.Tile, TileBegin, Cnt);
-      if (Cnt <= 0)
-         return;
-      G.Grid = dim3(Cnt, 1, 1), G.NFull = Cnt, G.TailSplit = 1;
-      WinC0 = Win.C0, WinCS = Win.CS;
-   }
    if constexpr (BodyMaxW<Body>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev,
-                            TileBegin, WinC0, WinCS);
+         hipLaunchKernelGGL((tileKernel<Body, dv2>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit, Rev,
-                      TileBegin, WinC0, WinCS);
+   hipLaunchKernelGGL((tileKernel<Body, double>), G.Grid, G.Block, Lds, S, B, N, G.KV, G.Tile, G.NFull, G.TailSplit);
    HIP_CHECK(hipGetLastError());
 }
 
@@ -471,29 +405,16 @@ template <class BA, class BB> void launchTile2(const BA &A0, int NA, const BB &B
          Grid      = dim3(NTA + NFullB + R * TailSplit, 1, 1);
       }
    }
-   int NTAw = NTA, TileBeginA = 0, TileBeginB = 0, WinC0 = 0, WinCS = 1;
-   if (const SliceWindow &Win = sliceWindow(); Win.Active) { // measurement probe: one block of each sweep, one chunk
-      if (!(Win.LevelMask >> Win.Level & 1))
-         return;
-      int CntB;
-      sliceTiles(NTA, TileBeginA, NTAw);
-      sliceTiles(NTB, TileBeginB, CntB);
-      if (NTAw + CntB <= 0)
-         return;
-      NFullB = CntB, TailSplit = 1;
-      Grid   = dim3(NTAw + CntB, 1, 1);
-      WinC0 = Win.C0, WinCS = Win.CS;
-   }
    if constexpr (BodyMaxW<BA>::V >= 2) {
       if (G.W == 2) {
-         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTAw, NFullB,
-                            TailSplit, sweepDirection(), TileBeginA, TileBeginB, WinC0, WinCS);
+         hipLaunchKernelGGL((tileKernel2<BA, BB, dv2>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
+                            TailSplit);
          HIP_CHECK(hipGetLastError());
          return;
       }
    }
-   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTAw, NFullB,
-                      TailSplit, sweepDirection(), TileBeginA, TileBeginB, WinC0, WinCS);
+   hipLaunchKernelGGL((tileKernel2<BA, BB, double>), Grid, G.Block, Lds, S, A, Bb, NA, NB, G.KV, G.Tile, NTA, NFullB,
+                      TailSplit);
    HIP_CHECK(hipGetLastError());
 }
 
@@ -507,7 +428,6 @@ constexpr int MaxSweeps = 4;
 struct SweepPlan {
    int N[MaxSweeps];             ///< elements of each sweep
    int TileStart[MaxSweeps + 1]; ///< first workgroup of each sweep; [NBodies] = grid size
-   int Rev;                      ///< walk every sweep from its end (sweepDirection)
 };
 template <int I, class T, class B, class... Rest>
 __device__ __forceinline__ void runSweep(const SweepPlan &Pl, int KV, int Tile, unsigned char *Lds, const B &Body,
@@ -515,7 +435,7 @@ __device__ __forceinline__ void runSweep(const SweepPlan &Pl, int KV, int Tile, 
    if ((int)blockIdx.x < Pl.TileStart[I + 1]) {
       const int NTiles = Pl.TileStart[I + 1] - Pl.TileStart[I];
       const int Tl     = xcdRemap(blockIdx.x - Pl.TileStart[I], NTiles);
-      const int First  = (Pl.Rev ? NTiles - 1 - Tl : Tl) * Tile;
+      const int First  = Tl * Tile;
       const int Cnt    = Pl.N[I] - First < Tile ? Pl.N[I] - First : Tile;
       typename B::Lds L = Body.carve(Lds, Tile);
       const int Tid     = threadIdx.y * blockDim.x + threadIdx.x;
@@ -561,7 +481,6 @@ template <class B> inline void prepBody(B &Body, int K) {
 template <class B0, class B1> void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N1) {
    static_assert(BodyMaxW<B0>::V == BodyMaxW<B1>::V, "launchTileV: bodies must agree on the levels per thread");
    static_assert(sizeof(B0) + sizeof(B1) + sizeof(SweepPlan) <= 3900, "launchTileV: kernel arguments exceed 4 KiB");
-   OMEGA_REQUIRE(!sliceWindow().Active, "the ProbeSlice measurement covers list-free meshes only (launchTile / launchTile2)");
    B0 X0 = A0;
    B1 X1 = A1;
    detail::prepBody(X0, K), detail::prepBody(X1, K);
@@ -569,7 +488,6 @@ template <class B0, class B1> void launchTileV(int K, hipStream_t S, const B0 &A
    const int Ty0 = bodyMaxTY(X0), Ty1 = bodyMaxTY(X1);
    Geom G = makeGeom(Ns[0] + Ns[1], K, BodyMaxW<B0>::V, X0.K, Ty0 > Ty1 ? Ty0 : Ty1);
    SweepPlan Pl{};
-   Pl.Rev          = sweepDirection();
    Pl.TileStart[0] = 0;
    for (int I = 0; I < 2; ++I) {
       Pl.N[I]             = Ns[I];
@@ -595,7 +513,6 @@ void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N
    static_assert(BodyMaxW<B0>::V == BodyMaxW<B1>::V && BodyMaxW<B0>::V == BodyMaxW<B2>::V,
                  "launchTileV: bodies must agree on the levels per thread");
    static_assert(sizeof(B0) + sizeof(B1) + sizeof(B2) + sizeof(SweepPlan) <= 3900, "launchTileV: kernel arguments exceed 4 KiB");
-   OMEGA_REQUIRE(!sliceWindow().Active, "the ProbeSlice measurement covers list-free meshes only (launchTile / launchTile2)");
    B0 X0 = A0;
    B1 X1 = A1;
    B2 X2 = A2;
@@ -606,7 +523,6 @@ void launchTileV(int K, hipStream_t S, const B0 &A0, int N0, const B1 &A1, int N
    Ty     = bodyMaxTY(X2) > Ty ? bodyMaxTY(X2) : Ty;
    Geom G = makeGeom(Ns[0] + Ns[1] + Ns[2], K, BodyMaxW<B0>::V, X0.K, Ty);
    SweepPlan Pl{};
-   Pl.Rev          = sweepDirection();
    Pl.TileStart[0] = 0;
    for (int I = 0; I < 3; ++I) {
       Pl.N[I]             = Ns[I];

@@ -72,7 +72,9 @@ void launchTracerTendOnly(const MeshView &M, int K, int NT, const TendParams &P,
 /// PV: side-0 sums, then side-1 sums + remaining terms; otherwise one edge kernel in slot 4),
 /// 6 cell L3.  FusedKernelNames[i] is set by the launcher to the kernel actually used ("" = none).
 constexpr int FusedNumKernels = 7;
-/// MaxEdges in [5,8] and every array plane < 4 GiB (32-bit byte offsets inside a plane)
+/// MaxEdges in [5,8] and every array plane <= FusedMaxPlaneBytes (32-bit byte offsets inside a plane; the value is the
+/// size every buffer resource of the fused kernels is given, FusedKernelsImpl.h: BufOOB)
+constexpr unsigned FusedMaxPlaneBytes = 0xffffff00u;
 bool fusedRHSSupported(const MeshView &M, int K);
 extern const char *FusedKernelNames[FusedNumKernels];
 /// Runge-Kutta stage update folded into the kernels that produce the tendencies (the arithmetic of

@@ -8,6 +8,13 @@
 //      from tests/golden/*.npz), bit for bit, on a mesh read from an MPAS file through MeshFile;
 //   2. the reference's time-stepper known answer (test/timeStepping/TimeStepperTest.cpp:375-388): du/dt = -0.5 u as
 //      the custom velocity tendency, T = 1, dt = 0.2 and 0.1, L-inf error orders 4 / 1 / 2 +- 0.1.
+//   3. (r6) the REFERENCE'S CALL-SITE FORMS: a stepper subclass written HERE against the reference's signatures only --
+//      static Tracers::getAll, `SimTime + RKC[Stage] * TimeStep`, computeAllTendencies(..., TimeInstant),
+//      updateStateByTend(..., TimeInterval), ProvisState->exchangeHalo(Level), Halo::exchangeFullArrayHalo(Array, OnCell),
+//      State->updateTimeLevels(), Tracers::updateTimeLevels(), no stream anywhere (the scheme of
+//      RungeKutta4Stepper.cpp:68-137, in this file's own words) -- gives the golden RK4 vectors bit for bit, as does
+//      TimeStepper::doStep(OceanState *, TimeInstant &); a custom tendency in the reference's form (Array2DReal, ...,
+//      TimeInstant) receives the stage times.
 // usage: boundary_test <mesh.nc> <golden_dir> <K> <NT>
 #include "AuxiliaryState.h"
 #include "Decomp.h"
@@ -79,6 +86,45 @@ __global__ void decayKernel(double *Tend, const double *U, int NRows, int K, int
    }
 }
 
+// ---- 3. a time stepper written against the reference's signatures (TimeStepper.h:82-84, 174-237; Tendencies.h:73-102;
+// Tracers.h:119,195-199; OceanState.h:113-129; Halo.h:767) -- no hipStream_t, no seconds, no TracerStore ----
+class CallSiteRK4 : public RungeKutta4Stepper {
+ public:
+   CallSiteRK4(const std::string &Name, R8 Dt) : RungeKutta4Stepper(Name, Dt) {}
+   std::vector<double> StageSeconds; ///< what the stages passed as model time
+   void step(OceanState *State, TimeInstant &SimTime) {
+      const int Cur = 0, Next = 1;
+      Array3DReal CurTr, NextTr;
+      if (Tracers::getAll(CurTr, Cur) != 0 || Tracers::getAll(NextTr, Next) != 0)
+         throw std::runtime_error("CallSiteRK4: Tracers::getAll failed");
+      weightTracers(NextTr, CurTr, State, Cur);
+      OceanState *In             = State;
+      const Array3DReal *InTr    = &CurTr;
+      for (int Stage = 0; Stage < NStages; ++Stage) {
+         const TimeInstant StageTime = SimTime + RKC[Stage] * TimeStep;
+         StageSeconds.push_back(StageTime.getSeconds());
+         if (Stage > 0) { // provisional state of this stage from the tendencies of the one before
+            const TimeInterval A = RKA[Stage] * TimeStep;
+            updateStateByTend(ProvisState.get(), Cur, State, Cur, A);
+            updateTracersByTend(ProvisTracers, CurTr, ProvisState.get(), Cur, State, Cur, A);
+            if (Stage == 2) {
+               ProvisState->exchangeHalo(Cur);
+               MeshHalo->exchangeFullArrayHalo(ProvisTracers, OnCell);
+            }
+            In = ProvisState.get(), InTr = &ProvisTracers;
+         }
+         Tend->computeAllTendencies(In, AuxState, *InTr, Cur, Cur, StageTime);
+         const TimeInterval B = RKB[Stage] * TimeStep;
+         updateStateByTend(State, Next, State, Stage == 0 ? Cur : Next, B);
+         accumulateTracersUpdate(NextTr, B);
+      }
+      finalizeTracersUpdate(NextTr, State, Next);
+      State->updateTimeLevels();
+      Tracers::updateTimeLevels();
+      SimTime += TimeStep;
+   }
+};
+
 int main(int argc, char **argv) {
    if (argc < 5) {
       std::printf("usage: %s mesh.nc golden_dir K NT\n", argv[0]);
@@ -99,7 +145,7 @@ int main(int argc, char **argv) {
       OceanState *State = OceanState::create("Default", DefMesh, DefHalo, K, 2);
       AuxiliaryState *Aux = AuxiliaryState::create("Default", DefMesh, DefHalo, K, NT);
       Tendencies *Tend    = Tendencies::create("Default", DefMesh, K, NT, TendParams{});
-      Tracers Trc(DefMesh, DefHalo, K, NT, 2);
+      TracerStore Trc(DefMesh, DefHalo, K, NT, 2);
       CHECK(HorzMesh::get("Default") == DefMesh && Tendencies::get("nope") == nullptr, "get by name");
       const size_t NCg = File.desc().NCells, NEg = File.desc().NEdges;
 
@@ -209,7 +255,7 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(decayKernel, dim3((N + 255) / 256), dim3(256), 0, Str, NormalVelTend.Ptr, NormalVelEdge.Ptr,
                                DefMesh->NEdgesAll, NormalVelTend.Ext[1], NormalVelTend.Pitch, Coeff);
          };
-         Tracers TestTrc(DefMesh, DefHalo, K1, NT, 2);
+         TracerStore TestTrc(DefMesh, DefHalo, K1, NT, 2);
          const double TimeEnd = 1.0, Exact = std::exp(-Coeff * TimeEnd);
          const struct {
             const char *Name;
@@ -242,6 +288,70 @@ int main(int argc, char **argv) {
          }
          Tendencies::erase("TestTendencies");
          CHECK(Tendencies::get("TestTendencies") == nullptr, "erase");
+      }
+      // ---- 3. the reference's call-site forms ----
+      {
+         HIP_CHECK(hipDeviceSynchronize());
+         State->copyToDevice(Hl.data(), Ul.data(), 0);     // (level 0 = the current level, whatever the rotation so far)
+         Trc.copyToDevice(Tl.data(), 0);
+         Tracers::setDefault(&Trc);
+         CHECK(Tracers::getDefault() == &Trc && Tracers::getNumTracers() == NT, "Tracers: static interface on a default store");
+         CallSiteRK4 Mine("CallSite", 600.0);
+         Mine.attachData(Tend, Aux, DefMesh, DefHalo, nullptr); // nullptr: the static Tracers' store, as in the reference
+         Mine.finalizeInit();
+         TimeInstant SimTime = TimeInstant::fromSeconds(1200.0);
+         // a custom tendency in the REFERENCE'S form (Tendencies.h:51-53): records `Time - ReferenceTime` in seconds
+         std::vector<double> Seen;
+         const TimeInstant ReferenceTime = TimeInstant::fromSeconds(200.0);
+         Tend->CustomThicknessTend       = [&Seen, ReferenceTime](Array2DReal, const OceanState *, const AuxiliaryState *, int, int,
+                                                            TimeInstant Time) {
+            R8 ElapsedSec;
+            TimeInterval Elapsed = Time - ReferenceTime;
+            Elapsed.get(ElapsedSec, TimeUnits::Seconds);
+            Seen.push_back(ElapsedSec);
+         };
+         Mine.step(State, SimTime);
+         HIP_CHECK(hipDeviceSynchronize());
+         Tend->CustomThicknessTend = nullptr;
+         CHECK(SimTime == TimeInstant::fromSeconds(1800.0) && (SimTime - ReferenceTime).getSeconds() == 1600.0, "SimTime advanced by TimeStep");
+         CHECK(Mine.StageSeconds == (std::vector<double>{1200.0, 1500.0, 1500.0, 1800.0}), "stage times SimTime + RKC * TimeStep");
+         CHECK(Seen == (std::vector<double>{1000.0, 1300.0, 1300.0, 1600.0}), "reference-form custom tendency saw Time - ReferenceTime");
+         State->copyToHost(H1.data(), U1.data(), 0);
+         Trc.copyToHost(T1.data(), 0);
+         CHECK(sameRows(H1, readBin(Dir + "/rk4_h.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K) &&
+                   sameRows(U1, readBin(Dir + "/rk4_u.bin"), DefDecomp->EdgeIDH, DefMesh->NEdgesOwned, DefMesh->NEdgesSize, K) &&
+                   sameRows(T1, readBin(Dir + "/rk4_tr.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K,
+                            NT, NCg),
+               "a stepper written against the reference's signatures gives the golden RK4 vectors");
+         // ... and TimeStepper::doStep(OceanState *, TimeInstant &) of the library's own scheme, through a const pointer
+         State->copyToDevice(Hl.data(), Ul.data(), 0);
+         Trc.copyToDevice(Tl.data(), 0);
+         const TimeStepper *ConstStepper = TimeStepper::getDefault();
+         TimeInstant T2                  = TimeInstant::fromSeconds(0.0);
+         ConstStepper->doStep(State, T2);
+         HIP_CHECK(hipDeviceSynchronize());
+         CHECK(T2.getSeconds() == 600.0 && ConstStepper->getTimeStep() == TimeInterval(10.0, TimeUnits::Minutes), "doStep(State, SimTime)");
+         State->copyToHost(H1.data(), U1.data(), 0);
+         Trc.copyToHost(T1.data(), 0);
+         CHECK(sameRows(H1, readBin(Dir + "/rk4_h.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K) &&
+                   sameRows(U1, readBin(Dir + "/rk4_u.bin"), DefDecomp->EdgeIDH, DefMesh->NEdgesOwned, DefMesh->NEdgesSize, K) &&
+                   sameRows(T1, readBin(Dir + "/rk4_tr.bin"), DefDecomp->CellIDH, DefMesh->NCellsOwned, DefMesh->NCellsSize, K,
+                            NT, NCg),
+               "doStep(OceanState *, TimeInstant &) gives the golden RK4 vectors");
+         // the other reference-signature methods compile and run: group tendencies, aux state, state exchange
+         Array3DReal Tr0;
+         Tracers::getAll(Tr0, 0);
+         Tend->computeThicknessTendencies(State, Aux, 0, 0, T2);
+         Tend->computeVelocityTendenciesOnly(State, Aux, 0, 0, T2);
+         Tend->computeTracerTendencies(State, Aux, Tr0, 0, 0, T2);
+         Aux->computeAll(State, Tr0, 0, 0);
+         Aux->computeMomAux(State, 0, 0);
+         CHECK(State->exchangeHalo(0) == 0 && Tracers::exchangeHalo(0) == 0 && Aux->exchangeHalo() == 0 &&
+                   DefHalo->exchangeFullArrayHalo(Tr0, OnCell) == 0,
+               "reference-signature exchanges");
+         HIP_CHECK(hipDeviceSynchronize());
+         Tracers::setDefault(nullptr);
+         CHECK(Tracers::getAll(Tr0, 0) == -1, "Tracers::getAll without a default store returns an error code");
       }
       HIP_CHECK(hipStreamDestroy(S));
       // reference shutdown order (TimeStepperTest.cpp finalizeTimeStepperTest)

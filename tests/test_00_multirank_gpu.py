@@ -192,18 +192,6 @@ def test_unmerged_unpaired_kernel_structure_in_a_child_process():
     assert " passed" in out and "failed" not in out
 
 
-def test_paired_level3_launch_for_the_plain_rhs_in_a_child_process():
-    """Option FuseL3 = 0: the plain RHS runs CellPVFinalBody + FusedCell3Body as the paired launch the RK4 stages use
-    (default: both in one thread, CellPVFinalTracerBody); same bits required."""
-    env = dict(os.environ, OMEGA_AMD_OPTIONS="FuseL3=0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-k",
-                        "compute_all_tendencies and fused and (K80 or K4_ or K60 or ico3 or fib1500 or coast)"],
-                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    out = r.stdout.decode()
-    assert r.returncode == 0, out[-3000:]
-    assert " passed" in out and "failed" not in out
-
-
 def test_wide_tables_only_in_a_child_process():
     """Option NarrowTables = 0: meshes of hexagons with a few heptagons keep ONE set of cell tables, 7 wide, and sweep
     them with the 6-valent kernel instantiations (round 2's structure; what meshes whose ring tables are not all valid

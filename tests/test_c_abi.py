@@ -109,9 +109,15 @@ def test_library_never_reads_the_environment():
 def test_options_api():
     import omega_amd as oa
     import pytest
-    for name, default in (("MergeL1", 1), ("Pair", 1), ("FuseL3", 1), ("ForceGeneric", 0), ("KeepMaxEdges", 0),
-                          ("DomValence", 1), ("NarrowTables", 1), ("Graphs", -1), ("TX", 0), ("ChunkSplit", -1),
-                          ("SendBand", 1), ("BandOnComm", 1), ("ShrinkSweeps", 1), ("FoldLists", 1), ("InlineOther", 1)):
+    # every option the library has (omega_amd/csrc/Tuning.h names, next to each, the mesh class that reaches the
+    # structure it forces without the switch); the round-1..5 A/B knobs and the ProbeSlice measurement probe are gone
+    survivors = (("MergeL1", 1), ("Pair", 1), ("TracerPatch", 1), ("SendBand", 1), ("BandOnComm", 1), ("ShrinkSweeps", 1),
+                 ("ForceGeneric", 0), ("KeepMaxEdges", 0), ("NarrowTables", 1), ("ValenceSort", 0), ("Graphs", -1))
+    for gone in ("ProbeSlice", "ProbeBlocks", "EdgeMode", "FuseFinal", "FuseL3", "InlineOther", "FoldLists", "Alternate",
+                 "WaveWindow", "DomValence", "W", "TX", "TY", "Sweeps", "ChunkSplit", "TailSplit"):
+        with pytest.raises(oa.OmegaAmdError):
+            oa.set_option(gone, 1)
+    for name, default in survivors:
         if not __import__("os").environ.get("OMEGA_AMD_OPTIONS"):
             assert oa.get_option(name) == default, name
         old = oa.get_option(name)
@@ -120,3 +126,27 @@ def test_options_api():
         oa.set_option(name, old)
     with pytest.raises(oa.OmegaAmdError):
         oa.set_option("NoSuchOption", 1)
+
+
+def test_the_fused_rhs_limit_is_a_decision_not_a_surprise():
+    """The fused kernels address an array plane with 32-bit byte offsets: a rank with an array of 4 GiB or more (about
+    2.2 M cells x 80 levels) is outside them.  omg_tend_create then FAILS naming the limit (omg_tend_create_reference_structured
+    is the caller's explicit acceptance of the 23-launch path) -- checked here on sizes alone, no allocation."""
+    import omega_amd as oa
+    K = 80
+    rows_max = 0xffffff00 // (oa.level_pitch(K) * 8)              # rows of 640 bytes below 4 GiB
+    ok, why = oa.fused_limit(rows_max // 3, rows_max, 2 * rows_max // 3, 6, K)
+    assert ok and why == ""
+    ok, why = oa.fused_limit(rows_max // 3 + 1, rows_max + 1, 2 * rows_max // 3, 6, K)      # one edge row more
+    assert not ok and "4 GiB" in why and str(rows_max) in why and "more ranks" in why, why
+    ok, why = oa.fused_limit(2_300_000, 6_900_000, 4_600_000, 6, K)                         # "2.3 M cells on one GPU"
+    assert not ok and "6900000 rows" in why
+    ok, _ = oa.fused_limit(2_300_000, 6_900_000, 4_600_000, 6, 60)                          # the same mesh at 60 (-> 64) levels fits
+    assert ok
+    ok, why = oa.fused_limit(1000, 3000, 2000, 9, K)
+    assert not ok and "MaxEdges = 9" in why
+    ok, why = oa.fused_limit(1000, 3000, 2000, 4, K)
+    assert not ok and "MaxEdges = 4" in why
+    # configs[4] per rank (462 400 owned cells + 4 halo layers, 80 levels) is far inside
+    assert oa.fused_limit(480_000, 1_440_000, 960_000, 6, 80)[0]
+

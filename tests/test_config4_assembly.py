@@ -86,6 +86,20 @@ def test_one_real_rank_of_the_eight_on_the_gpu(big):
     hT, uT = tend.get(0)[:nc].copy(), tend.get(1)[:ne].copy()
     trT = tend.get(2)[[0, 17, 36], :nc].copy()
     assert np.isfinite(hT).all() and np.isfinite(uT).all() and np.isfinite(trT).all() and np.abs(trT).max() > 0
+    # ---- the oracle at this rank's size (r6).  Tracers do not couple in the RHS (TendencyTerms.h:343-492: every tracer
+    # term reads h, u and ITS tracer), so the oracle runs the rank's local mesh with h, u and tracers {0, 17, 36} as an
+    # NT = 3 problem (~ one headline-size oracle evaluation): hTend, uTend and those three planes of the NT = 37 GPU
+    # evaluation must be bit-identical on owned elements.
+    from oracle import oracle as O
+    SUB = [0, 17, 36]
+    omesh = O.Mesh(mesh.local_arrays(), K)
+    orc = O.Oracle(omesh, len(SUB), O.default_config())
+    tr3 = np.ascontiguousarray(tr_host[SUB][:, :, :K])
+    ohT, ouT, otrT = orc.compute_all_tendencies(h, u, tr3)
+    assert np.array_equal(hT, ohT[:nc]), "configs[4] rank: LayerThicknessTend differs from the oracle"
+    assert np.array_equal(uT, ouT[:ne]), "configs[4] rank: NormalVelocityTend differs from the oracle"
+    assert np.array_equal(trT, otrT[:, :nc]), "configs[4] rank: TracerTend planes 0 / 17 / 36 differ from the oracle"
+    del ohT, ouT, otrT
     # determinism, and the reference-structured launch sequence gives the same bits on owned elements
     tend.compute_all_tendencies(state, aux, tracers)
     oa.device_synchronize()
@@ -168,3 +182,20 @@ def test_one_real_rank_of_the_eight_on_the_gpu(big):
     del hb, ub, tb
     hc, uc, tc = two_steps(False, False)
     assert np.array_equal(ha, hc) and np.array_equal(ua, uc) and np.array_equal(ta, tc), "stage-fused != reference-structured"
+    del hc, uc, tc
+    # ---- ... and the oracle's two RK4 steps of the same rank (r6): orc_rk4_step with an exchange callback that does what
+    # the frozen-halo wire does -- every halo row back to its initial state at both exchange points of a step
+    # (RungeKutta4Stepper.cpp:107-113, 127-131) -- on the NT = 3 subset.  h, u and tracers 0 / 17 / 36 of the 37-tracer
+    # GPU run must equal it bit for bit on owned elements.
+    na, nea = mesh.NCellsAll, mesh.NEdgesAll
+
+    def frozen_halo(hh, uu, tt):
+        hh[nc:na] = h[nc:na]
+        uu[ne:nea] = u[ne:nea]
+        tt[:, nc:na] = tr3[:, nc:na]
+    ost = orc.make_state(h, u, tr3)
+    for _ in range(2):
+        orc.step("rk4", ost, dt, exchange=frozen_halo)
+    assert np.array_equal(ha, ost["h"][0][:nc]), "configs[4] rank: h after two RK4 steps differs from the oracle"
+    assert np.array_equal(ua, ost["u"][0][:ne]), "configs[4] rank: u after two RK4 steps differs from the oracle"
+    assert np.array_equal(ta[SUB], ost["tr"][0][:, :nc]), "configs[4] rank: tracers 0 / 17 / 36 after two RK4 steps differ"

@@ -13,7 +13,7 @@
 #   args=<bench.py args>    e.g. args=--local-order curve
 # and "" or "default" = the default build, options and arguments.  Examples:
 #   bash tools/ab.sh r05 qu30 -- default "opt=TracerPatch=0"
-#   bash tools/ab.sh r05 ico7 --reps 3 -- default "lib=_x" "lib=_x;opt=FuseL3=0"
+#   bash tools/ab.sh r05 ico7 --reps 3 -- default "lib=_x" "lib=_x;opt=TracerPatch=0"
 #   bash tools/ab.sh r05 qu30 -- "lib=_r2;args=--local-order curve" "lib=_r3;args=--local-order curve" default
 #   bash tools/ab.sh r05 qu240 --args "--steps 200 --warmup 20 --rk4-steps 100" -- default "opt=Graphs=1"
 # --kernel-stats runs each variant once under rocprofv3 --kernel-trace --stats instead and prints the per-kernel
