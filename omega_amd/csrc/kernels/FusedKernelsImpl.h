@@ -66,12 +66,6 @@ namespace OMEGA {
 // out of range -- its load returns 0 without touching memory (checked on the hardware).  ldoIf uses that to switch a
 // load off by a (wave-uniform or per-lane) condition without a branch, so it can be issued early with the others.
 constexpr unsigned BufOOB = FusedMaxPlaneBytes;
-#ifdef OMEGA_PRICE_NO_PV_SCRATCH
-// PRICING BUILD (variant library only, profiles/EXPERIMENTS.md r6): the PV scratch round trip switched off -- level 1
-// keeps the side-0 arithmetic but its store never executes, level 3 starts every running sum at zero.  Values wrong.
-__device__ __forceinline__ bool priceNever(double V) { return V == 1.2345e300; }
-__device__ __forceinline__ bool priceNever(dv2 V) { return V.x == 1.2345e300; }
-#endif
 typedef unsigned BufV4 __attribute__((ext_vector_type(4)));
 typedef unsigned BufV2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bufRsrc(const Real *Base) {
@@ -546,11 +540,7 @@ template <int TME, bool Fast, bool EPI = false, int NR = TME, bool INLO = false,
                   const T NormVort = (QRe[I] + QFe[I] + QRe[Kk] + QFe[Kk]) * 0.5;
                   Acc += L.Wt[(Le * TME + I) * TM1 + J - 1] * Flux[Kk] * Ue[Kk] * NormVort;
                }
-#ifdef OMEGA_PRICE_NO_PV_SCRATCH
-               stoIf<T>(priceNever(Acc), Partial, OffE[I], Acc);
-#else
                sto<T>(Partial, OffE[I], Acc);
-#endif
             }
          }
       };
@@ -1436,11 +1426,7 @@ template <int TME, int NR = TME, bool EPI = false> struct CellPVFinalBody {
       T Acc[N];
 #pragma unroll
       for (int I = 0; I < N; ++I)
-#ifdef OMEGA_PRICE_NO_PV_SCRATCH
-         Acc[I] = splat<T>(0.0);
-#else
          Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, OffE[I]);
-#endif
 #pragma unroll
       for (int I = 0; I < N; ++I) {
          if (L.Role[Le * TME + I] != 2)
@@ -1639,11 +1625,7 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerBody {
          T Acc[N];
 #pragma unroll
          for (int I = 0; I < N; ++I)
-#ifdef OMEGA_PRICE_NO_PV_SCRATCH
-            Acc[I] = splat<T>(0.0);
-#else
             Acc[I] = ldntIf<T>(L.Role[Le * TME + I] == 2, Partial, OffE[I]);
-#endif
 #pragma unroll
          for (int I = 0; I < N; ++I) {
             if (L.Role[Le * TME + I] != 2)
@@ -1767,10 +1749,6 @@ template <int TME, int NR = TME, int FL = 3> struct CellPVFinalTracerPatchBody :
       int *OKp;
    };
    size_t ldsBytes(int Tile) const {
-#ifdef OMEGA_PRICE_EXTRA_LDS
-      return Base::ldsBytes(Tile) + ldsRound8(sizeof(int) * NP) + ldsRound8((size_t)Tile * 8) + 16 + 8 + (size_t)4 * NP * 128 +
-             (size_t)OMEGA_PRICE_EXTRA_LDS; // PRICING BUILD: the LDS a 2-ring patch of u / h / q rows would occupy (unused)
-#endif
       return Base::ldsBytes(Tile) + ldsRound8(sizeof(int) * NP) + ldsRound8((size_t)Tile * 8) + 16 + 8 + (size_t)4 * NP * 128;
    }
    __device__ Lds carve(unsigned char *Ptr, int Tile) const {
