@@ -267,8 +267,8 @@ int omg_halo_check(const omg_halo *h);
  *      that tests can drive generated meshes through it -- no option can make a result wrong, and there is no measurement
  *      probe in the library.  Names: MergeL1 Pair TracerPatch (structure of the fused RHS; read at every launch); SendBand
  *      BandOnComm ShrinkSweeps (what a rank leaves out inside an RK4 step; read at every stage); ForceGeneric KeepMaxEdges
- *      NarrowTables (mesh tables; read when a HorzMesh is created); ValenceSort (local numbering; read when a Decomp with
- *      the k-d order is created); Graphs (-1 per object, 0 never, 1 default on).  Unknown names fail.
+ *      NarrowTables (mesh tables; read when a HorzMesh is created); Graphs (-1 per object, 0 never, 1 default on).
+ *      Unknown names fail.
  *      omg_set_timing_level: roctx ranges named after the reference's Pacer timers ("Tend:...", "AuxState:...",
  *      "RK4:haloExch"; share/pacer/Pacer.cpp:138-200) are emitted for timers up to this level (default 3 = all). ---- */
 int omg_set_option(const char *name, int value);

@@ -5,7 +5,6 @@
 #include "Decomp.h"
 #include "Partition.h"
 
-#include "Tuning.h"
 
 #include <algorithm>
 #include <array>
@@ -106,36 +105,6 @@ void Decomp::buildCellOrder() {
 // Deterministic (ties by global id): every rank derives every rank's numbering.
 void Decomp::kdOrder(std::vector<I4> &List, size_t Begin, size_t End) const {
    OMEGA_REQUIRE(G.XCell && G.YCell, "Decomp: k-d ordering needs cell coordinates");
-   // Valence sort (option ValenceSort, default OFF: measured +-0.3 % on the spheres, profiles/r05_ab_valence_sort_*.jsonl): the cell sweeps of the kernels are instantiated for the valence most
-   // cells have and skip the others, which run as list launches (FusedKernelsImpl.h: launchFusedT) -- a pentagon or heptagon
-   // inside a tile of hexagons is a row of idle lanes for the tile's whole life.  So inside every group the cells of the
-   // group's dominant valence come first, k-d ordered among themselves, and the rest after them (k-d ordered too):
-   // tiles of the first part are full, the list cells' own rows are contiguous.  A function of the group's contents
-   // alone (every rank derives every rank's numbering); meshes of one valence are unchanged.
-   if (tuning().ValenceSort && End - Begin > 1) {
-      auto Valence = [&](I4 C) {
-         int N = 0;
-         for (int J = 0; J < MaxEdges; ++J) {
-            const I4 E = G.EdgesOnCell[(size_t)C * MaxEdges + J];
-            N += (E >= 0 && E < NEdgesGlobal) ? 1 : 0;
-         }
-         return N;
-      };
-      std::vector<size_t> Count(MaxEdges + 1, 0);
-      for (size_t I = Begin; I < End; ++I)
-         ++Count[Valence(List[I])];
-      int Dom = 0;
-      for (int V = 1; V <= MaxEdges; ++V)
-         if (Count[V] > Count[Dom])
-            Dom = V;
-      if (Count[Dom] < End - Begin) {
-         const size_t Mid = std::stable_partition(List.begin() + Begin, List.begin() + End, [&](I4 C) { return Valence(C) == Dom; }) -
-                            List.begin();
-         kdOrderRange(List, Begin, Mid);
-         kdOrderRange(List, Mid, End);
-         return;
-      }
-   }
    kdOrderRange(List, Begin, End);
 }
 

@@ -29,7 +29,6 @@ const OptionName OptionTable[] = {
     {"ForceGeneric", &TuningOptions::ForceGeneric},
     {"KeepMaxEdges", &TuningOptions::KeepMaxEdges},
     {"NarrowTables", &TuningOptions::NarrowTables},
-    {"ValenceSort", &TuningOptions::ValenceSort},
     {"Graphs", &TuningOptions::Graphs},
 };
 } // namespace

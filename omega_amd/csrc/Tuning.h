@@ -32,8 +32,6 @@ struct TuningOptions {
    int KeepMaxEdges = 0; ///< 1: the file's maxEdges as the table width -- what a mesh with real 8-valent cells takes
    int NarrowTables = 1; ///< 0: one set of cell tables, MaxEdges wide -- what a hexagon mesh with heptagons takes when a ring
                          ///< table of it is not valid
-   // ---- local numbering (read when a Decomp is constructed with LocalOrder::KdTree)
-   int ValenceSort = 0; ///< 1: the cells of each group's dominant valence first (Decomp.cpp: kdOrder)
    // ---- HIP-graph replay: -1 = as each object's UseGraphs says, 0 = never, 1 = default on
    int Graphs = -1;
 };

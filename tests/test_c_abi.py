@@ -112,9 +112,9 @@ def test_options_api():
     # every option the library has (omega_amd/csrc/Tuning.h names, next to each, the mesh class that reaches the
     # structure it forces without the switch); the round-1..5 A/B knobs and the ProbeSlice measurement probe are gone
     survivors = (("MergeL1", 1), ("Pair", 1), ("TracerPatch", 1), ("SendBand", 1), ("BandOnComm", 1), ("ShrinkSweeps", 1),
-                 ("ForceGeneric", 0), ("KeepMaxEdges", 0), ("NarrowTables", 1), ("ValenceSort", 0), ("Graphs", -1))
+                 ("ForceGeneric", 0), ("KeepMaxEdges", 0), ("NarrowTables", 1), ("Graphs", -1))
     for gone in ("ProbeSlice", "ProbeBlocks", "EdgeMode", "FuseFinal", "FuseL3", "InlineOther", "FoldLists", "Alternate",
-                 "WaveWindow", "DomValence", "W", "TX", "TY", "Sweeps", "ChunkSplit", "TailSplit"):
+                 "WaveWindow", "ValenceSort", "DomValence", "W", "TX", "TY", "Sweeps", "ChunkSplit", "TailSplit"):
         with pytest.raises(oa.OmegaAmdError):
             oa.set_option(gone, 1)
     for name, default in survivors:
