@@ -143,6 +143,10 @@ TracerStore *&defaultStore() {
    return P;
 }
 } // namespace
+TracerStore::~TracerStore() {
+   if (defaultStore() == this) // never leave the static interface pointing at a store that is gone
+      defaultStore() = nullptr;
+}
 TracerStore *Tracers::init(const HorzMesh *Mesh, Halo *MeshHalo, int NVertLayers, int NTracers, int NTimeLevels) {
    ownedDefaultStore().reset(new TracerStore(Mesh, MeshHalo, NVertLayers, NTracers, NTimeLevels));
    return defaultStore() = ownedDefaultStore().get();

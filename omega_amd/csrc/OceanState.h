@@ -48,6 +48,9 @@ class OceanState : public Registry<OceanState> {
 class TracerStore {
  public:
    TracerStore(const HorzMesh *Mesh, Halo *MeshHalo, int NVertLayers, int NTracers, int NTimeLevels);
+   ~TracerStore(); ///< (a store that is the static interface's default stops being it)
+   TracerStore(const TracerStore &) = delete;
+   TracerStore &operator=(const TracerStore &) = delete;
    hipStream_t Stream = nullptr; ///< stream of the static `Tracers` interface's calls on this store
    I4 NTracers, NTimeLevels, NVertLayers, NCellsOwned, NCellsAll, NCellsSize;
    std::vector<Array3DReal> TracerArrays; ///< [NTimeLevels] (NTracers, NCellsSize, NVertLayers)
