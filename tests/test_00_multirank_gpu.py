@@ -117,6 +117,9 @@ HALO3 = ["--halo-width", 3, "--against-partitioned", "--eddy-diff4", 1.0e11]
     # the headline's shape per rank: 80 levels (five level chunks per workgroup), 6 tracers (LDS tile patches), k-d numbering
     (2, [*HALO3, "--nx", 64, "--ny", 32, "--levels", 80, "--tracers", 6, "--local-order", "kd", "--wire", "ipc"]),
     (4, [*HALO3, "--nx", 96, "--ny", 96, "--levels", 16, "--tracers", 6, "--partition", "graph", "--local-order", "kd", "--wire", "ipc"]),
+    # a halo narrower than the reference's default: still "whatever the reference prints" (every shortcut keyed on the halo
+    # width must fall back to full sweeps)
+    (2, ["--halo-width", 2, "--against-partitioned", "--eddy-diff4", 1.0e11, "--nx", 32, "--ny", 24, "--tracers", 2]),
     # three valences (pentagons, hexagons, heptagons: narrow tables + wide-cell lists) on three ranks
     (3, [*HALO3, "--mesh", "fib1500", "--levels", 4, "--tracers", 2, "--partition", "graph", "--local-order", "kd", "--wire", "ipc"]),
     # the other two schemes exchange once per step (RungeKutta2Stepper.cpp:27-73: two evaluations in between;
