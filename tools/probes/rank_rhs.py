@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--levels", type=int, default=80)
     ap.add_argument("--tracers", type=int, default=6)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--halo-width", type=int, default=4, help="HaloWidth of the N > 1 decompositions (bench.py: 4; the reference's default: 3)")
     a = ap.parse_args()
     K, NT = a.levels, a.tracers
     oa.device_init(0)
@@ -39,7 +40,7 @@ def main():
         cell_task = oa.partition_cells(gm, n, "graph")[0] if n > 1 else None
         rec = {}
         for r in sorted({min(int(x), n - 1) for x in a.ranks.split(",")}):
-            d = oa.Decomp(gm, n, r, 4 if n > 1 else 3, cell_task=cell_task, local_order="kd")
+            d = oa.Decomp(gm, n, r, a.halo_width if n > 1 else 3, cell_task=cell_task, local_order="kd")
             mesh = oa.HorzMesh(d, K)
             cells0 = d.get_array("CellID")[: mesh.NCellsAll] - 1
             edges0 = d.get_array("EdgeID")[: mesh.NEdgesAll] - 1
