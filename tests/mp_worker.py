@@ -6,7 +6,10 @@ mode cpu: Decomp + Halo exchange lists from the product's HOST code (no device),
           RK4 steps of the partitioned run against the single-rank oracle on owned elements.
 mode gpu: the full product path on the GPU -- C++ Halo::exchange* with HIP pack/unpack kernels,
           RungeKutta4Stepper::doStep -- with the messages staged through gloo (both ranks may
-          share one GPU), against the same single-rank oracle.
+          share one GPU), against the same single-rank oracle -- or, with --against-partitioned, against
+          the PARTITIONED oracle of the same world size and halo width on every local element (what the
+          reference itself prints at N ranks when the setting is not partition independent: its default
+          HaloWidth 3 with the del4 terms on, RungeKutta4Stepper.cpp:107).
 """
 import argparse
 import ctypes as C
