@@ -978,6 +978,13 @@ class Tendencies:
         out = [(L.omg_tend_kernel_name(i).decode(), ms[i] / ns.value) for i in range(nk.value)]
         return [(k, v) for k, v in out if k]
 
+    def device_ptr(self, which: int):
+        """omg_tend_device_ptr: (device address, number of values incl. the row padding) of LayerThicknessTend (0),
+        NormalVelocityTend (1), TracerTend (2)"""
+        p, n = C.POINTER(C.c_double)(), C.c_size_t()
+        _chk(lib().omg_tend_device_ptr(self.h, which, C.byref(p), C.byref(n)))
+        return C.cast(p, C.c_void_p).value, n.value
+
     def get(self, which: int) -> np.ndarray:
         m = self.mesh
         shape = [(m.NCellsSize, self.K), (m.NEdgesSize, self.K), (max(self.NT, 1), m.NCellsSize, self.K)][which]

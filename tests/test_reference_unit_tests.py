@@ -120,3 +120,50 @@ def test_time_level_rotation_like_the_reference_tests(ntl):
         tst.copy_to_host(2)
     with pytest.raises(oa.OmegaAmdError):
         tst.copy_to_host(-(ntl - 1))
+
+
+# ---------------------------------------------------------------------------------------------------------- TendenciesTest
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["ico5", "fib1500", "ico4_coast_lakes", "hex48x24_coast_mixed"])
+def test_tendencies_like_the_reference_test(name, fused):
+    """test/ocn/TendenciesTest.cpp:25-44, 150-212: the analytic state h = 2 + cos(lon) cos^4(lat), u from its vector field,
+    tracers 2 - cos(lon) cos^4(lat); EVERY tendency variable filled with NaN first; after computeAllTendencies the sums over
+    the owned elements are finite and non-zero -- i.e. every owned value was written, by the fused launches and by the
+    reference-structured sequence (and, beyond the reference's test, they are the oracle's values)."""
+    from tests.problem import Problem
+    oa.device_init(0)
+    g = named_mesh(name)
+    K, NT = 60, 3
+    P = Problem(g, K, NT)
+    m = P.mesh
+    L = m.local_arrays()
+    R = 6371220.0
+    sphere = "zCell" in g and float(np.abs(g["zCell"]).max()) > 0
+    lonc, latc = (L["LonCell"], L["LatCell"]) if sphere else (2 * np.pi * L["XCell"] / max(L["XCell"].max(), 1.0), 0.3 * np.ones_like(L["XCell"]))
+    lone, late = (L["LonEdge"], L["LatEdge"]) if sphere else (2 * np.pi * L["XEdge"] / max(L["XEdge"].max(), 1.0), 0.3 * np.ones_like(L["XEdge"]))
+    h = np.zeros((m.NCellsSize, K))
+    h[:] = (2 + np.cos(lonc) * np.cos(latc) ** 4)[:, None]
+    ux = -R * np.sin(lone) ** 2 * np.cos(late) ** 3
+    uy = -4 * R * np.sin(lone) * np.cos(lone) * np.cos(late) ** 3 * np.sin(late)
+    u = np.zeros((m.NEdgesSize, K))
+    u[:] = (1.0e-6 * (ux * np.cos(L["AngleEdge"]) + uy * np.sin(L["AngleEdge"])))[:, None]    # (scaled to m/s-sized values)
+    tr = np.zeros((NT, m.NCellsSize, K))
+    tr[:] = (2 - np.cos(lonc) * np.cos(latc) ** 4)[None, :, None] + 0.1 * np.arange(NT)[:, None, None]
+    h[-1] = u[-1] = 0.0
+    tr[:, -1] = 0.0
+    P.state.copy_to_device(h, u, 0)
+    P.tracers.copy_to_device(tr, 0)
+    P.tend.set_fused(fused)
+    for which in (0, 1, 2):
+        ptr, n = P.tend.device_ptr(which)
+        oa.copy_to_device(ptr, np.full(n, np.nan))
+    P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
+    oa.device_synchronize()
+    hT, uT, trT = P.tend.get(0), P.tend.get(1), P.tend.get(2)
+    nc, ne = m.NCellsOwned, m.NEdgesOwned
+    for nm, a in (("LayerThickTend", hT[:nc]), ("NormVelTend", uT[:ne]), ("TraceTend", trT[:NT, :nc])):
+        sm = float(a.sum())
+        assert np.isfinite(a).all() and np.isfinite(sm) and sm != 0.0, nm
+    oh, ou, otr = P.oracle.compute_all_tendencies(h, u, tr)
+    assert np.array_equal(hT[:nc], oh[:nc]) and np.array_equal(uT[:ne], ou[:ne]) and np.array_equal(trT[:NT, :nc], otr[:NT, :nc])
