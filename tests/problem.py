@@ -57,3 +57,15 @@ def max_rel_diff(a, b, scale=None):
         r = d / den
     r[~np.isfinite(r)] = 0.0 if np.array_equal(np.isnan(a), np.isnan(b)) else np.inf
     return float(r.max()) if r.size else 0.0
+
+
+def poison_tendencies(P):
+    """Every value of the three tendency arrays NaN (test/ocn/TendenciesTest.cpp:159-163 does so before its evaluation) --
+    the whole device arrays, row padding included; only the zero sentinel row, which no kernel writes, stays zero."""
+    pitch = oa.level_pitch(P.K)
+    for which, rows, planes in ((0, P.mesh.NCellsSize, 1), (1, P.mesh.NEdgesSize, 1), (2, P.mesh.NCellsSize, max(P.NT, 1))):
+        ptr, _ = P.tend.device_ptr(which)
+        poison = np.full((planes, rows, pitch), np.nan)
+        poison[:, -1, :] = 0.0
+        oa.copy_to_device(ptr, poison)
+

@@ -12,7 +12,7 @@ import pytest
 import omega_amd as oa
 from omega_amd.meshgen import planar_hex, spherical_voronoi, icosahedral_points, pad_max_edges
 from oracle import oracle as O
-from tests.problem import Problem, max_rel_diff
+from tests.problem import Problem, max_rel_diff, poison_tendencies
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
@@ -114,6 +114,14 @@ def _mk(case):
 def test_aux_state_compute_all(case):
     """AuxiliaryState::computeAll, array by array (reference-structured kernels)."""
     P = _mk(case)
+    # (r6, after test/ocn/TendenciesTest.cpp:159-163) every computed array starts as NaN: an owned element that no kernel
+    # writes cannot pass for one whose value happens to be what the allocation held
+    # (the zero sentinel row, which no kernel writes and missing neighbours read, stays zero)
+    for name in (*AUX_2D, "HTracersEdge", "Del2TracersCell"):
+        if name in AUX_2D or case[4] > 0:
+            poison = np.full(P.aux._shape(name), np.nan)
+            poison[..., -1, :] = 0.0
+            P.aux.set(name, poison)
     P.aux.compute_all(P.state, P.tracers)
     oa.device_synchronize()
     P.oracle.compute_all_aux(P.h, P.u, P.tr)
@@ -135,6 +143,7 @@ def test_compute_all_tendencies(case, fused):
     P = _mk(case)
     wind = case[5].get("WindForcingTendencyEnable")
     P.tend.set_fused(fused)
+    poison_tendencies(P)          # (r6) TendenciesTest.cpp:159-163: every tendency variable is NaN before the evaluation
     P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
     oa.device_synchronize()
     hT, uT, trT = P.oracle.compute_all_tendencies(P.h, P.u, P.tr)

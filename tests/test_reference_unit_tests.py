@@ -131,7 +131,7 @@ def test_tendencies_like_the_reference_test(name, fused):
     tracers 2 - cos(lon) cos^4(lat); EVERY tendency variable filled with NaN first; after computeAllTendencies the sums over
     the owned elements are finite and non-zero -- i.e. every owned value was written, by the fused launches and by the
     reference-structured sequence (and, beyond the reference's test, they are the oracle's values)."""
-    from tests.problem import Problem
+    from tests.problem import Problem, poison_tendencies
     oa.device_init(0)
     g = named_mesh(name)
     K, NT = 60, 3
@@ -155,9 +155,7 @@ def test_tendencies_like_the_reference_test(name, fused):
     P.state.copy_to_device(h, u, 0)
     P.tracers.copy_to_device(tr, 0)
     P.tend.set_fused(fused)
-    for which in (0, 1, 2):
-        ptr, n = P.tend.device_ptr(which)
-        oa.copy_to_device(ptr, np.full(n, np.nan))
+    poison_tendencies(P)
     P.tend.compute_all_tendencies(P.state, P.aux, P.tracers)
     oa.device_synchronize()
     hT, uT, trT = P.tend.get(0), P.tend.get(1), P.tend.get(2)
