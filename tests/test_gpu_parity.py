@@ -240,6 +240,14 @@ def test_time_steppers(kind, okind, fuse):
         st.set_option("FuseStageUpdates", fuse)
     ost = P.oracle.make_state(P.h, P.u, P.tr)
     m = P.mesh
+    # (r6) the NEW time level and the tendencies start as NaN (sentinel rows zero): a scheme must write every element of
+    # what it hands back, whatever the buffers held
+    nan_h, nan_u, nan_tr = np.full_like(P.h, np.nan), np.full_like(P.u, np.nan), np.full_like(P.tr, np.nan)
+    nan_h[-1] = nan_u[-1] = 0.0
+    nan_tr[:, -1] = 0.0
+    P.state.copy_to_device(nan_h, nan_u, 1)
+    P.tracers.copy_to_device(nan_tr, 1)
+    poison_tendencies(P)
     for step in range(3):
         st.do_step(P.state)
         oa.device_synchronize()
